@@ -1,0 +1,190 @@
+"""Pins the CPU oracle (numpy + C) to the golden vectors produced from the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import im_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    so = os.path.join(ROOT, "oracle", "libim_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def c_binary(lib, preds, thr, ge, img=None, bi=0, bo=0):
+    n, h, w, kb = preds.shape
+    hw = h * w
+    preds = np.ascontiguousarray(preds, np.float32)
+    final = np.zeros((kb, h, w), np.uint8)
+    im = np.zeros((h, w), np.uint8)
+    ims = np.zeros(kb, np.int64)
+    ps = np.zeros(kb, np.int64)
+    c = 0 if img is None else img.shape[-1]
+    img_out = None if img is None else np.zeros_like(img)
+    lib.oracle_im_binary(_p(preds, ctypes.c_float), n, hw, kb, ctypes.c_float(thr), int(ge),
+                         None if img is None else _p(np.ascontiguousarray(img), ctypes.c_uint8), c, bi, bo,
+                         None if img is None else _p(img_out, ctypes.c_uint8),
+                         _p(final, ctypes.c_uint8), _p(im, ctypes.c_uint8),
+                         _p(ims, ctypes.c_int64), _p(ps, ctypes.c_int64))
+    return final, im, ims, ps, img_out
+
+
+def c_multi(lib, probs, img=None, bi=0, bo=0):
+    n, h, w, k = probs.shape
+    probs = np.ascontiguousarray(probs, np.float32)
+    final = np.zeros((h, w), np.uint8)
+    im = np.zeros((h, w), np.uint8)
+    ims = np.zeros(1, np.int64)
+    pres = np.zeros((n, k), np.uint8)
+    c = 0 if img is None else img.shape[-1]
+    img_out = None if img is None else np.zeros_like(img)
+    lib.oracle_im_multiclass(_p(probs, ctypes.c_float), n, h * w, k,
+                             None if img is None else _p(np.ascontiguousarray(img), ctypes.c_uint8), c, bi, bo,
+                             None if img is None else _p(img_out, ctypes.c_uint8),
+                             _p(final, ctypes.c_uint8), _p(im, ctypes.c_uint8), _p(ims, ctypes.c_int64),
+                             _p(pres, ctypes.c_uint8))
+    return final, im, ims[0], pres, img_out
+
+
+def test_binary_golden(golden_dir, c_oracle):
+    g = load(golden_dir, "im_binary.npz")
+    assert len(g["cases"]) >= 30
+    for k in g["cases"]:
+        preds = g[k + "_preds"][:, 0]           # [N,H,W,1]
+        r = O.im_binary(preds, 0.5, False)
+        assert np.array_equal(r["final"][0], g[k + "_final"]), k
+        assert np.array_equal(r["im"], g[k + "_im"]), k
+        assert [int(r["im_size"]), int(r["pred_size"])] == g[k + "_sizes"].tolist(), k
+        f, im, ims, ps, _ = c_binary(c_oracle, preds, 0.5, False)
+        assert np.array_equal(f[0], g[k + "_final"]) and np.array_equal(im, g[k + "_im"]), k
+        assert [int(ims[0]), int(ps[0])] == g[k + "_sizes"].tolist(), k
+
+
+def test_hela_golden(golden_dir, c_oracle):
+    g = load(golden_dir, "im_hela.npz")
+    for k in g["cases"]:
+        preds = g[k + "_preds"][:, 0]           # [N,H,W,3]
+        r = O.im_binary(preds, 0.5, True)
+        for c, nm in enumerate(("alive", "dead", "pos")):
+            assert np.array_equal(r["final"][c], g[f"{k}_{nm}"]), (k, nm)
+        assert np.array_equal(r["im"], g[k + "_im"]), k
+        assert int(r["im_size"]) == int(g[k + "_sizes"][0]), k
+        f, im, ims, ps, _ = c_binary(c_oracle, preds, 0.5, True)
+        assert np.array_equal(f, r["final"]) and np.array_equal(im, r["im"]) and int(ims.sum()) == int(r["im_size"])
+
+
+def test_multiclass_golden(golden_dir, c_oracle):
+    g = load(golden_dir, "im_multiclass.npz")
+    assert len(g["cases"]) >= 80
+    for k in g["cases"]:
+        probs = g[k + "_preds"][:, 0]           # [N,H,W,K]
+        r = O.im_multiclass(probs, True)
+        assert np.array_equal(r["final"], g[k + "_final"]), k
+        assert np.array_equal(r["im"], g[k + "_im"]), k
+        assert int(r["im_size"]) == int(g[k + "_sizes"][0]), k
+        assert int(r["lists_equal"]) == int(g[k + "_lists_equal"][0]), k
+        assert O.im_multiclass(probs, False)["lists_equal"] is True
+        f, im, ims, pres, _ = c_multi(c_oracle, probs)
+        assert np.array_equal(f, g[k + "_final"]) and np.array_equal(im, g[k + "_im"]) and int(ims) == int(r["im_size"])
+        assert np.array_equal(pres, r["presence"]), k
+
+
+def _writer_expect_isic(g, tag, bi, bo, filt):
+    """Re-derive the reference writer's output files from the oracle primitives."""
+    names = [str(n) for n in g["names"]]
+    out, sizes = {}, []
+    for i, name in enumerate(names):
+        bgr = g[f"img_{i}"]
+        preds = np.stack([g[f"pred_{i}_{n}"][0] for n in range(2)], 0)
+        r = O.im_binary(preds, 0.5, False)
+        sizes.append(r["im_size"])
+        img, (mask,) = O.block(bgr, [r["final"][0]], r["im"], bi, bo)
+        if O.keep_isic(r["pred_size"], r["im_size"], filt):
+            out["images/" + name] = img
+            out["masks/" + name] = mask
+        out["im/" + name] = r["im"]
+    return out, O.mean_im_size(sizes)
+
+
+def test_writer_isic_golden(golden_dir):
+    g = load(golden_dir, "writer_isic.npz")
+    for tag in g["combos"]:
+        tag = str(tag)
+        bi, bo, filt = (tag[2] == "1"), (tag[6] == "1"), (tag[9] == "1")
+        exp, mean = _writer_expect_isic(g, tag, bi, bo, filt)
+        files = sorted(str(f) for f in g[tag + "_files"])
+        assert files == sorted(exp), tag
+        for f in files:
+            assert np.array_equal(exp[f], g[tag + "/" + f]), (tag, f)
+        assert mean == float(g[tag + "_mean"][0])
+    # the filter must actually drop something in this fixture
+    assert len(g["bi1_bo1_f1_files"]) < len(g["bi1_bo1_f0_files"])
+
+
+def test_writer_multi_golden(golden_dir):
+    g = load(golden_dir, "writer_multi.npz")
+    names = [str(n) for n in g["names"]]
+    for tag in g["combos"]:
+        tag = str(tag)
+        bi, bo, filt = (tag[2] == "1"), (tag[6] == "1"), (tag[9] == "1")
+        exp, sizes = {}, []
+        for i, name in enumerate(names):
+            bgr = g[f"img_{i}"]
+            probs = np.stack([g[f"pred_{i}_{n}"][0] for n in range(3)], 0)
+            r = O.im_multiclass(probs, filt)
+            sizes.append(r["im_size"])
+            img, (mask,) = O.block(bgr, [r["final"]], r["im"], bi, bo)
+            if (not filt) or r["lists_equal"]:
+                exp["images/" + name] = img
+                exp["masks/" + name] = mask
+            exp["im/" + name] = r["im"]
+        files = sorted(str(f) for f in g[tag + "_files"])
+        assert files == sorted(exp), tag
+        for f in files:
+            assert np.array_equal(exp[f], g[tag + "/" + f]), (tag, f)
+        assert O.mean_im_size(sizes) == float(g[tag + "_mean"][0])
+    assert len(g["bi1_bo1_f1_files"]) < len(g["bi1_bo1_f0_files"])
+
+
+def test_c_oracle_blocking(c_oracle):
+    rng = np.random.default_rng(0)
+    preds = rng.random((3, 9, 11, 1), dtype=np.float32)
+    img = rng.integers(1, 255, (9, 11, 3)).astype(np.uint8)
+    r = O.im_binary(preds)
+    for bi in (0, 1):
+        for bo in (0, 1):
+            f, im, ims, ps, io = c_binary(c_oracle, preds, 0.5, False, img, bi, bo)
+            ei, (em,) = O.block(img, [r["final"][0]], r["im"], bi, bo)
+            assert np.array_equal(io, ei) and np.array_equal(f[0], em) and np.array_equal(im, r["im"])
+
+
+def test_morphology_properties():
+    rng = np.random.default_rng(1)
+    m = (rng.random((20, 30)) > 0.6).astype(np.uint8) * 255
+    for k in (3, 5):
+        e, d = O.erode(m, k), O.dilate(m, k)
+        assert np.all(e <= m) and np.all(d >= m)
+        assert np.array_equal(O.erode(np.full_like(m, 255), k), np.full_like(m, 255))  # border never erodes a full mask
+        assert np.array_equal(O.dilate(np.zeros_like(m), k), np.zeros_like(m))
+    one = np.zeros((9, 9), np.uint8)
+    one[4, 4] = 255
+    assert O.dilate(one, 3).sum() == 9 * 255 and O.dilate(one, 5).sum() == 25 * 255
+    assert np.array_equal(O.erode(O.dilate(one, 3), 3), one)
