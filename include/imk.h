@@ -1,0 +1,178 @@
+/* imk.h -- C ABI of libimk.so: the MI355X (gfx950) implementation of the Inconsistency-Mask hot path.
+ *
+ * The reference (MichaelVorndran/InconsistencyMasks) is pure Python and has no FFI/plugin layer; the
+ * boundary it offers for this path is a set of Python functions.  Each entry
+ * point below names the reference call site(s) whose arithmetic it replaces (file:line relative to the
+ * reference checkout).  The Python host layer (inconsistencymasks_amd/) binds these with ctypes and
+ * presents the reference's own function names on top (functions.py / unet.py mirrors).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative IMK_E* code for bad arguments, a positive value = hipError_t;
+ *   - never throw, never allocate or free caller memory, never synchronise: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and the caller owns every buffer until
+ *     it has synchronised that stream;
+ *   - all pointers are DEVICE pointers unless a parameter says "host";
+ *   - re-entrant and thread-safe: no global state besides read-only code objects.
+ *   - images and masks are uint8, NHWC; probabilities float32 NHWC; sizes int64.
+ */
+#ifndef IMK_H
+#define IMK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMK_VERSION 100 /* 0.1.0 */
+
+enum {
+    IMK_OK = 0,
+    IMK_EINVAL = -1,      /* null pointer / non-positive size / unsupported combination */
+    IMK_EUNSUPPORTED = -2,/* shape outside what the kernels cover (e.g. more than 64 classes) */
+    IMK_EWORKSPACE = -3,  /* workspace too small */
+};
+
+int imk_version(void);
+const char *imk_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Inconsistency-mask kernels
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Binary / HeLa IM.  Replaces get_im_prediction_binary (functions.py:3140-3162: `> thr`, Kb = 1),
+ * get_im_prediction_hela (functions.py:3165-3202: `>= thr`, Kb = 3, combined IM = max, size = sum),
+ * pred_masks_to_im_binary (functions.py:3104-3120) and the blocking of functions.py:2867-2874, for a
+ * whole batch in one launch.
+ *   preds      [N,B,H,W,Kb] float32   probabilities of the N ensemble members
+ *   img        [B,H,W,C] uint8 or NULL (no image blocking)
+ *   img_out    [B,H,W,C] uint8 (ignored when img == NULL); = img with IM pixels zeroed if block_in
+ *   masks_out  [B,Kb,H,W] uint8 {0,255}; IM pixels zeroed if block_out
+ *   im_out     [B,H,W]   uint8 {0,255}  (max over the Kb channel IMs)
+ *   im_size    [B,Kb] int64, pred_size [B,Kb] int64   -- counted BEFORE blocking, like the reference
+ * NaN votes 0 under both comparison operators.                                                        */
+int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int kb,
+                  float thr, int cmp_ge,
+                  const uint8_t *img, int c, int block_in, int block_out,
+                  uint8_t *img_out, uint8_t *masks_out, uint8_t *im_out,
+                  int64_t *im_size, int64_t *pred_size, void *stream);
+
+/* Multi-class IM.  Replaces get_im_prediction_multiclass (functions.py:3206-3238: argmax, first
+ * maximum wins), pred_masks_to_im_multiclass (functions.py:3123-3137) and the blocking of
+ * functions.py:3055-3062.
+ *   probs      [N,B,H,W,K] float32, K <= 64
+ *   final_out  [B,H,W] uint8 class ids (0 where the models disagree; zeroed on IM pixels if block_out --
+ *              the same thing, kept for symmetry with the reference's order of operations)
+ *   im_out     [B,H,W] uint8 {0,255}
+ *   im_size    [B] int64
+ *   presence   [N,B,K] uint8 or NULL: 1 where model n predicts class k somewhere in image b (the
+ *              `np.unique` sets of functions.py:3226, for the unique-set filter of :3231-3234)        */
+int imk_im_multiclass(const float *probs, int n_models, int batch, int h, int w, int k,
+                      const uint8_t *img, int c, int block_in, int block_out,
+                      uint8_t *img_out, uint8_t *final_out, uint8_t *im_out,
+                      int64_t *im_size, uint8_t *presence, void *stream);
+
+/* k x k all-ones erosion (op = 0) / dilation (op = 1) of [B,H,W] uint8 masks, out-of-image taps ignored.
+ * Replaces cv2.erode / cv2.dilate at functions.py:2858-2864 (dead in every shipped config: EK = DK = 0). */
+int imk_morph(const uint8_t *src, uint8_t *dst, int batch, int h, int w, int ksize, int op, void *stream);
+
+/* image[im>0] = 0 (all C channels) and mask[im>0] = 0 for n_masks [B,H,W] masks packed as [B,n_masks,H,W]:
+ * the blocking step of functions.py:2867-2874 when it has to run AFTER morphology changed the IM.
+ * In place.  img or masks may be NULL.                                                                */
+int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *masks, int n_masks,
+                    int batch, int h, int w, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tiny U-Net (unet.py:4-67): plan, parameters, forward, fused forward+IM, training step
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct imk_unet_cfg {
+    int h, w;        /* input height / width; multiples of 16 (4 poolings) */
+    int c_in;        /* image channels (1 or 3)                              */
+    int n_out;       /* output maps K (unet.py:63)                           */
+    int ch[5];       /* int(16a), int(32a), int(64a), int(128a), int(256a)   (unet.py:49-56) */
+    int act_out;     /* 0 = sigmoid, 1 = softmax                             */
+} imk_unet_cfg;
+
+typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory */
+
+int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out);
+void imk_unet_plan_destroy(imk_unet_plan *plan);
+
+/* Flat fp32 parameter vector.  Trainable section first (what AdamW and the gradient all-reduce see),
+ * in unet.py creation order: per Conv2D kernel [kh][kw][cin][cout] (Keras HWIO) then bias [cout]; per
+ * BatchNormalization gamma then beta.  Then the non-trainable section: per BN moving_mean, moving_var. */
+int imk_unet_param_count(const imk_unet_plan *plan, int64_t *total, int64_t *trainable);
+
+typedef struct imk_layer_info {
+    char name[16];   /* "in.c", "e1.c3", "e1.c1", "e1.bn", "b.c3", ..., "d6.ca", "d6.bna", ..., "out" */
+    int kind;        /* 0 = conv, 1 = batch-norm */
+    int ksize, cin, cout;
+    int64_t off_w, off_b;         /* conv: kernel, bias;   bn: gamma, beta   (offsets in floats) */
+    int64_t off_mean, off_var;    /* bn only */
+} imk_layer_info;
+int imk_unet_num_layers(const imk_unet_plan *plan);
+int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer_info *out);
+
+/* fp16 copies of the conv kernels in MFMA-fragment order (forward and transposed/flipped for dgrad),
+ * folded BN scale/shift.  Re-run after every change of `params`.  train = 0 folds the moving statistics
+ * into scale/shift (inference); in training the batch statistics are produced by the step itself. */
+int64_t imk_unet_packed_bytes(const imk_unet_plan *plan);
+int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream);
+
+/* Workspace (activations, gradients, reduction scratch).  mode 0 = inference, 1 = training. */
+int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode);
+
+/* Batched inference: replaces model.predict at functions.py:3157, 3184, 3224 (and the batch-64 form at
+ * :1120).  x [B,H,W,c_in] uint8 (the model divides by 255 itself, unet.py:5) -> probs [B,H,W,n_out] f32. */
+int imk_unet_forward(const imk_unet_plan *plan, const float *params, const void *packed,
+                     const uint8_t *x, int batch, float *probs, void *workspace, int64_t workspace_bytes,
+                     void *stream);
+
+/* Debug/parity: after imk_unet_forward or a training step, byte offset/shape of a stored intermediate
+ * inside the workspace (fp16, NHWC with the channel count padded to a multiple of 8).
+ * which: 0 = conv output of layer `layer_idx` (post-ReLU, pre-BN).  Returns IMK_EINVAL if not stored. */
+int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
+                         int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
+
+/* Ensemble inference fused with the IM chain: N models' forward passes, then head -> threshold/argmax ->
+ * agreement -> IM -> blocking without writing the probability stack.  One call = functions.py:2844-2887
+ * minus file I/O, for a batch.  `params`/`packed` are arrays (host) of n_models device pointers.
+ * binary heads (act_out = 0): outputs as imk_im_binary;  softmax heads: as imk_im_multiclass
+ * (masks_out = final_out [B,H,W], pred_size unused, presence optional).                                */
+int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
+                        const float *const *params, const void *const *packed,
+                        const uint8_t *x, int batch, float thr, int cmp_ge,
+                        const uint8_t *img, int block_in, int block_out,
+                        uint8_t *img_out, uint8_t *masks_out, uint8_t *im_out,
+                        int64_t *im_size, int64_t *pred_size, uint8_t *presence,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Training (functions.py:207-218, one step of model.fit): forward with batch statistics, loss,
+ * backward, optimizer.  Split in two so that a data-parallel caller can all-reduce `grads` in between.
+ *   loss_kind 0 = 'mse' on {0,1} targets y u8 [B,H,W,n_out]   (ISIC, HeLa)
+ *             1 = categorical cross-entropy, y u8 [B,H,W] class ids (one-hot formed on the fly)
+ *   grads     [trainable] float32, UNSCALED gradient of the mean loss
+ *   stats     device float[4]: {loss, found_inf (0/1), loss_scale used, reserved}
+ *   state     device buffer of imk_unet_state_bytes(): Adam m, v, step counter, dynamic loss scale
+ * imk_unet_fwd_bwd also updates the BN moving statistics in `params` (momentum 0.99).                  */
+int64_t imk_unet_state_bytes(const imk_unet_plan *plan);
+int imk_unet_state_init(const imk_unet_plan *plan, void *state, void *stream);
+int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state,
+                     const uint8_t *x, const uint8_t *y, int batch, int loss_kind,
+                     float *grads, float *stats, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* tensorflow_addons AdamW (functions.py:215): var -= wd*var; Adam(b1,b2,eps) with bias-corrected lr.
+ * Skips the update (and halves the dynamic loss scale) when stats[1] != 0; re-packs the weights.
+ * grad_scale multiplies grads first (1/world_size after a sum all-reduce).                            */
+int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, void *state,
+                        const float *grads, const float *stats, float grad_scale,
+                        float lr, float wd, float beta1, float beta2, float eps, void *stream);
+
+/* Host-readable copy of a name for a layer/tensor kind is not needed beyond imk_layer_info. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMK_H */

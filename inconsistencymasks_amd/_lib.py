@@ -1,0 +1,82 @@
+"""ctypes binding of libimk.so (include/imk.h).  There is no fallback: if the library is missing or an
+entry point is absent, importing this module raises."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libimk.so")
+
+c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+
+
+class UnetCfg(ctypes.Structure):
+    _fields_ = [("h", c_int), ("w", c_int), ("c_in", c_int), ("n_out", c_int),
+                ("ch", c_int * 5), ("act_out", c_int)]
+
+
+class LayerInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 16), ("kind", c_int), ("ksize", c_int), ("cin", c_int), ("cout", c_int),
+                ("off_w", c_int64), ("off_b", c_int64), ("off_mean", c_int64), ("off_var", c_int64)]
+
+
+# name -> (restype, argtypes); must list every symbol include/imk.h declares
+SIGNATURES = {
+    "imk_version": (c_int, []),
+    "imk_error_string": (ctypes.c_char_p, [c_int]),
+    "imk_im_binary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                              c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "imk_im_multiclass": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "imk_morph": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "imk_block_apply": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "imk_unet_plan_create": (c_int, [ctypes.POINTER(UnetCfg), ctypes.POINTER(c_void_p)]),
+    "imk_unet_plan_destroy": (None, [c_void_p]),
+    "imk_unet_param_count": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "imk_unet_num_layers": (c_int, [c_void_p]),
+    "imk_unet_layer_info": (c_int, [c_void_p, c_int, ctypes.POINTER(LayerInfo)]),
+    "imk_unet_packed_bytes": (c_int64, [c_void_p]),
+    "imk_unet_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imk_unet_workspace_bytes": (c_int64, [c_void_p, c_int, c_int]),
+    "imk_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "imk_unet_tensor_info": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64),
+                                     ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                     ctypes.POINTER(c_int)]),
+    "imk_unet_forward_im": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                    c_void_p, c_int, c_float, c_int, c_void_p, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p]),
+    "imk_unet_state_bytes": (c_int64, [c_void_p]),
+    "imk_unet_state_init": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "imk_unet_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                    c_float, c_float, c_float, c_float, c_float, c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class ImkError(RuntimeError):
+    pass
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib.imk_error_string(code)
+        raise ImkError(f"{what}: imk error {code} ({msg.decode() if msg else '?'})")

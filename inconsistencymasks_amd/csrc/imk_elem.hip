@@ -1,0 +1,497 @@
+// Streaming kernels around the convolutions: BatchNorm statistics / backward, output head, loss gradient,
+// fused AdamW.  All are HBM-bound; every tensor access is a 16-byte (8 x fp16) vector per lane.
+//
+// Reference ops replaced (third-party TF/Keras/TFA, call sites): BatchNormalization unet.py:7,16,27,35,41;
+// head Conv2D(dtype float32)+sigmoid/softmax unet.py:63; losses 'mse' / CategoricalCrossentropy
+// (ISIC_2018/09_ISIC_2018_IM.py:110, SUIM/10_SUIM_IM.py:114); tfa AdamW functions.py:215;
+// Keras LossScaleOptimizer (dynamic loss scaling under mixed_float16).
+#include "imk_elem.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;       // Keras BatchNormalization default epsilon
+constexpr float BN_MOMENTUM = 0.99f;  // Keras default momentum
+
+// ---- BatchNorm forward statistics ---------------------------------------------------------------
+// partial [n_part][2*cs] (sum | sumsq) -> scale/shift for the consumers, saved mean/invstd for backward,
+// moving statistics update.  One block per channel, fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int n_part, int c, int cs,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ mov_mean,
+                                                          float *__restrict__ mov_var, float *__restrict__ scale,
+                                                          float *__restrict__ shift, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd) {
+    const int ch = blockIdx.x;
+    const int t = threadIdx.x;
+    if (ch >= c) {  // padded channels: identity-zero
+        if (t == 0) { scale[ch] = 0.f; shift[ch] = 0.f; save_mean[ch] = 0.f; save_invstd[ch] = 0.f; }
+        return;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = t; i < n_part; i += 256) {
+        s1 += (double)partial[(size_t)i * 2 * cs + ch];
+        s2 += (double)partial[(size_t)i * 2 * cs + cs + ch];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[t] = s1; r2[t] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { r1[t] += r1[t + o]; r2[t] += r2[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double mean = r1[0] / count;
+        double var = r2[0] / count - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        const float sc = gamma[ch] * invstd;
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - (float)mean * sc;
+        save_mean[ch] = (float)mean;
+        save_invstd[ch] = invstd;
+        mov_mean[ch] = mov_mean[ch] * BN_MOMENTUM + (float)mean * (1.f - BN_MOMENTUM);
+        mov_var[ch] = mov_var[ch] * BN_MOMENTUM + (float)var * (1.f - BN_MOMENTUM);
+    }
+}
+
+// inference: fold the moving statistics
+__global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ mean, const float *__restrict__ var, int c, int cs,
+                               float *__restrict__ scale, float *__restrict__ shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= cs) return;
+    if (ch >= c) { scale[ch] = 0.f; shift[ch] = 0.f; return; }
+    const float sc = gamma[ch] / sqrtf(var[ch] + BN_EPS);
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - mean[ch] * sc;
+}
+
+// ---- BatchNorm backward, pass 1: assemble dy (if it has more than one source) and reduce --------------
+// Each thread owns one 8-channel chunk index for its whole grid-stride walk (grid size is a multiple of
+// nc8), so the per-channel sums live in registers until one LDS reduction per block.
+struct BnPrepArgs {
+    int mode;             // 0 DIRECT, 1 POOL, 2 SUM2
+    const f16 *g_direct;  // DIRECT: dy [B,H,W,cs]; POOL: skip-branch gradient at full res (may be null)
+    const f16 *g_other;   // POOL: dP [B,H/2,W/2,cs]; SUM2: dU [B,2H,2W,cs]
+    const f16 *z;         // [B,H,W,cs] the BN's input (post-ReLU conv output)
+    const float *sc, *sh; // POOL: forward affine, to recompute which window element was the max
+    f16 *dy_out;          // POOL / SUM2: assembled dy
+    float *partial;       // [gridDim.x][2*cs]
+    int B, H, W, cs;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
+    const int nc8 = a.cs / 8;
+    const long long n_items = (long long)a.B * a.H * a.W * nc8;
+    const long long G = (long long)gridDim.x * 256;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(gid % nc8);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    float sc[8], sh[8];
+    if (a.mode == 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c8 * 8 + j]; sh[j] = a.sh[c8 * 8 + j]; }
+    for (long long it = gid; it < n_items; it += G) {
+        const long long pix = it / nc8;
+        const f16x8 z = *reinterpret_cast<const f16x8 *>(a.z + it * 8);
+        f16x8 dy;
+        if (a.mode == 0) {
+            dy = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
+        } else if (a.mode == 1) {
+            const int x = (int)(pix % a.W);
+            const long long r = pix / a.W;
+            const int y = (int)(r % a.H);
+            const int b = (int)(r / a.H);
+            const int Hh = a.H / 2, Wh = a.W / 2;
+            const f16x8 dp = *reinterpret_cast<const f16x8 *>(a.g_other + (((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * nc8 + c8) * 8);
+            // window elements in row-major order; the first maximum takes the gradient
+            const size_t w00 = (((size_t)(b * a.H + (y & ~1)) * a.W + (x & ~1)) * nc8 + c8) * 8;
+            const f16x8 z00 = *reinterpret_cast<const f16x8 *>(a.z + w00);
+            const f16x8 z01 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.cs);
+            const f16x8 z10 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.W * a.cs);
+            const f16x8 z11 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.W * a.cs + a.cs);
+            const int me = (y & 1) * 2 + (x & 1);
+            f16x8 gd = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.g_direct) gd = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16 v0 = (f16)((float)z00[j] * sc[j] + sh[j]), v1 = (f16)((float)z01[j] * sc[j] + sh[j]);
+                const f16 v2 = (f16)((float)z10[j] * sc[j] + sh[j]), v3 = (f16)((float)z11[j] * sc[j] + sh[j]);
+                int best = 0;
+                f16 bv = v0;
+                if (v1 > bv) { bv = v1; best = 1; }
+                if (v2 > bv) { bv = v2; best = 2; }
+                if (v3 > bv) { bv = v3; best = 3; }
+                dy[j] = (f16)((float)gd[j] + (best == me ? (float)dp[j] : 0.f));
+            }
+            *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
+        } else {
+            const int x = (int)(pix % a.W);
+            const long long r = pix / a.W;
+            const int y = (int)(r % a.H);
+            const int b = (int)(r / a.H);
+            const int H2 = a.H * 2, W2 = a.W * 2;
+            const size_t u00 = (((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * nc8 + c8) * 8;
+            const f16x8 u0 = *reinterpret_cast<const f16x8 *>(a.g_other + u00);
+            const f16x8 u1 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)a.cs);
+            const f16x8 u2 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs);
+            const f16x8 u3 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs + a.cs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dy[j] = (f16)(((float)u0[j] + (float)u1[j]) + ((float)u2[j] + (float)u3[j]));
+            *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)dy[j]; s1[j] += d; s2[j] += d * (float)z[j]; }
+    }
+    // block reduction: threads with equal c8 are summed in thread order (deterministic)
+    __shared__ float s_r[256][17];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_r[threadIdx.x][j] = s1[j]; s_r[threadIdx.x][8 + j] = s2[j]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * a.cs; o += 256) {
+        const int which = o / a.cs, ch = o - which * a.cs;
+        const int want = ch >> 3, j = ch & 7;
+        const int first = (int)(((long long)want - ((long long)blockIdx.x * 256) % nc8 + nc8) % nc8);
+        float v = 0.f;
+        for (int tt = first; tt < 256; tt += nc8) v += s_r[tt][which * 8 + j];
+        a.partial[(size_t)blockIdx.x * 2 * a.cs + o] = v;
+    }
+}
+
+// pass 2: per-channel coefficients  dz = A*dy + Bc*z + Cc  and the gamma/beta gradients
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float *__restrict__ partial, int n_part, int c, int cs,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ save_mean,
+                                                          const float *__restrict__ save_invstd,
+                                                          const float *__restrict__ inv_scale_ptr,
+                                                          float *__restrict__ coef /*[3][cs]*/, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta, float *__restrict__ found_inf) {
+    const int ch = blockIdx.x, t = threadIdx.x;
+    if (ch >= c) {
+        if (t == 0) { coef[ch] = 0.f; coef[cs + ch] = 0.f; coef[2 * cs + ch] = 0.f; }
+        return;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = t; i < n_part; i += 256) {
+        s1 += (double)partial[(size_t)i * 2 * cs + ch];
+        s2 += (double)partial[(size_t)i * 2 * cs + cs + ch];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[t] = s1; r2[t] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { r1[t] += r1[t + o]; r2[t] += r2[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double S1 = r1[0], S2 = r2[0];
+        const double mean = save_mean[ch], invstd = save_invstd[ch];
+        const double dg = (S2 - mean * S1) * invstd;   // sum dy * zhat
+        const double A = (double)gamma[ch] * invstd;
+        coef[ch] = (float)A;
+        coef[cs + ch] = (float)(-A * invstd * dg / count);
+        coef[2 * cs + ch] = (float)(-A * S1 / count + A * mean * invstd * dg / count);
+        const float inv = *inv_scale_ptr;
+        const float g1 = (float)dg * inv, g2 = (float)S1 * inv;
+        if (!isfinite(g1) || !isfinite(g2)) *found_inf = 1.0f;
+        dgamma[ch] = g1;
+        dbeta[ch] = g2;
+    }
+}
+
+// pass 3: dA = (A*dy + Bc*z + Cc) * [z > 0]   (BN backward + ReLU backward of the conv that produced z)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f16 *__restrict__ dy, const f16 *__restrict__ z,
+                                                           const float *__restrict__ coef, int cs, long long n_items,
+                                                           f16 *__restrict__ dA) {
+    extern __shared__ float s_c[];
+    for (int i = threadIdx.x; i < 3 * cs; i += 256) s_c[i] = coef[i];
+    __syncthreads();
+    const int nc8 = cs / 8;
+    const long long G = (long long)gridDim.x * 256;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < n_items; it += G) {
+        const int c8 = (int)(it % nc8);
+        const f16x8 d = *reinterpret_cast<const f16x8 *>(dy + it * 8);
+        const f16x8 zz = *reinterpret_cast<const f16x8 *>(z + it * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = c8 * 8 + j;
+            const float zf = (float)zz[j];
+            const float v = s_c[ch] * (float)d[j] + s_c[cs + ch] * zf + s_c[2 * cs + ch];
+            o[j] = (zf > 0.f) ? (f16)v : (f16)0.f;
+        }
+        *reinterpret_cast<f16x8 *>(dA + it * 8) = o;
+    }
+}
+
+// ---- output head: BN on load -> 1x1 conv in fp32 -> sigmoid / softmax --------------------------------
+// one thread per pixel; weights broadcast from LDS.  K <= 64.
+template <int CS>
+__global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, const float *__restrict__ sc,
+                                                   const float *__restrict__ sh, const float *__restrict__ w /*[cin][K]*/,
+                                                   const float *__restrict__ bias, int cin, int K, int softmax,
+                                                   long long n_pix, float *__restrict__ probs) {
+    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
+    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
+    for (int i = threadIdx.x; i < K * CS; i += 256) {
+        const int k = i / CS, c = i - k * CS;
+        s_w[i] = (c < cin) ? w[(size_t)c * K + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < K; i += 256) s_b[i] = bias[i];
+    for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
+    __syncthreads();
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    float xin[CS];
+#pragma unroll
+    for (int q = 0; q < CS / 8; ++q) {
+        const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+    }
+    float *out = probs + p * K;
+    if (!softmax) {
+        for (int k = 0; k < K; ++k) {
+            float acc = s_b[k];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
+            out[k] = 1.0f / (1.0f + expf(-acc));
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            float acc = s_b[k];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
+            out[k] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) { const float e = expf(out[k] - mx); out[k] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int k = 0; k < K; ++k) out[k] *= inv;
+    }
+}
+
+// ---- loss + gradient w.r.t. the logits ------------------------------------------------------------
+// mse:  L = mean_{all elements}(p - t)^2, dlogit = S * 2 (p - t) / Ntot * p (1 - p)      (sigmoid head)
+// cce:  L = mean_{pixels} -log(p_t), dlogit_k = S * (p_k - [k == t]) / Npix   (softmax head; Keras takes the
+//       softmax ACTIVATION's cached logits, so there is no probability clipping in loss or gradient; p_t is only
+//       floored at FLT_MIN so that an fp32 underflow reports 87.3 instead of inf)
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ probs, const uint8_t *__restrict__ y,
+                                                        int K, int cs, int kind, long long n_pix,
+                                                        const float *__restrict__ loss_scale_ptr,
+                                                        f16 *__restrict__ dlogit, float *__restrict__ loss_partial) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float S = *loss_scale_ptr;
+    float l = 0.f;
+    if (p < n_pix) {
+        const float *pr = probs + p * K;
+        f16 *d = dlogit + p * cs;
+        if (kind == 0) {
+            const float inv_n = 1.0f / ((float)n_pix * (float)K);
+            for (int k = 0; k < cs; ++k) {
+                float g = 0.f;
+                if (k < K) {
+                    const float pk = pr[k], t = (float)y[p * K + k];
+                    const float e = pk - t;
+                    l += e * e;
+                    g = S * 2.0f * e * inv_n * pk * (1.0f - pk);
+                }
+                d[k] = (f16)g;
+            }
+        } else {
+            const int t = y[p];
+            const float inv_n = 1.0f / (float)n_pix;
+            for (int k = 0; k < cs; ++k) {
+                float g = 0.f;
+                if (k < K) {
+                    const float pk = pr[k];
+                    if (k == t) l = -logf(fmaxf(pk, 1.17549435e-38f));
+                    g = S * (pk - (k == t ? 1.0f : 0.0f)) * inv_n;
+                }
+                d[k] = (f16)g;
+            }
+        }
+    }
+    __shared__ float s_l[4];
+    l = wave_sum<64>(l);
+    if ((threadIdx.x & 63) == 0) s_l[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int n, double denom,
+                                                            const ImkCtl *__restrict__ ctl, float *__restrict__ stats) {
+    __shared__ double r[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    r[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = (float)(r[0] / denom);
+        stats[1] = ctl->found_inf;
+        stats[2] = ctl->loss_scale;
+        stats[3] = (float)ctl->step;
+    }
+}
+
+// ---- optimizer --------------------------------------------------------------------------------------
+__global__ void ctl_init_kernel(ImkCtl *ctl) {
+    ctl->loss_scale = 32768.0f;  // Keras LossScaleOptimizer initial_scale = 2^15
+    ctl->inv_loss_scale = 1.0f / 32768.0f;
+    ctl->good_steps = 0;
+    ctl->step = 0;
+    ctl->found_inf = 0.f;
+}
+
+__global__ void ctl_begin_step_kernel(ImkCtl *ctl) { ctl->found_inf = 0.f; }
+
+// tfa AdamW: var -= wd*var; m,v update; var -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                    const float *__restrict__ g, long long n, const ImkCtl *__restrict__ ctl,
+                                                    const float *__restrict__ stats, float grad_scale, float lr, float wd,
+                                                    float b1, float b2, float eps) {
+    if (stats[1] != 0.f) return;  // non-finite gradients somewhere: skip the step (dynamic loss scaling)
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = (float)(ctl->step + 1);
+    const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    const float gi = g[i] * grad_scale;
+    float pi = p[i];
+    pi -= wd * pi;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= lr_t * mi / (sqrtf(vi) + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// Keras dynamic loss scale: halve on overflow, double after 2000 consecutive finite steps
+__global__ void ctl_end_step_kernel(ImkCtl *ctl, const float *__restrict__ stats) {
+    if (stats[1] != 0.f) {
+        ctl->loss_scale = fmaxf(ctl->loss_scale * 0.5f, 1.0f);
+        ctl->good_steps = 0;
+    } else {
+        ctl->step += 1;
+        if (++ctl->good_steps >= 2000) { ctl->loss_scale *= 2.0f; ctl->good_steps = 0; }
+    }
+    ctl->inv_loss_scale = 1.0f / ctl->loss_scale;
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------------------
+int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
+                           const float *beta, float *mov_mean, float *mov_var, float *scale, float *shift,
+                           float *save_mean, float *save_invstd, hipStream_t stream) {
+    bn_finalize_kernel<<<cs, 256, 0, stream>>>(partial, n_part, c, cs, count, gamma, beta, mov_mean, mov_var, scale, shift,
+                                               save_mean, save_invstd);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, int c, int cs,
+                       float *scale, float *shift, hipStream_t stream) {
+    bn_fold_kernel<<<imk_cdiv(cs, 64), 64, 0, stream>>>(gamma, beta, mean, var, c, cs, scale, shift);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_bn_prep_blocks(int B, int H, int W, int cs) {
+    const int nc8 = cs / 8;
+    const long long items = (long long)B * H * W * nc8;
+    long long nb = (items + 256 * 8 - 1) / (256 * 8);  // about 8 items per thread
+    if (nb > 2048) nb = 2048;
+    nb = (nb + nc8 - 1) / nc8 * nc8;                    // multiple of nc8: fixed chunk index per thread
+    return (int)nb;
+}
+
+int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
+                           const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream) {
+    BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs};
+    bn_bwd_prep_kernel<<<imk_bn_prep_blocks(B, H, W, cs), 256, 0, stream>>>(a);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
+                           const float *save_mean, const float *save_invstd, const float *inv_scale_ptr, float *coef,
+                           float *dgamma, float *dbeta, float *found_inf, hipStream_t stream) {
+    bn_bwd_coef_kernel<<<cs, 256, 0, stream>>>(partial, n_part, c, cs, count, gamma, save_mean, save_invstd, inv_scale_ptr,
+                                               coef, dgamma, dbeta, found_inf);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_bn_bwd_apply(const f16 *dy, const f16 *z, const float *coef, int cs, long long n_pix, f16 *dA,
+                            hipStream_t stream) {
+    const long long items = n_pix * (cs / 8);
+    long long nb = (items + 256 * 4 - 1) / (256 * 4);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    bn_bwd_apply_kernel<<<(int)nb, 256, 3 * cs * sizeof(float), stream>>>(dy, z, coef, cs, items, dA);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                    int K, int softmax, long long n_pix, float *probs, hipStream_t stream) {
+    if (K > 64) return IMK_EUNSUPPORTED;
+    const int nb = (int)((n_pix + 255) / 256);
+    const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
+    switch (cs) {
+        case 8: head_kernel<8><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
+        case 16: head_kernel<16><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
+        case 24: head_kernel<24><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
+        case 32: head_kernel<32><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
+        default: return IMK_EUNSUPPORTED;
+    }
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_loss_blocks(long long n_pix) { return (int)((n_pix + 255) / 256); }
+
+int imk_launch_loss_grad(const float *probs, const uint8_t *y, int K, int cs, int kind, long long n_pix,
+                         const ImkCtl *ctl, f16 *dlogit, float *loss_partial, float *stats, hipStream_t stream) {
+    const int nb = imk_loss_blocks(n_pix);
+    loss_grad_kernel<<<nb, 256, 0, stream>>>(probs, y, K, cs, kind, n_pix, &ctl->loss_scale, dlogit, loss_partial);
+    IMK_LAUNCH_CHECK();
+    (void)stats;
+    return IMK_OK;
+}
+
+int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
+                             hipStream_t stream) {
+    const double denom = kind == 0 ? (double)n_pix * K : (double)n_pix;
+    loss_finalize_kernel<<<1, 256, 0, stream>>>(loss_partial, imk_loss_blocks(n_pix), denom, ctl, stats);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream) {
+    ctl_init_kernel<<<1, 1, 0, stream>>>(ctl);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_ctl_begin(ImkCtl *ctl, hipStream_t stream) {
+    ctl_begin_step_kernel<<<1, 1, 0, stream>>>(ctl);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
+                     float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream) {
+    adamw_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(p, m, v, g, n, ctl, stats, grad_scale, lr, wd, b1, b2, eps);
+    IMK_LAUNCH_CHECK();
+    ctl_end_step_kernel<<<1, 1, 0, stream>>>(ctl, stats);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}

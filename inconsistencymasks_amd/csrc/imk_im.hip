@@ -1,0 +1,398 @@
+// Fused Inconsistency-Mask kernels for gfx950 (MI355X).
+//
+// One launch per batch turns the N-model probability stack into pseudo-label, inconsistency mask,
+// blocked image and per-image sizes -- the chain the reference runs per image in numpy:
+//   threshold/argmax  functions.py:3157, 3187-3189, 3225
+//   agreement         functions.py:3104-3120 (binary), 3123-3137 (multiclass), 3195-3200 (HeLa combine)
+//   blocking          functions.py:2867-2874
+// The kernels are pure streaming (about 3 integer ops per byte): the roofline is HBM bandwidth.
+// Layout choices for that: every global access is a 16-byte vector per lane (float4 probability
+// loads, uint4 mask / image stores); results are staged in LDS so that the byte-granular outputs
+// (3-channel images, 1-byte masks) still leave the CU as full 16-byte stores; one workgroup never
+// straddles two images so the per-image sizes need one integer atomic per workgroup and channel.
+#include "imk_common.h"
+
+namespace {
+
+constexpr int BIN_CHUNK = 1024;  // pixels per workgroup, binary kernel (4 per thread)
+constexpr int MC_CHUNK = 256;    // pixels per workgroup, multiclass kernel (1 per thread)
+
+// ---- shared phase 2: LDS results -> global, 16-byte stores when the shape allows -------------------
+template <int CHUNK>
+__device__ __forceinline__ void store_bytes(uint8_t *__restrict__ dst, const uint8_t *s, int n, bool vec) {
+    const int t = threadIdx.x;
+    if (vec) {
+        for (int i = t; i < n / 16; i += 256)
+            reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(s)[i];
+    } else {
+        for (int i = t; i < n; i += 256) dst[i] = s[i];
+    }
+}
+
+__device__ __forceinline__ void block_image(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                            const uint8_t *s_im, int n_px, int c, int block_in, bool vec) {
+    const int t = threadIdx.x;
+    const int nbytes = n_px * c;
+    if (vec) {
+        for (int i = t; i < nbytes / 16; i += 256) {
+            uint4 v = reinterpret_cast<const uint4 *>(src)[i];
+            if (block_in) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t keep = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = i * 16 + q * 4 + k;
+                        const int px = (c == 3) ? idx / 3 : (c == 1 ? idx : idx / c);
+                        keep |= (s_im[px] ? 0u : 0xffu) << (8 * k);
+                    }
+                    w[q] &= keep;
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            reinterpret_cast<uint4 *>(dst)[i] = v;
+        }
+    } else {
+        for (int i = t; i < nbytes; i += 256) {
+            const int px = i / c;
+            dst[i] = (block_in && s_im[px]) ? 0 : src[i];
+        }
+    }
+}
+
+// ---- binary / HeLa -----------------------------------------------------------------------------
+// grid (ceil(HW/1024), B); requires HW % 4 == 0 and 16-byte aligned preds (host checks), else the
+// generic kernel below runs.
+template <int KB>
+__global__ __launch_bounds__(256) void im_binary_vec(
+    const float *__restrict__ preds, int n_models, int batch, int hw, float thr, int cmp_ge,
+    const uint8_t *__restrict__ img, int c, int block_in, int block_out,
+    uint8_t *__restrict__ img_out, uint8_t *__restrict__ masks_out, uint8_t *__restrict__ im_out,
+    unsigned long long *__restrict__ im_size, unsigned long long *__restrict__ pred_size, int vec_out, int vec_img) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_final[KB][BIN_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_im[BIN_CHUNK];
+    __shared__ int s_cnt[2 * KB];
+    const int b = blockIdx.y;
+    const int p_base = blockIdx.x * BIN_CHUNK;
+    const int t = threadIdx.x;
+    const int p0 = p_base + 4 * t;
+    if (t < 2 * KB) s_cnt[t] = 0;
+    int cnt_fg[KB], cnt_mx[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) cnt_fg[k] = cnt_mx[k] = 0;
+
+    if (p0 < hw) {
+        int s[4][KB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) s[j][k] = 0;
+        for (int n = 0; n < n_models; ++n) {
+            const float4 *src = reinterpret_cast<const float4 *>(preds + ((size_t)(n * batch + b) * hw + p0) * KB);
+            float v[4 * KB];
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+                const float4 f = src[q];
+                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * KB; ++i) {
+                const bool hit = cmp_ge ? (v[i] >= thr) : (v[i] > thr);  // NaN compares false
+                s[i / KB][i % KB] += hit ? 1 : 0;
+            }
+        }
+        uint32_t fin[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) fin[k] = 0;
+        uint32_t im4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool any = false;
+            bool fg[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                fg[k] = (s[j][k] == n_models);
+                const bool mx = (s[j][k] != 0) && !fg[k];
+                cnt_fg[k] += fg[k];
+                cnt_mx[k] += mx;
+                any |= mx;
+            }
+            if (any) im4 |= 0xffu << (8 * j);
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (fg[k] && !(block_out && any)) fin[k] |= 0xffu << (8 * j);
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) *reinterpret_cast<uint32_t *>(&s_final[k][4 * t]) = fin[k];
+        *reinterpret_cast<uint32_t *>(&s_im[4 * t]) = im4;
+    }
+    __syncthreads();
+    // per-image sizes: wave reduction, one LDS atomic per wave, one global atomic per workgroup
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        int a = cnt_fg[k], m = cnt_mx[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); m += __shfl_xor(m, o, 64); }
+        if ((t & 63) == 0) { atomicAdd(&s_cnt[2 * k], a); atomicAdd(&s_cnt[2 * k + 1], m); }
+    }
+    __syncthreads();
+    if (t < KB) {
+        if (s_cnt[2 * t]) atomicAdd(&pred_size[(size_t)b * KB + t], (unsigned long long)s_cnt[2 * t]);
+        if (s_cnt[2 * t + 1]) atomicAdd(&im_size[(size_t)b * KB + t], (unsigned long long)s_cnt[2 * t + 1]);
+    }
+    const int n_px = min(BIN_CHUNK, hw - p_base);
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+        store_bytes<BIN_CHUNK>(masks_out + ((size_t)b * KB + k) * hw + p_base, s_final[k], n_px, vec_out);
+    store_bytes<BIN_CHUNK>(im_out + (size_t)b * hw + p_base, s_im, n_px, vec_out);
+    if (img) {
+        const size_t off = ((size_t)b * hw + p_base) * c;
+        block_image(img + off, img_out + off, s_im, n_px, c, block_in, vec_img);
+    }
+}
+
+// Any shape / alignment: one pixel per thread.  Used for odd sizes only.
+__global__ __launch_bounds__(256) void im_binary_generic(
+    const float *__restrict__ preds, int n_models, int batch, int hw, int kb, float thr, int cmp_ge,
+    const uint8_t *__restrict__ img, int c, int block_in, int block_out,
+    uint8_t *__restrict__ img_out, uint8_t *__restrict__ masks_out, uint8_t *__restrict__ im_out,
+    unsigned long long *__restrict__ im_size, unsigned long long *__restrict__ pred_size) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    bool any = false;
+    for (int k = 0; k < kb; ++k) {
+        int s = 0;
+        for (int n = 0; n < n_models; ++n) {
+            const float v = preds[((size_t)(n * batch + b) * hw + p) * kb + k];
+            s += cmp_ge ? (v >= thr) : (v > thr);
+        }
+        const bool mx = (s != 0) && (s != n_models);
+        any |= mx;
+        if (s == n_models) atomicAdd(&pred_size[(size_t)b * kb + k], 1ull);
+        if (mx) atomicAdd(&im_size[(size_t)b * kb + k], 1ull);
+        masks_out[((size_t)b * kb + k) * hw + p] = (s == n_models) ? 255 : 0;
+    }
+    im_out[(size_t)b * hw + p] = any ? 255 : 0;
+    if (block_out && any)
+        for (int k = 0; k < kb; ++k) masks_out[((size_t)b * kb + k) * hw + p] = 0;
+    if (img)
+        for (int ch = 0; ch < c; ++ch) {
+            const size_t i = ((size_t)b * hw + p) * c + ch;
+            img_out[i] = (block_in && any) ? 0 : img[i];
+        }
+}
+
+// ---- multiclass ----------------------------------------------------------------------------------
+// grid (ceil(HW/256), B), dynamic LDS = 256 * (K|1) floats.  Each model's [256 px][K] slab is read
+// with coalesced 16-byte loads into LDS (odd row stride: conflict-free column walks), then one thread
+// per pixel takes the arg-max (strict >, so the lowest index wins ties like numpy).
+__global__ __launch_bounds__(256) void im_multi_kernel(
+    const float *__restrict__ probs, int n_models, int batch, int hw, int k_classes, uint32_t magic_k,
+    const uint8_t *__restrict__ img, int c, int block_in, int block_out,
+    uint8_t *__restrict__ img_out, uint8_t *__restrict__ final_out, uint8_t *__restrict__ im_out,
+    unsigned long long *__restrict__ im_size, uint8_t *__restrict__ presence, int vec_in, int vec_out, int vec_img) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];
+    __shared__ __attribute__((aligned(16))) uint8_t s_final[MC_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_im[MC_CHUNK];
+    __shared__ uint32_t s_pres[64];
+    __shared__ int s_cnt;
+    const int ks = k_classes | 1;
+    const int b = blockIdx.y;
+    const int p_base = blockIdx.x * MC_CHUNK;
+    const int n_px = min(MC_CHUNK, hw - p_base);
+    const int t = threadIdx.x;
+    if (t == 0) s_cnt = 0;
+    int label0 = 0;
+    bool agree = true;
+    for (int n = 0; n < n_models; ++n) {
+        if (t < 64) s_pres[t] = 0;
+        const float *src = probs + ((size_t)(n * batch + b) * hw + p_base) * k_classes;
+        const int total = n_px * k_classes;
+        if (vec_in && (total & 3) == 0) {
+            for (int i = t; i < total / 4; i += 256) {
+                const float4 v = reinterpret_cast<const float4 *>(src)[i];
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t idx = 4u * i + q;
+                    const uint32_t px = __umulhi(idx, magic_k);  // idx / K, exact for idx*K < 2^32
+                    s_p[px * ks + (idx - px * k_classes)] = e[q];
+                }
+            }
+        } else {
+            for (int i = t; i < total; i += 256) {
+                const int px = i / k_classes;
+                s_p[px * ks + (i - px * k_classes)] = src[i];
+            }
+        }
+        __syncthreads();
+        if (t < n_px) {
+            const float *row = s_p + t * ks;
+            int best = 0;
+            float bv = row[0];
+            for (int k = 1; k < k_classes; ++k) {
+                const float v = row[k];
+                if (v > bv) { bv = v; best = k; }
+            }
+            s_pres[best] = 1;
+            if (n == 0) label0 = best; else agree = agree && (best == label0);
+        }
+        __syncthreads();
+        if (presence && t < k_classes && s_pres[t]) presence[((size_t)n * batch + b) * k_classes + t] = 1;
+    }
+    int dis = 0;
+    if (t < n_px) {
+        const uint8_t im = agree ? 0 : 255;
+        s_im[t] = im;
+        s_final[t] = (agree && !(block_out && im)) ? (uint8_t)label0 : 0;
+        dis = agree ? 0 : 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dis += __shfl_xor(dis, o, 64);
+    if ((t & 63) == 0 && dis) atomicAdd(&s_cnt, dis);
+    __syncthreads();
+    if (t == 0 && s_cnt) atomicAdd(&im_size[b], (unsigned long long)s_cnt);
+    store_bytes<MC_CHUNK>(final_out + (size_t)b * hw + p_base, s_final, n_px, vec_out);
+    store_bytes<MC_CHUNK>(im_out + (size_t)b * hw + p_base, s_im, n_px, vec_out);
+    if (img) {
+        const size_t off = ((size_t)b * hw + p_base) * c;
+        block_image(img + off, img_out + off, s_im, n_px, c, block_in, vec_img);
+    }
+}
+
+// ---- morphology + late blocking (cold path: EK = DK = 0 in every shipped config) ------------------
+__global__ __launch_bounds__(256) void morph_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                    int h, int w, int ksize, int op) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int a = ksize / 2;
+    const uint8_t *s = src + (size_t)b * h * w;
+    int acc = op ? 0 : 255;
+    for (int dy = -a; dy < ksize - a; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -a; dx < ksize - a; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w) continue;
+            const int v = s[(size_t)yy * w + xx];
+            acc = op ? max(acc, v) : min(acc, v);
+        }
+    }
+    dst[(size_t)b * h * w + (size_t)y * w + x] = (uint8_t)acc;
+}
+
+__global__ __launch_bounds__(256) void block_apply_kernel(const uint8_t *__restrict__ im, uint8_t *__restrict__ img, int c,
+                                                          uint8_t *__restrict__ masks, int n_masks, int hw) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    if (im[(size_t)b * hw + p] == 0) return;
+    if (img)
+        for (int ch = 0; ch < c; ++ch) img[((size_t)b * hw + p) * c + ch] = 0;
+    if (masks)
+        for (int m = 0; m < n_masks; ++m) masks[((size_t)b * n_masks + m) * hw + p] = 0;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int kb,
+                             float thr, int cmp_ge, const uint8_t *img, int c, int block_in, int block_out,
+                             uint8_t *img_out, uint8_t *masks_out, uint8_t *im_out,
+                             int64_t *im_size, int64_t *pred_size, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_CHECK_ARG(preds && masks_out && im_out && im_size && pred_size);
+    IMK_CHECK_ARG(n_models > 0 && batch > 0 && h > 0 && w > 0 && kb > 0);
+    IMK_CHECK_ARG(!img || (img_out && c > 0));
+    const int64_t hw64 = (int64_t)h * w;
+    IMK_CHECK_ARG(hw64 < (1ll << 30));
+    const int hw = (int)hw64;
+    IMK_HIP(hipMemsetAsync(im_size, 0, sizeof(int64_t) * batch * kb, stream));
+    IMK_HIP(hipMemsetAsync(pred_size, 0, sizeof(int64_t) * batch * kb, stream));
+    auto *ims = reinterpret_cast<unsigned long long *>(im_size);
+    auto *pss = reinterpret_cast<unsigned long long *>(pred_size);
+    const bool vec_ok = (hw % 4 == 0) && aligned16(preds) && (kb == 1 || kb == 3);
+    if (vec_ok) {
+        const int vec_out = (hw % 16 == 0) && aligned16(masks_out) && aligned16(im_out);
+        const int vec_img = img && ((int64_t)hw * c % 16 == 0) && aligned16(img) && aligned16(img_out);
+        dim3 grid(imk_cdiv(hw, BIN_CHUNK), batch);
+        if (kb == 1)
+            im_binary_vec<1><<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
+                                                       img_out, masks_out, im_out, ims, pss, vec_out, vec_img);
+        else
+            im_binary_vec<3><<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
+                                                       img_out, masks_out, im_out, ims, pss, vec_out, vec_img);
+    } else {
+        dim3 grid(imk_cdiv(hw, 256), batch);
+        im_binary_generic<<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, kb, thr, cmp_ge, img, c, block_in, block_out,
+                                                    img_out, masks_out, im_out, ims, pss);
+    }
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+extern "C" int imk_im_multiclass(const float *probs, int n_models, int batch, int h, int w, int k,
+                                 const uint8_t *img, int c, int block_in, int block_out,
+                                 uint8_t *img_out, uint8_t *final_out, uint8_t *im_out,
+                                 int64_t *im_size, uint8_t *presence, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_CHECK_ARG(probs && final_out && im_out && im_size);
+    IMK_CHECK_ARG(n_models > 0 && batch > 0 && h > 0 && w > 0 && k > 0);
+    IMK_CHECK_ARG(!img || (img_out && c > 0));
+    if (k > 64) return IMK_EUNSUPPORTED;
+    const int64_t hw64 = (int64_t)h * w;
+    IMK_CHECK_ARG(hw64 < (1ll << 30));
+    const int hw = (int)hw64;
+    IMK_HIP(hipMemsetAsync(im_size, 0, sizeof(int64_t) * batch, stream));
+    if (presence) IMK_HIP(hipMemsetAsync(presence, 0, (size_t)n_models * batch * k, stream));
+    const int vec_in = aligned16(probs) && (((int64_t)hw * k) % 4 == 0) && ((MC_CHUNK * k) % 4 == 0);
+    const int vec_out = (hw % 16 == 0) && aligned16(final_out) && aligned16(im_out);
+    const int vec_img = img && ((int64_t)hw * c % 16 == 0) && aligned16(img) && aligned16(img_out);
+    const uint32_t magic = (uint32_t)((1ull << 32) / (uint32_t)k) + 1u;
+    const size_t lds = (size_t)MC_CHUNK * (k | 1) * sizeof(float);
+    dim3 grid(imk_cdiv(hw, MC_CHUNK), batch);
+    im_multi_kernel<<<grid, 256, lds, stream>>>(probs, n_models, batch, hw, k, magic, img, c, block_in, block_out,
+                                                img_out, final_out, im_out, reinterpret_cast<unsigned long long *>(im_size),
+                                                presence, vec_in, vec_out, vec_img);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+extern "C" int imk_morph(const uint8_t *src, uint8_t *dst, int batch, int h, int w, int ksize, int op, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_CHECK_ARG(src && dst && src != dst && batch > 0 && h > 0 && w > 0 && ksize > 0 && ksize <= 31 && (op == 0 || op == 1));
+    dim3 grid(imk_cdiv(w, 64), imk_cdiv(h, 4), batch);
+    morph_kernel<<<grid, 256, 0, stream>>>(src, dst, h, w, ksize, op);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+extern "C" int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *masks, int n_masks,
+                               int batch, int h, int w, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_CHECK_ARG(im && batch > 0 && h > 0 && w > 0);
+    IMK_CHECK_ARG(!img || c > 0);
+    IMK_CHECK_ARG(!masks || n_masks > 0);
+    const int hw = h * w;
+    dim3 grid(imk_cdiv(hw, 256), batch);
+    block_apply_kernel<<<grid, 256, 0, stream>>>(im, img, c, masks, n_masks, hw);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+extern "C" int imk_version(void) { return IMK_VERSION; }
+
+extern "C" const char *imk_error_string(int code) {
+    switch (code) {
+        case IMK_OK: return "ok";
+        case IMK_EINVAL: return "invalid argument";
+        case IMK_EUNSUPPORTED: return "unsupported shape";
+        case IMK_EWORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown imk error";
+    }
+}

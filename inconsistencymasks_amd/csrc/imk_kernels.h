@@ -1,0 +1,60 @@
+// Internal launch API between the U-Net orchestration (imk_unet.hip) and the kernels.
+#pragma once
+#include "imk_common.h"
+
+// How a conv kernel materialises its input tile (the producer's BatchNorm is applied on load).
+enum ImkLoadMode {
+    LM_RAW = 0,     // fp16 [B,H,W,cs] as is
+    LM_AFFINE = 1,  // fp16(z*sc + sh)                                   (BN on load)
+    LM_POOL = 2,    // 2x2 max of fp16(z*sc + sh), z at [B,2H,2W,cs]     (BN + MaxPooling2D, unet.py:16-17)
+    LM_UPADD = 3,   // fp16( fp16(zlo*sc+sh)[y/2,x/2] + fp16(zsk*sc2+sh2) )  (UpSampling2D + add, unet.py:32-33)
+    LM_U8 = 4,      // fp16(u8/255), [B,H,W,cin] bytes                   (Lambda x/255, unet.py:5)
+};
+enum ImkEpilogue {
+    EP_RELU = 0,   // fp16(max(acc + bias, 0)); optional per-channel sum / sum-of-squares partials
+    EP_PLAIN = 1,  // fp16(acc)                      (dgrad)
+    EP_MASK = 2,   // fp16(mask > 0 ? acc : 0)       (dgrad through the ReLU of the producing conv)
+};
+
+struct ImkInput {
+    const void *in;        // see ImkLoadMode
+    const void *in2;       // LM_UPADD: skip tensor
+    const float *sc, *sh;  // [cs_in] affine of `in`
+    const float *sc2, *sh2;
+    int lmode;
+    int cin, cs_in;        // logical / padded-to-8 channel count (LM_U8: cs_in = 8)
+};
+
+struct ImkConvArgs {
+    ImkInput x;
+    int B, H, W;           // resolution of the conv (= of the output)
+    int ksize;             // 1 or 3
+    int cout, cs_out;
+    const f16 *wpk;        // packed weights, fragment order (see pack_conv_weights)
+    const float *bias;     // [cout], EP_RELU only
+    f16 *out;              // [B,H,W,cs_out]
+    const f16 *mask;       // EP_MASK: [B,H,W,cs_out]
+    float *stats_partial;  // EP_RELU, optional: [n_tiles][2*cs_out] (sum, sumsq of the fp16-rounded outputs)
+    int epi;
+};
+int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize);  // rows of stats_partial
+int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream);
+
+struct ImkWgradArgs {
+    ImkInput x;            // the conv's input, same modes as forward
+    const f16 *dA;         // [B,H,W,cs_out] gradient w.r.t. the conv's pre-activation output (loss-scaled)
+    int B, H, W, ksize, cout, cs_out;
+    float *partial;        // [n_split][n_pairs][taps+1][256] fp32 scratch
+    int n_split;
+};
+int imk_wgrad_splits(int B, int H, int W, int cin, int cout);
+size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout);
+int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
+// sums the partials in a fixed order, multiplies by inv_scale, writes dW (HWIO) and db into the flat
+// gradient vector, ORs non-finite detection into *found_inf.
+int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int cin, int cout,
+                              const float *inv_scale_ptr, float *dw, float *db, float *found_inf, hipStream_t stream);
+
+// weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand.
+size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed);
+int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream);

@@ -1,0 +1,596 @@
+// Host orchestration of the tiny U-Net (unet.py:4-67) on top of the kernels in imk_conv.hip /
+// imk_elem.hip: parameter layout, weight packing, workspace layout, batched inference, ensemble
+// inference + IM, and the training step (forward with batch statistics, loss, backward, AdamW).
+// Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
+#include <cstring>
+#include <new>
+#include "imk_elem.h"
+#include "imk_kernels.h"
+#include "imk_plan.h"
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+// ---- topology ------------------------------------------------------------------------------------
+void add_conv(imk_unet_plan *p, const char *name, int k, int cin, int cout, int res) {
+    ImkLayer l{};
+    l.name = name; l.kind = 0; l.ksize = k; l.cin = cin; l.cout = cout; l.res = res;
+    p->layers.push_back(l);
+}
+void add_bn(imk_unet_plan *p, const char *name, int c, int res) {
+    ImkLayer l{};
+    l.name = name; l.kind = 1; l.ksize = 0; l.cin = c; l.cout = c; l.res = res;
+    p->layers.push_back(l);
+}
+
+void build_layers(imk_unet_plan *p) {
+    const int *ch = p->cfg.ch;  // 16a 32a 64a 128a 256a
+    add_conv(p, "in.c", 1, p->cfg.c_in, ch[0], 0);
+    add_bn(p, "in.bn", ch[0], 0);
+    const int enc_in[4] = {ch[0], ch[0], ch[1], ch[2]};
+    const int enc_f[4] = {ch[0], ch[1], ch[2], ch[3]};
+    char nm[16];
+    for (int i = 0; i < 4; ++i) {
+        snprintf(nm, sizeof nm, "e%d.c3", i + 1); add_conv(p, nm, 3, enc_in[i], enc_f[i], i);
+        snprintf(nm, sizeof nm, "e%d.c1", i + 1); add_conv(p, nm, 1, enc_f[i], enc_f[i], i);
+        snprintf(nm, sizeof nm, "e%d.bn", i + 1); add_bn(p, nm, enc_f[i], i);
+    }
+    add_conv(p, "b.c3", 3, ch[3], ch[4], 4);
+    add_conv(p, "b.c1", 1, ch[4], ch[3], 4);
+    add_bn(p, "b.bn", ch[3], 4);
+    const int dec_in[4] = {ch[3], ch[2], ch[1], ch[0]};
+    const int dec_f1[4] = {ch[3], ch[2], ch[1], ch[0]};
+    const int dec_f2[4] = {ch[2], ch[1], ch[0], ch[0]};
+    for (int j = 0; j < 4; ++j) {
+        const int res = 3 - j;
+        snprintf(nm, sizeof nm, "d%d.ca", j + 6); add_conv(p, nm, 1, dec_in[j], dec_f1[j], res);
+        snprintf(nm, sizeof nm, "d%d.bna", j + 6); add_bn(p, nm, dec_f1[j], res);
+        snprintf(nm, sizeof nm, "d%d.c3", j + 6); add_conv(p, nm, 3, dec_f1[j], dec_f1[j], res);
+        snprintf(nm, sizeof nm, "d%d.c1", j + 6); add_conv(p, nm, 1, dec_f1[j], dec_f2[j], res);
+        snprintf(nm, sizeof nm, "d%d.bnb", j + 6); add_bn(p, nm, dec_f2[j], res);
+    }
+    add_conv(p, "out", 1, ch[0], p->cfg.n_out, 0);
+
+    // flat parameter layout: trainable section, then moving statistics
+    int64_t off = 0;
+    for (auto &l : p->layers) {
+        if (l.kind == 0) { l.off_w = off; off += (int64_t)l.ksize * l.ksize * l.cin * l.cout; l.off_b = off; off += l.cout; }
+        else { l.off_w = off; off += l.cout; l.off_b = off; off += l.cout; }
+        l.off_mean = l.off_var = -1;
+    }
+    p->n_trainable = off;
+    for (auto &l : p->layers)
+        if (l.kind == 1) { l.off_mean = off; off += l.cout; l.off_var = off; off += l.cout; }
+    p->n_total = off;
+
+    // packed buffer
+    size_t pk = 0;
+    for (auto &l : p->layers) {
+        if (l.kind == 0) {
+            l.pk_bytes_fwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 0) * 2;
+            l.pk_bytes_bwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 1) * 2;
+            l.pk_fwd = (int64_t)pk; pk = up(pk + l.pk_bytes_fwd);
+            l.pk_bwd = (int64_t)pk; pk = up(pk + l.pk_bytes_bwd);
+        } else {
+            l.pk_scale = (int64_t)pk; pk = up(pk + 2 * (size_t)imk_pad8(l.cout) * sizeof(float));
+        }
+    }
+    p->packed_bytes = (int64_t)pk;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------
+struct LayerWs {
+    size_t out = 0;            // conv: output tensor fp16 [B,H,W,cs]
+    size_t dA = 0;             // conv (train): gradient w.r.t. pre-activation output
+    size_t dy = 0;             // bn (train): gradient w.r.t. the BN output
+    size_t stats_partial = 0;  // bn (train): [n_tiles][2cs]
+    size_t scale = 0;          // bn (train): scale[cs], shift[cs]
+    size_t save = 0;           // bn (train): mean[cs], invstd[cs]
+    size_t bwd_partial = 0;    // bn (train)
+    size_t coef = 0;           // bn (train): [3][cs]
+    int n_stats_tiles = 0;
+};
+
+struct Ws {
+    std::vector<LayerWs> L;
+    size_t dU[4] = {0, 0, 0, 0};   // train: gradient w.r.t. decoder j's upsample+add output
+    size_t dP[4] = {0, 0, 0, 0};   // train: gradient w.r.t. the pooled input of encoder i+1 / bottleneck
+    size_t probs = 0, dlogit = 0, loss_partial = 0, wgrad_partial = 0;
+    size_t total = 0;
+};
+
+struct Dim { int h, w; };
+inline Dim res_dim(const imk_unet_cfg &c, int res) { return Dim{c.h >> res, c.w >> res}; }
+
+// index of the conv whose output a given conv / bn consumes, and friends
+struct Topo {
+    int in_c, in_bn;
+    int e_c3[4], e_c1[4], e_bn[4];
+    int b_c3, b_c1, b_bn;
+    int d_ca[4], d_bna[4], d_c3[4], d_c1[4], d_bnb[4];
+    int out;
+};
+
+Topo make_topo(const imk_unet_plan *p) {
+    Topo t{};
+    t.in_c = p->find("in.c"); t.in_bn = p->find("in.bn");
+    char nm[16];
+    for (int i = 0; i < 4; ++i) {
+        snprintf(nm, sizeof nm, "e%d.c3", i + 1); t.e_c3[i] = p->find(nm);
+        snprintf(nm, sizeof nm, "e%d.c1", i + 1); t.e_c1[i] = p->find(nm);
+        snprintf(nm, sizeof nm, "e%d.bn", i + 1); t.e_bn[i] = p->find(nm);
+    }
+    t.b_c3 = p->find("b.c3"); t.b_c1 = p->find("b.c1"); t.b_bn = p->find("b.bn");
+    for (int j = 0; j < 4; ++j) {
+        snprintf(nm, sizeof nm, "d%d.ca", j + 6); t.d_ca[j] = p->find(nm);
+        snprintf(nm, sizeof nm, "d%d.bna", j + 6); t.d_bna[j] = p->find(nm);
+        snprintf(nm, sizeof nm, "d%d.c3", j + 6); t.d_c3[j] = p->find(nm);
+        snprintf(nm, sizeof nm, "d%d.c1", j + 6); t.d_c1[j] = p->find(nm);
+        snprintf(nm, sizeof nm, "d%d.bnb", j + 6); t.d_bnb[j] = p->find(nm);
+    }
+    t.out = p->find("out");
+    return t;
+}
+
+// the conv that feeds each BN
+int bn_producer(const Topo &t, int bn) {
+    if (bn == t.in_bn) return t.in_c;
+    for (int i = 0; i < 4; ++i) if (bn == t.e_bn[i]) return t.e_c1[i];
+    if (bn == t.b_bn) return t.b_c1;
+    for (int j = 0; j < 4; ++j) { if (bn == t.d_bna[j]) return t.d_ca[j]; if (bn == t.d_bnb[j]) return t.d_c1[j]; }
+    return -1;
+}
+
+Ws make_ws(const imk_unet_plan *p, int B, int mode) {
+    Ws w;
+    const Topo t = make_topo(p);
+    w.L.resize(p->layers.size());
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
+    const int n = (int)p->layers.size();
+    size_t wg_max = 0;
+    for (int i = 0; i < n; ++i) {
+        const ImkLayer &l = p->layers[i];
+        const Dim d = res_dim(p->cfg, l.res);
+        const size_t px = (size_t)B * d.h * d.w;
+        if (l.kind == 0) {
+            if (i != t.out) w.L[i].out = take(px * imk_pad8(l.cout) * 2);
+            if (mode == 1) {
+                w.L[i].dA = take(px * imk_pad8(l.cout) * 2);
+                const size_t f = imk_wgrad_partial_floats(B, d.h, d.w, l.ksize, l.cin, l.cout) * sizeof(float);
+                if (f > wg_max) wg_max = f;
+            }
+        } else if (mode == 1) {
+            const int cs = imk_pad8(l.cout);
+            const ImkLayer &pc = p->layers[bn_producer(t, i)];
+            w.L[i].n_stats_tiles = imk_conv_num_tiles(B, d.h, d.w, imk_pad8(pc.cin), pc.ksize);
+            w.L[i].stats_partial = take((size_t)w.L[i].n_stats_tiles * 2 * cs * sizeof(float));
+            w.L[i].scale = take(2 * (size_t)cs * sizeof(float));
+            w.L[i].save = take(2 * (size_t)cs * sizeof(float));
+            w.L[i].bwd_partial = take((size_t)imk_bn_prep_blocks(B, d.h, d.w, cs) * 2 * cs * sizeof(float));
+            w.L[i].coef = take(3 * (size_t)cs * sizeof(float));
+            w.L[i].dy = take(px * cs * 2);
+        }
+    }
+    if (mode == 1) {
+        for (int j = 0; j < 4; ++j) {  // decoder j+6 at res 3-j; u has the channels of ca's input
+            const ImkLayer &ca = p->layers[t.d_ca[j]];
+            const Dim d = res_dim(p->cfg, ca.res);
+            w.dU[j] = take((size_t)B * d.h * d.w * imk_pad8(ca.cin) * 2);
+        }
+        for (int i = 0; i < 4; ++i) {  // pooled output of encoder i+1, at res i+1
+            const ImkLayer &e = p->layers[t.e_c1[i]];
+            const Dim d = res_dim(p->cfg, i + 1);
+            w.dP[i] = take((size_t)B * d.h * d.w * imk_pad8(e.cout) * 2);
+        }
+        const size_t px = (size_t)B * p->cfg.h * p->cfg.w;
+        w.dlogit = take(px * imk_pad8(p->cfg.n_out) * 2);
+        w.loss_partial = take((size_t)imk_loss_blocks((long long)px) * sizeof(float));
+        w.wgrad_partial = take(wg_max);
+        w.probs = take(px * p->cfg.n_out * sizeof(float));
+    }
+    w.total = off;
+    return w;
+}
+
+// ---- one forward pass --------------------------------------------------------------------------------
+struct Ctx {
+    const imk_unet_plan *p;
+    Topo t;
+    Ws ws;
+    uint8_t *base;        // workspace
+    const float *params;
+    const uint8_t *packed;
+    int B;
+    bool train;
+    hipStream_t stream;
+    f16 *act(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].out); }
+    f16 *dA(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].dA); }
+    f16 *dy(int bn) const { return reinterpret_cast<f16 *>(base + ws.L[bn].dy); }
+    const float *bn_scale(int bn) const {
+        return train ? reinterpret_cast<const float *>(base + ws.L[bn].scale)
+                     : reinterpret_cast<const float *>(packed + p->layers[bn].pk_scale);
+    }
+    const float *bn_shift(int bn) const { return bn_scale(bn) + imk_pad8(p->layers[bn].cout); }
+    const f16 *wfwd(int conv) const { return reinterpret_cast<const f16 *>(packed + p->layers[conv].pk_fwd); }
+    const f16 *wbwd(int conv) const { return reinterpret_cast<const f16 *>(packed + p->layers[conv].pk_bwd); }
+};
+
+// the input description of every conv (shared by forward and wgrad)
+ImkInput conv_input(const Ctx &c, int conv, const uint8_t *x_u8) {
+    const Topo &t = c.t;
+    const ImkLayer &l = c.p->layers[conv];
+    ImkInput in{};
+    in.cin = l.cin;
+    in.cs_in = imk_pad8(l.cin);
+    auto affine = [&](int src_conv, int bn, int mode) {
+        in.in = c.act(src_conv); in.sc = c.bn_scale(bn); in.sh = c.bn_shift(bn); in.lmode = mode;
+    };
+    if (conv == t.in_c) { in.in = x_u8; in.lmode = LM_U8; in.cs_in = 8; return in; }
+    if (conv == t.e_c3[0]) { affine(t.in_c, t.in_bn, LM_AFFINE); return in; }
+    for (int i = 1; i < 4; ++i) if (conv == t.e_c3[i]) { affine(t.e_c1[i - 1], t.e_bn[i - 1], LM_POOL); return in; }
+    if (conv == t.b_c3) { affine(t.e_c1[3], t.e_bn[3], LM_POOL); return in; }
+    for (int j = 0; j < 4; ++j) {
+        if (conv == t.d_ca[j]) {
+            const int lo_c = j == 0 ? t.b_c1 : t.d_c1[j - 1], lo_bn = j == 0 ? t.b_bn : t.d_bnb[j - 1];
+            const int sk = 3 - j;
+            affine(lo_c, lo_bn, LM_UPADD);
+            in.in2 = c.act(t.e_c1[sk]); in.sc2 = c.bn_scale(t.e_bn[sk]); in.sh2 = c.bn_shift(t.e_bn[sk]);
+            return in;
+        }
+        if (conv == t.d_c3[j]) { affine(t.d_ca[j], t.d_bna[j], LM_AFFINE); return in; }
+        if (conv == t.d_c1[j]) { in.in = c.act(t.d_c3[j]); in.lmode = LM_RAW; return in; }
+    }
+    for (int i = 0; i < 4; ++i) if (conv == t.e_c1[i]) { in.in = c.act(t.e_c3[i]); in.lmode = LM_RAW; return in; }
+    if (conv == t.b_c1) { in.in = c.act(t.b_c3); in.lmode = LM_RAW; return in; }
+    if (conv == t.out) { affine(t.d_c1[3], t.d_bnb[3], LM_AFFINE); return in; }
+    return in;
+}
+
+int bn_of_conv(const Topo &t, int conv) {  // the BN that directly follows a conv, or -1
+    if (conv == t.in_c) return t.in_bn;
+    for (int i = 0; i < 4; ++i) if (conv == t.e_c1[i]) return t.e_bn[i];
+    if (conv == t.b_c1) return t.b_bn;
+    for (int j = 0; j < 4; ++j) { if (conv == t.d_ca[j]) return t.d_bna[j]; if (conv == t.d_c1[j]) return t.d_bnb[j]; }
+    return -1;
+}
+
+int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw) {
+    const ImkLayer &l = c.p->layers[conv];
+    const Dim d = res_dim(c.p->cfg, l.res);
+    ImkConvArgs a{};
+    a.x = conv_input(c, conv, x_u8);
+    a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
+    a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+    a.wpk = c.wfwd(conv);
+    a.bias = c.params + l.off_b;
+    a.out = c.act(conv);
+    a.epi = EP_RELU;
+    const int bn = bn_of_conv(c.t, conv);
+    if (c.train && bn >= 0) a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].stats_partial);
+    int rc = imk_launch_conv(a, c.stream);
+    if (rc) return rc;
+    if (c.train && bn >= 0) {
+        const ImkLayer &b = c.p->layers[bn];
+        const int cs = imk_pad8(b.cout);
+        float *sc = reinterpret_cast<float *>(c.base + c.ws.L[bn].scale);
+        float *sv = reinterpret_cast<float *>(c.base + c.ws.L[bn].save);
+        rc = imk_launch_bn_finalize(a.stats_partial, c.ws.L[bn].n_stats_tiles, b.cout, cs, (double)c.B * d.h * d.w,
+                                    c.params + b.off_w, c.params + b.off_b, params_rw + b.off_mean, params_rw + b.off_var,
+                                    sc, sc + cs, sv, sv + cs, c.stream);
+    }
+    return rc;
+}
+
+int run_forward(Ctx &c, const uint8_t *x, float *probs, float *params_rw) {
+    const Topo &t = c.t;
+    int rc;
+#define RUN(conv) do { rc = run_conv_fwd(c, (conv), x, params_rw); if (rc) return rc; } while (0)
+    RUN(t.in_c);
+    for (int i = 0; i < 4; ++i) { RUN(t.e_c3[i]); RUN(t.e_c1[i]); }
+    RUN(t.b_c3); RUN(t.b_c1);
+    for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN(t.d_c3[j]); RUN(t.d_c1[j]); }
+#undef RUN
+    const ImkLayer &o = c.p->layers[t.out];
+    const int bn = t.d_bnb[3];
+    return imk_launch_head(c.act(t.d_c1[3]), c.bn_scale(bn), c.bn_shift(bn), c.params + o.off_w, c.params + o.off_b,
+                           o.cin, imk_pad8(o.cin), o.cout, c.p->cfg.act_out, (long long)c.B * c.p->cfg.h * c.p->cfg.w,
+                           probs, c.stream);
+}
+
+bool cfg_ok(const imk_unet_cfg *c) {
+    if (!c) return false;
+    if (c->h <= 0 || c->w <= 0 || (c->h % 16) || (c->w % 16)) return false;
+    if (c->c_in < 1 || c->c_in > 8 || c->n_out < 1 || c->n_out > 64) return false;
+    for (int i = 0; i < 5; ++i) if (c->ch[i] < 1 || c->ch[i] > 512) return false;
+    if (imk_pad8(c->ch[0]) > 32) return false;  // head kernel instantiations
+    return c->act_out == 0 || c->act_out == 1;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out) {
+    IMK_CHECK_ARG(out);
+    if (!cfg_ok(cfg)) return IMK_EINVAL;
+    imk_unet_plan *p = new (std::nothrow) imk_unet_plan();
+    if (!p) return IMK_EINVAL;
+    p->cfg = *cfg;
+    build_layers(p);
+    *out = p;
+    return IMK_OK;
+}
+
+extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) { delete plan; }
+
+extern "C" int imk_unet_param_count(const imk_unet_plan *plan, int64_t *total, int64_t *trainable) {
+    IMK_CHECK_ARG(plan);
+    if (total) *total = plan->n_total;
+    if (trainable) *trainable = plan->n_trainable;
+    return IMK_OK;
+}
+
+extern "C" int imk_unet_num_layers(const imk_unet_plan *plan) { return plan ? (int)plan->layers.size() : IMK_EINVAL; }
+
+extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer_info *out) {
+    IMK_CHECK_ARG(plan && out && idx >= 0 && idx < (int)plan->layers.size());
+    const ImkLayer &l = plan->layers[idx];
+    memset(out, 0, sizeof *out);
+    strncpy(out->name, l.name.c_str(), sizeof(out->name) - 1);
+    out->kind = l.kind; out->ksize = l.ksize; out->cin = l.cin; out->cout = l.cout;
+    out->off_w = l.off_w; out->off_b = l.off_b; out->off_mean = l.off_mean; out->off_var = l.off_var;
+    return IMK_OK;
+}
+
+extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return plan ? plan->packed_bytes : IMK_EINVAL; }
+
+extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_CHECK_ARG(plan && params && packed);
+    uint8_t *pk = (uint8_t *)packed;
+    const int out_idx = plan->find("out");
+    for (size_t i = 0; i < plan->layers.size(); ++i) {
+        const ImkLayer &l = plan->layers[i];
+        int rc = 0;
+        if (l.kind == 0) {
+            if ((int)i != out_idx)
+                rc = imk_launch_pack_conv(params + l.off_w, l.ksize, l.cin, l.cout, 0, (f16 *)(pk + l.pk_fwd), stream);
+            if (!rc) rc = imk_launch_pack_conv(params + l.off_w, l.ksize, l.cin, l.cout, 1, (f16 *)(pk + l.pk_bwd), stream);
+        } else {
+            float *sc = (float *)(pk + l.pk_scale);
+            rc = imk_launch_bn_fold(params + l.off_w, params + l.off_b, params + l.off_mean, params + l.off_var, l.cout,
+                                    imk_pad8(l.cout), sc, sc + imk_pad8(l.cout), stream);
+        }
+        if (rc) return rc;
+    }
+    return IMK_OK;
+}
+
+extern "C" int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode) {
+    if (!plan || batch <= 0 || (mode != 0 && mode != 1)) return IMK_EINVAL;
+    return (int64_t)make_ws(plan, batch, mode).total;
+}
+
+extern "C" int imk_unet_forward(const imk_unet_plan *plan, const float *params, const void *packed, const uint8_t *x,
+                                int batch, float *probs, void *workspace, int64_t workspace_bytes, void *stream_) {
+    IMK_CHECK_ARG(plan && params && packed && x && probs && workspace && batch > 0);
+    Ctx c{plan, make_topo(plan), make_ws(plan, batch, 0), (uint8_t *)workspace, params, (const uint8_t *)packed, batch,
+          false, (hipStream_t)stream_};
+    if ((int64_t)c.ws.total > workspace_bytes) return IMK_EWORKSPACE;
+    return run_forward(c, x, probs, nullptr);
+}
+
+extern "C" int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
+                                    int64_t *byte_offset, int *h, int *w, int *c, int *c_stride) {
+    IMK_CHECK_ARG(plan && batch > 0 && layer_idx >= 0 && layer_idx < (int)plan->layers.size());
+    IMK_CHECK_ARG(mode == 0 || mode == 1);
+    const Ws ws = make_ws(plan, batch, mode);
+    const ImkLayer &l = plan->layers[layer_idx];
+    const Dim d = res_dim(plan->cfg, l.res);
+    size_t off = 0;
+    if (which == 0 && l.kind == 0 && layer_idx != plan->find("out")) off = ws.L[layer_idx].out;
+    else if (which == 1 && l.kind == 0 && mode == 1) off = ws.L[layer_idx].dA;
+    else if (which == 2 && l.kind == 1 && mode == 1) off = ws.L[layer_idx].dy;
+    else return IMK_EINVAL;
+    if (byte_offset) *byte_offset = (int64_t)off;
+    if (h) *h = d.h;
+    if (w) *w = d.w;
+    if (c) *c = l.cout;
+    if (c_stride) *c_stride = imk_pad8(l.cout);
+    return IMK_OK;
+}
+
+// Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
+extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, const float *const *params,
+                                   const void *const *packed, const uint8_t *x, int batch, float thr, int cmp_ge,
+                                   const uint8_t *img, int block_in, int block_out, uint8_t *img_out, uint8_t *masks_out,
+                                   uint8_t *im_out, int64_t *im_size, int64_t *pred_size, uint8_t *presence,
+                                   void *workspace, int64_t workspace_bytes, void *stream_) {
+    IMK_CHECK_ARG(plan && params && packed && x && workspace && batch > 0 && n_models > 0);
+    const imk_unet_cfg &cf = plan->cfg;
+    const size_t probs_one = up((size_t)batch * cf.h * cf.w * cf.n_out * sizeof(float));
+    const Ws ws = make_ws(plan, batch, 0);
+    if ((int64_t)(probs_one * n_models + ws.total) > workspace_bytes) return IMK_EWORKSPACE;
+    // the probability stack must be contiguous [N,B,H,W,K]: only the last slab may be padded
+    const size_t probs_exact = (size_t)batch * cf.h * cf.w * cf.n_out * sizeof(float);
+    uint8_t *base = (uint8_t *)workspace;
+    for (int m = 0; m < n_models; ++m) {
+        Ctx c{plan, make_topo(plan), ws, base + probs_one * n_models, params[m], (const uint8_t *)packed[m], batch, false,
+              (hipStream_t)stream_};
+        int rc = run_forward(c, x, (float *)(base + probs_exact * m), nullptr);
+        if (rc) return rc;
+    }
+    if (cf.act_out == 0)
+        return imk_im_binary((const float *)base, n_models, batch, cf.h, cf.w, cf.n_out, thr, cmp_ge, img, cf.c_in, block_in,
+                             block_out, img_out, masks_out, im_out, im_size, pred_size, stream_);
+    return imk_im_multiclass((const float *)base, n_models, batch, cf.h, cf.w, cf.n_out, img, cf.c_in, block_in, block_out,
+                             img_out, masks_out, im_out, im_size, presence, stream_);
+}
+
+// =====================================================================================================
+// training
+// =====================================================================================================
+namespace {
+struct StateView { float *m, *v; ImkCtl *ctl; };
+StateView state_view(const imk_unet_plan *p, void *state) {
+    uint8_t *b = (uint8_t *)state;
+    const size_t n = up((size_t)p->n_trainable * sizeof(float));
+    return StateView{(float *)b, (float *)(b + n), (ImkCtl *)(b + 2 * n)};
+}
+
+struct Bwd {
+    Ctx &c;
+    const uint8_t *x;
+    float *grads;
+    ImkCtl *ctl;
+    float *wg_partial;
+
+    // dgrad of `conv`: input dA[conv] -> dst, optionally masked by the ReLU of the tensor `mask`
+    int dgrad(int conv, f16 *dst, const f16 *mask) {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        ImkConvArgs a{};
+        a.x.in = c.dA(conv); a.x.lmode = LM_RAW; a.x.cin = l.cout; a.x.cs_in = imk_pad8(l.cout);
+        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
+        a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
+        a.wpk = c.wbwd(conv);
+        a.out = dst;
+        a.mask = mask;
+        a.epi = mask ? EP_MASK : EP_PLAIN;
+        return imk_launch_conv(a, c.stream);
+    }
+    int wgrad(int conv, const f16 *dA_override = nullptr) {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        ImkWgradArgs a{};
+        a.x = conv_input(c, conv, x);
+        a.dA = dA_override ? dA_override : c.dA(conv);
+        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+        a.partial = wg_partial;
+        a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
+        int rc = imk_launch_wgrad(a, c.stream);
+        if (rc) return rc;
+        return imk_launch_wgrad_finalize(wg_partial, a.n_split, l.ksize, l.cin, l.cout, &ctl->inv_loss_scale,
+                                         grads + l.off_w, grads + l.off_b, &ctl->found_inf, c.stream);
+    }
+    // BN backward for `bn` whose output gradient is dy[bn] (already assembled unless mode != 0), producing
+    // dA of the conv that feeds it.
+    int bn_bwd(int bn, int mode, const f16 *g_direct, const f16 *g_other) {
+        const ImkLayer &b = c.p->layers[bn];
+        const Dim d = res_dim(c.p->cfg, b.res);
+        const int cs = imk_pad8(b.cout);
+        const int prod = bn_producer(c.t, bn);
+        const LayerWs &lw = c.ws.L[bn];
+        float *partial = reinterpret_cast<float *>(c.base + lw.bwd_partial);
+        float *coef = reinterpret_cast<float *>(c.base + lw.coef);
+        const float *save = reinterpret_cast<const float *>(c.base + lw.save);
+        const f16 *z = c.act(prod);
+        int rc = imk_launch_bn_bwd_prep(mode, mode == 0 ? c.dy(bn) : g_direct, g_other, z, c.bn_scale(bn), c.bn_shift(bn),
+                                        c.dy(bn), partial, c.B, d.h, d.w, cs, c.stream);
+        if (rc) return rc;
+        rc = imk_launch_bn_bwd_coef(partial, imk_bn_prep_blocks(c.B, d.h, d.w, cs), b.cout, cs, (double)c.B * d.h * d.w,
+                                    c.params + b.off_w, save, save + cs, &ctl->inv_loss_scale, coef, grads + b.off_w,
+                                    grads + b.off_b, &ctl->found_inf, c.stream);
+        if (rc) return rc;
+        return imk_launch_bn_bwd_apply(c.dy(bn), z, coef, cs, (long long)c.B * d.h * d.w, c.dA(prod), c.stream);
+    }
+};
+}  // namespace
+
+extern "C" int64_t imk_unet_state_bytes(const imk_unet_plan *plan) {
+    if (!plan) return IMK_EINVAL;
+    return (int64_t)(2 * up((size_t)plan->n_trainable * sizeof(float)) + up(sizeof(ImkCtl)));
+}
+
+extern "C" int imk_unet_state_init(const imk_unet_plan *plan, void *state, void *stream_) {
+    IMK_CHECK_ARG(plan && state);
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_HIP(hipMemsetAsync(state, 0, (size_t)imk_unet_state_bytes(plan), stream));
+    return imk_launch_ctl_init(state_view(plan, state).ctl, stream);
+}
+
+extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state, const uint8_t *x,
+                                const uint8_t *y, int batch, int loss_kind, float *grads, float *stats, void *workspace,
+                                int64_t workspace_bytes, void *stream_) {
+    IMK_CHECK_ARG(plan && params && packed && state && x && y && grads && stats && workspace && batch > 0);
+    IMK_CHECK_ARG(loss_kind == 0 || loss_kind == 1);
+    IMK_CHECK_ARG((loss_kind == 0) == (plan->cfg.act_out == 0));  // mse <-> sigmoid head, cce <-> softmax head
+    hipStream_t stream = (hipStream_t)stream_;
+    Ctx c{plan, make_topo(plan), make_ws(plan, batch, 1), (uint8_t *)workspace, params, (const uint8_t *)packed, batch, true,
+          stream};
+    if ((int64_t)c.ws.total > workspace_bytes) return IMK_EWORKSPACE;
+    const StateView sv = state_view(plan, state);
+    const imk_unet_cfg &cf = plan->cfg;
+    const Topo &t = c.t;
+    const long long n_pix = (long long)batch * cf.h * cf.w;
+    int rc;
+#define OK(e) do { rc = (e); if (rc) return rc; } while (0)
+    OK(imk_launch_ctl_begin(sv.ctl, stream));
+    float *probs = reinterpret_cast<float *>(c.base + c.ws.probs);
+    OK(run_forward(c, x, probs, params));
+
+    // loss and d(loss*scale)/d(logits)
+    f16 *dlogit = reinterpret_cast<f16 *>(c.base + c.ws.dlogit);
+    float *loss_partial = reinterpret_cast<float *>(c.base + c.ws.loss_partial);
+    OK(imk_launch_loss_grad(probs, y, cf.n_out, imk_pad8(cf.n_out), loss_kind, n_pix, sv.ctl, dlogit, loss_partial, stats,
+                            stream));
+
+    Bwd b{c, x, grads, sv.ctl, reinterpret_cast<float *>(c.base + c.ws.wgrad_partial)};
+    // head: its "dA" is dlogit
+    OK(b.wgrad(t.out, dlogit));
+    {
+        const ImkLayer &l = plan->layers[t.out];
+        ImkConvArgs a{};
+        a.x.in = dlogit; a.x.lmode = LM_RAW; a.x.cin = l.cout; a.x.cs_in = imk_pad8(l.cout);
+        a.B = batch; a.H = cf.h; a.W = cf.w; a.ksize = 1; a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
+        a.wpk = c.wbwd(t.out); a.out = c.dy(t.d_bnb[3]); a.epi = EP_PLAIN;
+        OK(imk_launch_conv(a, stream));
+    }
+    // decoders 9..6
+    for (int j = 3; j >= 0; --j) {
+        f16 *dU = reinterpret_cast<f16 *>(c.base + c.ws.dU[j]);
+        if (j == 3) OK(b.bn_bwd(t.d_bnb[j], 0, nullptr, nullptr));
+        else OK(b.bn_bwd(t.d_bnb[j], 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[j + 1])));
+        OK(b.wgrad(t.d_c1[j]));
+        OK(b.dgrad(t.d_c1[j], c.dA(t.d_c3[j]), c.act(t.d_c3[j])));
+        OK(b.wgrad(t.d_c3[j]));
+        OK(b.dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr));
+        OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
+        OK(b.wgrad(t.d_ca[j]));
+        OK(b.dgrad(t.d_ca[j], dU, nullptr));
+    }
+    // bottleneck: dy = 2x2 sum of dU[decoder 6]
+    OK(b.bn_bwd(t.b_bn, 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[0])));
+    OK(b.wgrad(t.b_c1));
+    OK(b.dgrad(t.b_c1, c.dA(t.b_c3), c.act(t.b_c3)));
+    OK(b.wgrad(t.b_c3));
+    OK(b.dgrad(t.b_c3, reinterpret_cast<f16 *>(c.base + c.ws.dP[3]), nullptr));
+    // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
+    for (int i = 3; i >= 0; --i) {
+        OK(b.bn_bwd(t.e_bn[i], 1, reinterpret_cast<f16 *>(c.base + c.ws.dU[3 - i]),
+                    reinterpret_cast<f16 *>(c.base + c.ws.dP[i])));
+        OK(b.wgrad(t.e_c1[i]));
+        OK(b.dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
+        OK(b.wgrad(t.e_c3[i]));
+        f16 *dst = i > 0 ? reinterpret_cast<f16 *>(c.base + c.ws.dP[i - 1]) : c.dy(t.in_bn);
+        OK(b.dgrad(t.e_c3[i], dst, nullptr));
+    }
+    OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
+    OK(b.wgrad(t.in_c));
+    OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, sv.ctl, stats, stream));
+#undef OK
+    return IMK_OK;
+}
+
+extern "C" int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, void *state,
+                                   const float *grads, const float *stats, float grad_scale, float lr, float wd,
+                                   float beta1, float beta2, float eps, void *stream_) {
+    IMK_CHECK_ARG(plan && params && packed && state && grads && stats);
+    const StateView sv = state_view(plan, state);
+    int rc = imk_launch_adamw(params, sv.m, sv.v, grads, plan->n_trainable, sv.ctl, stats, grad_scale, lr, wd, beta1, beta2,
+                              eps, (hipStream_t)stream_);
+    if (rc) return rc;
+    return imk_unet_pack_weights(plan, params, packed, stream_);
+}

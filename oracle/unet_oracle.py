@@ -99,6 +99,19 @@ class _RoundF16(torch.autograd.Function):
         return g.half().float()
 
 
+class _RoundF16Fwd(torch.autograd.Function):
+    """Round to fp16 in forward only: used for the fp16 copy of the fp32 master weights (their gradient
+    is accumulated and kept in fp32 by the HIP path, like Keras keeps variable gradients in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def _r(x, on):
     return _RoundF16.apply(x) if on else x
 
@@ -107,7 +120,7 @@ def _conv(x, w, b, relu, f16):
     k = w.shape[0]
     wt = w.permute(3, 2, 0, 1)
     if f16:
-        wt = _RoundF16.apply(wt)
+        wt = _RoundF16Fwd.apply(wt)
     y = F.conv2d(x, wt, b, padding=k // 2)
     if relu:
         y = F.relu(y)
@@ -130,9 +143,13 @@ def _bn(x, p, name, training, f16, stats_out):
 
 
 def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_fp16=False,
-            stats_out=None, taps=None):
+            stats_out=None, taps=None, override=None, return_logits=False):
     """x uint8 [B,H,W,C] (numpy or torch) -> probabilities float32 [B,H,W,K] (torch).
-    `taps`, if a dict, receives every stored intermediate in NHWC float32 (pre-BN conv outputs)."""
+    `taps`, if a dict, receives every stored intermediate in NHWC float32 (pre-BN conv outputs).
+    `override`, if a dict name -> NHWC float32 tensor, replaces the VALUE of that conv output while
+    keeping the autograd graph (straight-through): gradients can then be compared with an
+    implementation whose forward values differ by fp16 rounding noise, without the chaotic
+    amplification through ReLU masks / max-pool arg-maxes."""
     f16 = emulate_fp16
     x = torch.as_tensor(np.asarray(x_u8_nhwc)).float().permute(0, 3, 1, 2) / 255.0
     x = _r(x, f16)
@@ -143,6 +160,10 @@ def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_f
 
     def c(name, t, relu=True):
         y = _conv(t, p[name + ".w"], p[name + ".b"], relu, f16)
+        if override is not None and name in override:
+            ov = torch.as_tensor(override[name]).float().permute(0, 3, 1, 2)
+            mask = (ov > 0).float() if relu else 1.0          # the ReLU decision follows the overriding values
+            y = y * mask + (ov - y * mask).detach()
         tap(name, y)
         return y
 
@@ -165,14 +186,23 @@ def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_f
     w = p["out.w"].permute(3, 2, 0, 1)
     logits = F.conv2d(y, w, p["out.b"])
     probs = torch.sigmoid(logits) if act_out == "sigmoid" else torch.softmax(logits, dim=1)
-    return probs.permute(0, 2, 3, 1).contiguous()
+    probs = probs.permute(0, 2, 3, 1).contiguous()
+    if return_logits:
+        return probs, logits.permute(0, 2, 3, 1).contiguous()
+    return probs
 
 
-def loss_fn(probs, target, kind):
+def loss_fn(probs, target, kind, logits=None):
     """'mse' : mean over all elements of (p - t)^2, t in {0,1} [B,H,W,K]   (Keras 'mse')
-       'cce' : mean over pixels of -sum_k t_k log(clip(p_k, 1e-7, 1-1e-7)), t one-hot [B,H,W,K]"""
+       'cce' : mean over pixels of -sum_k t_k log softmax(logits)_k, t one-hot [B,H,W,K].
+               Keras' CategoricalCrossentropy() on the output of a softmax ACTIVATION goes back to the
+               cached logits (backend.categorical_crossentropy, `_keras_logits`), i.e. no probability
+               clipping and d loss / d logits = p - t exactly.  (Third-party behaviour, unpinned.)
+               Without logits the clipped-probability form [1e-7, 1-1e-7] is used."""
     if kind == "mse":
         return ((probs - target) ** 2).mean()
+    if logits is not None:
+        return -(target * torch.log_softmax(logits, dim=-1)).sum(-1).mean()
     pc = probs.clamp(1e-7, 1 - 1e-7)
     return -(target * pc.log()).sum(-1).mean()
 
@@ -188,7 +218,7 @@ def new_opt_state(p):
 
 def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
                lr=3e-3, wd=1e-4, b1=0.9, b2=0.999, eps=1e-7, emulate_fp16=False, loss_scale=1.0,
-               return_grads=False):
+               return_grads=False, override=None):
     """One step of forward(train) -> loss -> backward -> tfa-AdamW, in place on p / opt.
     Returns (loss, grads?)"""
     names = trainable_names(p)
@@ -196,10 +226,10 @@ def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
     q = dict(p)
     q.update(leaves)
     stats = {}
-    probs = forward(q, x_u8, c_in, n_out, alpha, act_out, training=True, emulate_fp16=emulate_fp16,
-                    stats_out=stats)
+    probs, logits = forward(q, x_u8, c_in, n_out, alpha, act_out, training=True, emulate_fp16=emulate_fp16,
+                            stats_out=stats, override=override, return_logits=True)
     t = torch.as_tensor(np.asarray(target)).float()
-    loss = loss_fn(probs, t, loss_kind)
+    loss = loss_fn(probs, t, loss_kind, logits if act_out == "softmax" else None)
     (loss * loss_scale).backward()
     grads = {k: leaves[k].grad / loss_scale for k in names}
     opt["step"] += 1

@@ -1,0 +1,119 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol include/imk.h declares; the
+plan/parameter layout agrees with the oracle's reading of unet.py; host logic (sharding, reductions)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    from inconsistencymasks_amd.build import build_lib
+    return build_lib()
+
+
+def test_header_symbols_exported(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "imk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(imk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from inconsistencymasks_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(built_lib)
+    for name in declared:
+        getattr(lib, name)
+    assert _lib.lib.imk_version() == 100
+    assert _lib.lib.imk_error_string(-1) == b"invalid argument"
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import importlib.util, sys\n"
+            f"spec = importlib.util.spec_from_file_location('x', r'{ROOT}/inconsistencymasks_amd/_lib.py')\n"
+            "m = importlib.util.module_from_spec(spec)\n"
+            f"import os; os.path.exists = lambda p, _e=os.path.exists: False if p.endswith('libimk.so') else _e(p)\n"
+            "try:\n    spec.loader.exec_module(m)\n    print('LOADED')\nexcept RuntimeError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout
+    assert "RAISED True" in out
+
+
+CFGS = [(256, 256, 3, 1, 0.5, "sigmoid"), (256, 256, 1, 3, 1.0, "sigmoid"), (256, 256, 3, 9, 1.0, "softmax"),
+        (208, 416, 3, 35, 1.0, "softmax"), (256, 256, 3, 9, 2.0, "softmax"), (64, 64, 3, 1, 1.25, "sigmoid")]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_plan_matches_oracle_layer_table(built_lib, cfg):
+    from inconsistencymasks_amd.unet import Plan
+    from oracle import unet_oracle as U
+    h, w, c, k, alpha, act = cfg
+    p = Plan(h, w, c, k, alpha, act)
+    total, trainable = U.count_params(c, k, alpha)
+    assert (p.n_total, p.n_trainable) == (total, trainable)
+    table = U.layer_table(c, k, alpha)
+    assert [l["name"] for l in p.layers] == [t[0] for t in table]
+    off = 0
+    for l, t in zip(p.layers, table):
+        assert (l["kind"], l["ksize"], l["cin"], l["cout"]) == ({"conv": 0, "bn": 1}[t[1]], t[2], t[3], t[4])
+        assert l["off_w"] == off
+        if l["kind"] == 0:
+            off += t[2] * t[2] * t[3] * t[4]
+            assert l["off_b"] == off
+            off += t[4]
+        else:
+            assert l["off_b"] == off + t[4]
+            off += 2 * t[4]
+    assert off == trainable
+    assert p.workspace_bytes(8, 1) > p.workspace_bytes(8, 0) > 0
+    assert p.workspace_bytes(16, 0) > p.workspace_bytes(8, 0)
+    assert p.packed_bytes > 0 and p.state_bytes >= 8 * trainable
+
+
+def test_published_param_counts(built_lib):
+    """README.md:25 of the reference: 0.17 M ... 2.72 M parameters."""
+    from inconsistencymasks_amd.unet import Plan
+    assert Plan(256, 256, 3, 1, 0.5, "sigmoid").n_total == 171561
+    assert Plan(256, 256, 3, 9, 2.0, "softmax").n_total == 2717865
+
+
+def test_plan_rejects_bad_config(built_lib):
+    from inconsistencymasks_amd._lib import ImkError
+    from inconsistencymasks_amd.unet import Plan
+    with pytest.raises(ImkError):
+        Plan(250, 256, 3, 1, 0.5, "sigmoid")      # not a multiple of 16
+    with pytest.raises(ValueError):
+        Plan(256, 256, 3, 1, 0.5, "tanh")
+
+
+def test_shard_list_partitions():
+    from inconsistencymasks_amd.functions import shard_list
+    names = [f"img_{i:04d}.png" for i in np.random.default_rng(0).permutation(2335)]
+    for world in (1, 2, 4, 8):
+        parts = [shard_list(names, r, world) for r in range(world)]
+        assert sum(parts, []) == sorted(names)                       # contiguous blocks of the sorted list
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_metric_helpers_golden(golden_dir):
+    from inconsistencymasks_amd import functions as F
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for k in g["cases"]:
+        assert F.get_IoU_binary(g[k + "_gt"], g[k + "_pr"]) == pytest.approx(float(g[k + "_iou"][0]), abs=1e-12)
+        assert F.dice_score_numpy_binary(g[k + "_gt"], g[k + "_pr"]) == pytest.approx(float(g[k + "_dice"][0]), abs=1e-7)
+
+
+def test_parse_mask_rule(tmp_path):
+    """functions.py:975: uint8(mask/255) keeps only 255."""
+    from inconsistencymasks_amd import functions as F
+    os.makedirs(tmp_path / "images")
+    os.makedirs(tmp_path / "masks")
+    ramp = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    F.write_png(str(tmp_path / "masks" / "a.png"), ramp)
+    F.write_png(str(tmp_path / "images" / "a.png"), np.stack([ramp] * 3, -1))
+    img, mask = F.parse_image_ISIC_2018(str(tmp_path / "images" / "a.png"))
+    assert img.shape == (16, 16, 3) and np.array_equal(img[..., 1], ramp)
+    assert mask.shape == (16, 16, 1) and mask.sum() == 1 and mask.reshape(-1)[255] == 1

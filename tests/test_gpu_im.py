@@ -1,0 +1,131 @@
+"""GPU parity of the fused IM kernels against the oracle and the golden vectors (through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import im_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def im():
+    assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
+    from inconsistencymasks_amd import im as m
+    return m
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def test_binary_golden(im, golden_dir):
+    g = np.load(os.path.join(golden_dir, "im_binary.npz"))
+    for k in g["cases"]:
+        preds = torch.from_numpy(g[k + "_preds"]).cuda()          # [N,1,H,W,1]
+        r = im.im_binary(preds, 0.5, False, block_out=False)
+        assert np.array_equal(_np(r["masks"])[0, 0], g[k + "_final"]), k
+        assert np.array_equal(_np(r["im"])[0], g[k + "_im"]), k
+        assert [int(r["im_size"][0, 0]), int(r["pred_size"][0, 0])] == g[k + "_sizes"].tolist(), k
+
+
+def test_hela_golden(im, golden_dir):
+    g = np.load(os.path.join(golden_dir, "im_hela.npz"))
+    for k in g["cases"]:
+        preds = torch.from_numpy(g[k + "_preds"]).cuda()          # [N,1,H,W,3]
+        r = im.im_binary(preds, 0.5, True, block_out=False)
+        m = _np(r["masks"])[0]
+        for c, nm in enumerate(("alive", "dead", "pos")):
+            assert np.array_equal(m[c], g[f"{k}_{nm}"]), (k, nm)
+        assert np.array_equal(_np(r["im"])[0], g[k + "_im"]), k
+        assert int(r["im_size"][0].sum()) == int(g[k + "_sizes"][0]), k
+
+
+def test_multiclass_golden(im, golden_dir):
+    g = np.load(os.path.join(golden_dir, "im_multiclass.npz"))
+    for k in g["cases"]:
+        probs = torch.from_numpy(g[k + "_preds"]).cuda()          # [N,1,H,W,K]
+        r = im.im_multiclass(probs, block_out=False)
+        assert np.array_equal(_np(r["final"])[0], g[k + "_final"]), k
+        assert np.array_equal(_np(r["im"])[0], g[k + "_im"]), k
+        assert int(r["im_size"][0]) == int(g[k + "_sizes"][0]), k
+        pres = _np(r["presence"])[:, 0]
+        assert int(np.all(pres == pres[0:1])) == int(g[k + "_lists_equal"][0]), k
+        assert np.array_equal(pres, O.im_multiclass(g[k + "_preds"][:, 0])["presence"]), k
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 256, 256, 1, 3), (3, 2, 64, 48, 3, 1), (4, 2, 35, 21, 1, 3), (2, 5, 16, 16, 1, 1)])
+@pytest.mark.parametrize("bi,bo", [(True, True), (False, True), (True, False)])
+def test_binary_batch_vs_oracle(im, shape, bi, bo):
+    n, b, h, w, kb, c = shape
+    rng = np.random.default_rng(h * w + n)
+    base = rng.random((1, b, h, w, kb), dtype=np.float32)
+    preds = np.clip(base + (rng.random((n, b, h, w, kb), dtype=np.float32) - 0.5) * 0.3, 0, 1).astype(np.float32)
+    preds[0, 0, 0, :4, 0] = [0.5, np.nan, 0.50000006, 0.49999997][:min(4, w)]
+    img = rng.integers(1, 256, (b, h, w, c)).astype(np.uint8)
+    ge = kb == 3
+    r = im.im_binary(torch.from_numpy(preds).cuda(), 0.5, ge, torch.from_numpy(img).cuda(), bi, bo)
+    for i in range(b):
+        e = O.im_binary(preds[:, i], 0.5, ge)
+        eimg, emasks = O.block(img[i], list(e["final"]), e["im"], bi, bo)
+        assert np.array_equal(_np(r["im"])[i], e["im"])
+        assert np.array_equal(_np(r["masks"])[i], np.stack(emasks))
+        assert np.array_equal(_np(r["img_out"])[i], eimg)
+        assert _np(r["im_size"])[i].tolist() == e["im_size_ch"].tolist()
+        assert _np(r["pred_size"])[i].tolist() == e["pred_size_ch"].tolist()
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 256, 256, 9, 3), (2, 2, 208, 416, 35, 3), (2, 3, 13, 26, 35, 3), (3, 1, 17, 9, 4, 1)])
+def test_multiclass_batch_vs_oracle(im, shape):
+    n, b, h, w, k, c = shape
+    rng = np.random.default_rng(k * 7 + h)
+    base = rng.random((1, b, h, w, k), dtype=np.float32)
+    probs = (base + 0.2 * rng.random((n, b, h, w, k), dtype=np.float32)).astype(np.float32)
+    probs[:, :, : h // 3] = np.round(probs[:, :, : h // 3] * 3) / 3   # exact ties
+    img = rng.integers(1, 256, (b, h, w, c)).astype(np.uint8)
+    r = im.im_multiclass(torch.from_numpy(probs).cuda(), torch.from_numpy(img).cuda(), True, True)
+    for i in range(b):
+        e = O.im_multiclass(probs[:, i])
+        eimg, (efinal,) = O.block(img[i], [e["final"]], e["im"], True, True)
+        assert np.array_equal(_np(r["im"])[i], e["im"])
+        assert np.array_equal(_np(r["final"])[i], efinal)
+        assert np.array_equal(_np(r["img_out"])[i], eimg)
+        assert int(r["im_size"][i]) == int(e["im_size"])
+        assert np.array_equal(_np(r["presence"])[:, i], e["presence"])
+
+
+def test_binary_properties_full_size(im):
+    """Size-independent properties at the BASELINE shape (256x256x3, N=2): N=2 binary IM == XOR of votes,
+    final & im disjoint, sizes add up, permutation invariance over models."""
+    b = 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    preds = torch.rand((2, b, 256, 256, 1), device="cuda", generator=g)
+    img = torch.randint(1, 256, (b, 256, 256, 3), device="cuda", dtype=torch.uint8, generator=g)
+    r = im.im_binary(preds, 0.5, False, img, True, False)
+    v = preds > 0.5
+    xor = (v[0] ^ v[1])[..., 0]
+    assert torch.equal(r["im"] > 0, xor)
+    assert not torch.any((r["masks"][:, 0] > 0) & (r["im"] > 0))
+    assert torch.equal(r["im_size"][:, 0], xor.sum(dim=(1, 2)))
+    assert torch.equal(r["pred_size"][:, 0], (v[0] & v[1])[..., 0].sum(dim=(1, 2)))
+    assert torch.equal(r["img_out"], img * (~xor)[..., None])
+    r2 = im.im_binary(preds.flip(0), 0.5, False, img, True, False)
+    for k in ("masks", "im", "im_size", "pred_size", "img_out"):
+        assert torch.equal(r[k], r2[k])
+
+
+def test_morph_and_block(im):
+    rng = np.random.default_rng(3)
+    m = (rng.random((3, 40, 56)) > 0.6).astype(np.uint8) * 255
+    t = torch.from_numpy(m).cuda()
+    for k in (3, 5):
+        assert np.array_equal(_np(im.morph(t, k, "erode")), np.stack([O.erode(x, k) for x in m]))
+        assert np.array_equal(_np(im.morph(t, k, "dilate")), np.stack([O.dilate(x, k) for x in m]))
+    img = rng.integers(1, 256, (3, 40, 56, 3)).astype(np.uint8)
+    masks = rng.integers(1, 256, (3, 2, 40, 56)).astype(np.uint8)
+    ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(masks).cuda()
+    im.block_apply(t, ti, tm)
+    assert np.array_equal(_np(ti), img * (m == 0)[..., None])
+    assert np.array_equal(_np(tm), masks * (m == 0)[:, None])
