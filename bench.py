@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star metric: images/sec per IM generation (ensemble inference + IM creation +
+one U-Net training epoch) on ISIC-2018-shaped synthetic data, 256x256x3, 2-model ensemble, alpha = 0.5.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+One "step" = one IM generation over this rank's shard of the image set:
+  1. N-model ensemble forward over the U unlabeled images (batches of --infer-batch) fused with the IM chain
+     (threshold -> agreement -> IM -> blocking -> sizes)                       functions.py:2844-2887
+  2. keep rule pred_size > im_size and pred_size > 0                           functions.py:2878-2886
+  3. one epoch (steps = n_images // 32, batch 32) of a fresh U-Net on kept pseudo-labels + labelled set,
+     mse loss, tfa-AdamW(3e-3, 1e-4)                                            functions.py:207-218
+Inputs are resident in HBM when the timed region starts (PNG decode/encode is excluded on both the GPU and
+the CPU side).  Multi-GPU: every rank owns a full-size shard (weak scaling), inference/IM need no collective,
+the training step all-reduces one flat fp32 gradient buffer (RCCL).  value = images of all ranks / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 256
+C = 3
+K = 1
+ALPHA = 0.5
+N_MODELS = 2
+U_UNLABELED = 2335      # ISIC-2018 Task-1: 2594 train images, 10/90 split
+U_LABELED = 259
+BATCH = 32
+LR, WD = 3e-3, 1e-4
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_images(n, seed, device):
+    """Seeded ISIC-like images: smooth low-frequency field + elliptical 'lesion' + noise; mask = the ellipse."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    yy = torch.arange(H, device=device, dtype=torch.float32)[None, :, None]
+    xx = torch.arange(W, device=device, dtype=torch.float32)[None, None, :]
+    r = lambda *s: torch.rand(*s, device=device, generator=g)
+    field = torch.zeros((n, H, W), device=device)
+    for _ in range(4):
+        fy, fx, ph = r(n, 1, 1) * 0.05, r(n, 1, 1) * 0.05, r(n, 1, 1) * 6.28
+        field += torch.cos(yy * fy + xx * fx + ph)
+    cy, cx = (0.3 + 0.4 * r(n, 1, 1)) * H, (0.3 + 0.4 * r(n, 1, 1)) * W
+    ry, rx = (0.12 + 0.2 * r(n, 1, 1)) * H, (0.12 + 0.2 * r(n, 1, 1)) * W
+    ell = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1
+    base = 150 + 15 * field - ell * (40 + 50 * r(n, 1, 1))
+    img = base[..., None] + torch.tensor([10.0, -5.0, -15.0], device=device) + (r(n, H, W, C) * 16 - 8)
+    return img.clamp(0, 255).to(torch.uint8).contiguous(), (ell.to(torch.uint8) * 255)[..., None].contiguous()
+
+
+def _usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline():
+    """The oracle (torch-CPU fp32 restatement, reference-structured: batch-1 forward per image per model,
+    numpy IM, batch-32 training) on a bounded sample, extrapolated to one generation.  The thread count is
+    calibrated (tiny batch-1 convolutions get SLOWER with hundreds of threads) and reported as `cores`."""
+    from oracle import im_oracle, unet_oracle as U
+    rng = np.random.default_rng(0)
+    n_img = 8
+    x = rng.integers(0, 256, (max(n_img, BATCH), H, W, C)).astype(np.uint8)
+    models = [U.init_weights(C, K, ALPHA, 1000 + j) for j in range(N_MODELS)]
+    best = None
+    for nt in [n for n in (4, 8, 16, 32, 64) if n <= _usable_cpus()] or [1]:
+        torch.set_num_threads(nt)
+        U.predict_batch1(models[0], x[:1], C, K, ALPHA, "sigmoid")  # warm-up
+        t0 = time.perf_counter()
+        U.predict_batch1(models[0], x[:2], C, K, ALPHA, "sigmoid")
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+        if dt > 2 * best[1]:
+            break
+    n_threads = best[0]
+    torch.set_num_threads(n_threads)
+    t0 = time.perf_counter()
+    preds = [U.predict_batch1(m, x[:n_img], C, K, ALPHA, "sigmoid") for m in models]
+    t_inf = (time.perf_counter() - t0) / n_img                    # per image, all N models
+    t0 = time.perf_counter()
+    for i in range(n_img):
+        r = im_oracle.im_binary(np.stack([p[i] for p in preds], 0), 0.5, False)
+        im_oracle.block(x[i], [r["final"][0]], r["im"], True, True)
+    t_im = (time.perf_counter() - t0) / n_img
+    p = U.init_weights(C, K, ALPHA, 7)
+    opt = U.new_opt_state(p)
+    y = (rng.random((BATCH, H, W, K)) > 0.5).astype(np.float32)
+    t0 = time.perf_counter()
+    U.train_step(p, opt, x[:BATCH], y, C, K, ALPHA, "sigmoid", "mse")  # includes one-off autograd warm-up
+    t_first = time.perf_counter() - t0
+    n_steps = 1 if t_first > 10 else 2
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        U.train_step(p, opt, x[:BATCH], y, C, K, ALPHA, "sigmoid", "mse")
+    t_step = (time.perf_counter() - t0) / n_steps
+    steps = (U_UNLABELED + U_LABELED) // BATCH
+    t_gen = U_UNLABELED * (t_inf + t_im) + steps * t_step
+    return {"value": round(U_UNLABELED / t_gen, 3), "unit": "images/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n_img} images x {N_MODELS} models batch-1 fp32 forward + numpy IM, {n_steps} train steps of "
+                      f"batch {BATCH}; extrapolated to U={U_UNLABELED}, {steps} steps; {_usable_cpus()} CPUs usable",
+            "t_infer_per_image_s": round(t_inf, 5), "t_im_per_image_s": round(t_im, 6), "t_train_step_s": round(t_step, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--infer-batch", type=int, default=128)
+    ap.add_argument("--images", type=int, default=U_UNLABELED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pretrain-steps", type=int, default=300)
+    ap.add_argument("--bn-settle-steps", type=int, default=600)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import ctypes
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd import im as imk_im
+    from inconsistencymasks_amd._lib import lib as imk_lib
+    from inconsistencymasks_amd.unet import UNet
+
+    # ---- synthetic, HBM-resident inputs (per rank: a full-size shard -> weak scaling) -----------------
+    U = args.images
+    x_unl, _ = synth_images(U, 42 + 1000 * rank, dev)
+    x_lab, m_lab = synth_images(U_LABELED, 4242 + 1000 * rank, dev)
+    y_lab = (m_lab // 255).contiguous()
+
+    # ---- ensemble: seeded he_normal, briefly trained on the labelled set so that predictions are lesions
+    models = []
+    for j in range(N_MODELS):
+        m = UNet(H, W, C, K, ALPHA, "sigmoid", seed=1000 + j, device=dev)
+        g = torch.Generator(device=dev).manual_seed(j)
+        for it in range(args.pretrain_steps + args.bn_settle_steps):
+            idx = torch.randint(0, U_LABELED, (BATCH,), device=dev, generator=g)
+            # Keras BN momentum 0.99 needs ~500 steps before the moving statistics (what inference uses) have
+            # forgotten their initial values; the reference trains 4050 steps.  Settle them with lr = wd = 0.
+            lr, wd = (LR, WD) if it < args.pretrain_steps else (0.0, 0.0)
+            m.train_step(x_lab[idx].contiguous(), y_lab[idx].contiguous(), 0, lr, wd)
+        m.repack()   # fold the moving statistics for inference
+        models.append(m)
+    ens = F.EnsembleIM(models)
+    student = UNet(H, W, C, K, ALPHA, "sigmoid", seed=7, device=dev)
+    init_params = student.params.clone()
+    gen_perm = torch.Generator(device=dev).manual_seed(42)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    info = {}
+
+    def generation(record=None):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        imgs, masks, keep, ps, ims = [], [], [], [], []
+        for i in range(0, U, args.infer_batch):
+            r = ens.run(x_unl[i:i + args.infer_batch], 0.5, False, True, True)
+            imgs.append(r["img_out"]); masks.append(r["masks"][:, 0])
+            ps.append(r["pred_size"][:, 0]); ims.append(r["im_size"][:, 0])
+            keep.append((ps[-1] > ims[-1]) & (ps[-1] > 0))
+        keep = torch.cat(keep)
+        e1.record()
+        # training set = kept pseudo-labelled pairs + labelled pairs (the directory the reference builds)
+        kidx = torch.nonzero(keep).squeeze(1)
+        tx = torch.cat([torch.cat(imgs)[kidx], x_lab])
+        ty = torch.cat([(torch.cat(masks)[kidx] // 255)[..., None], y_lab])
+        n_train = tx.shape[0]
+        steps = n_train // BATCH
+        student.params.copy_(init_params)
+        student._packed_ok = False
+        student.init_train_state()
+        perm = torch.randperm(n_train, device=dev, generator=gen_perm)
+        for s in range(steps):
+            idx = perm[s * BATCH:(s + 1) * BATCH]
+            student.fwd_bwd(tx[idx].contiguous(), ty[idx].contiguous(), 0)
+            scale = F._grad_allreduce(student)
+            student.adamw_step(LR, WD, grad_scale=scale)
+        e2.record()
+        if record is not None:
+            record.append((e0, e1, e2))
+        info.update(kept=int(kidx.numel()), train_images=int(n_train), epoch_steps=int(steps),
+                    mean_pred_size=round(float(torch.cat(ps).float().mean()), 1),
+                    mean_im_size=round(float(torch.cat(ims).float().mean()), 1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        generation()
+    barrier()
+    rec = []
+    imk_lib.imk_prof_enable(1)          # HIP events around every conv launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        generation(rec)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    imk_lib.imk_prof_enable(0)
+    pc = (ctypes.c_int64 * 6)(); pms = (ctypes.c_double * 6)(); pby = (ctypes.c_double * 6)()
+    imk_lib.imk_prof_collect(pc, pms, pby)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    t_inf = sum(a.elapsed_time(b) for a, b, _ in rec) / len(rec)
+    t_ep = sum(b.elapsed_time(c) for _, b, c in rec) / len(rec)
+
+    # ---- roofline of the dominant kernel: conv_mfma_kernel, the variant with the largest summed time ---------
+    names = ["conv_mfma_kernel<16,1>", "conv_mfma_kernel<16,2>", "conv_mfma_kernel<16,4>",
+             "conv_mfma_kernel<8,1>", "conv_mfma_kernel<8,2>", "conv_mfma_kernel<8,4>"]
+    v = max(range(6), key=lambda i: pms[i])
+    conv_all = {names[i]: {"launches": int(pc[i]), "ms": round(pms[i], 3),
+                           "GBps": round(pby[i] / pms[i] / 1e6, 1) if pms[i] else None} for i in range(6) if pc[i]}
+    achieved = pby[v] / pms[v] / 1e6 if pms[v] else 0.0      # bytes / ms / 1e6 = GB/s
+    roofline = {"bound": "hbm", "kernel": names[v], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
+                "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
+                "share_of_step_time": round(pms[v] / (1000 * elapsed), 3), "all_conv_variants": conv_all}
+
+    # ---- the fused IM kernel on the same shapes (HBM-bound; SURVEY 8d: 1 MiB / image) ------------------------
+    probs = torch.stack([m.predict_device(x_unl[:args.infer_batch]) for m in models], 0)
+    for _ in range(3):
+        imk_im.im_binary(probs, 0.5, False, x_unl[:args.infer_batch], True, True)
+    a, b = ev(), ev()
+    n_rep = 20
+    a.record()
+    for _ in range(n_rep):
+        imk_im.im_binary(probs, 0.5, False, x_unl[:args.infer_batch], True, True)
+    b.record()
+    torch.cuda.synchronize()
+    im_ms = a.elapsed_time(b) / n_rep
+    im_bytes = probs.shape[1] * (N_MODELS * H * W * K * 4 + 2 * H * W * C + 2 * H * W)
+    im_kernel = {"kernel": "im_binary_vec<1>", "GBps": round(im_bytes / im_ms / 1e6, 1),
+                 "frac_of_hbm_peak": round(im_bytes / im_ms / 1e6 / HBM_PEAK_GBS, 4),
+                 "bytes_per_launch": im_bytes, "ms_per_launch": round(im_ms, 4)}
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec per IM generation (ensemble infer + IM build + 1 train epoch), 256x256",
+            "value": round(U * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "ISIC-2018 binary 256x256x3, 2-model IM ensemble, tiny U-Net alpha=0.5 on MI355X "
+                                   "(configs[1])", "unlabeled_images_per_gpu": U, "labeled_images": U_LABELED,
+                       "n_models": N_MODELS, "infer_batch": args.infer_batch, "train_batch_per_gpu": BATCH,
+                       "parallelism": f"dp{world}", **info},
+            "stage_ms": {"ensemble_infer_plus_im": round(t_inf, 2), "train_epoch": round(t_ep, 2)},
+            "roofline": roofline,
+            "im_kernel": im_kernel,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -346,6 +346,24 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
     }
 }
 
+// stage 1 of the deterministic split reduction: [n_split][n_tiles][256] -> [n_chunks][n_tiles][256],
+// 16 splits per chunk; coalesced (thread = element of a 16x16 tile).
+constexpr int WG_RED_CHUNK = 16;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_split, int n_tiles,
+                                                           float *__restrict__ red) {
+    const int tile = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
+    const int s0 = chunk * WG_RED_CHUNK, s1 = min(n_split, s0 + WG_RED_CHUNK);
+    const size_t stride = (size_t)n_tiles * 256;
+    const float *p = partial + (size_t)tile * 256 + t;
+    float v[WG_RED_CHUNK];
+#pragma unroll
+    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = (s0 + i < s1) ? p[(size_t)(s0 + i) * stride] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += v[i];
+    red[((size_t)chunk * n_tiles + tile) * 256 + t] = acc;
+}
+
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ partial, int n_split, int T,
                                                              int cin, int cout, int cit_n, int cot_n,
                                                              const float *__restrict__ inv_scale_ptr,
@@ -396,7 +414,39 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
     dst[i] = (f16)v;
 }
 
+// all conv layers of a model in one launch: blockIdx.y = job
+__global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs) {
+    const ImkPackJob &jb = jobs.j[blockIdx.y];
+    const int T = jb.ksize == 3 ? 9 : 1;
+    const int m_dim = jb.transposed ? jb.cin : jb.cout, k_dim = jb.transposed ? jb.cout : jb.cin;
+    const int nc8 = ((k_dim + 7) & ~7) / 8;
+    const int ns = (T * nc8 + 3) / 4;
+    const int total = ((m_dim + 15) / 16) * ns * 512;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int j = i & 7, lane = (i >> 3) & 63;
+        const int cs = i >> 9;
+        const int s = cs % ns, ct = cs / ns;
+        const int m = lane & 15, g = lane >> 4;
+        const int q = 4 * s + g;
+        const int tap = q / nc8, c8 = q - tap * nc8;
+        const int mi = ct * 16 + m, ki = c8 * 8 + j;
+        float v = 0.f;
+        if (tap < T && mi < m_dim && ki < k_dim) {
+            if (!jb.transposed) v = jb.w[((size_t)tap * jb.cin + ki) * jb.cout + mi];
+            else v = jb.w[((size_t)(T - 1 - tap) * jb.cin + mi) * jb.cout + ki];
+        }
+        jb.dst[i] = (f16)v;
+    }
+}
+
 }  // namespace
+
+int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
+    if (jobs.n <= 0) return IMK_OK;
+    pack_conv_batched_kernel<<<dim3(16, jobs.n), 256, 0, stream>>>(jobs);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
 
 // -----------------------------------------------------------------------------------------------------
 static inline int odd_ps(int nc8) { return nc8 | 1; }
@@ -410,6 +460,52 @@ static inline int conv_tile_h(int cs_in, int ksize) {
 
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
     return B * imk_cdiv(H, conv_tile_h(cs_in, ksize)) * imk_cdiv(W, TW);
+}
+
+// ---- optional per-launch event timing (bench.py roofline) ---------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int variant; double bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;       // recorded launches since the last collect
+std::vector<hipEvent_t> g_ev_pool; // recycled events
+
+hipEvent_t prof_event() {
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+double conv_algorithmic_bytes(const ImkConvArgs &a) {
+    const double px = (double)a.B * a.H * a.W;
+    double in_b;
+    switch (a.x.lmode) {
+        case LM_POOL: in_b = 4.0 * px * a.x.cs_in * 2; break;                     // reads the 2H x 2W tensor
+        case LM_UPADD: in_b = px * a.x.cs_in * 2 + 0.25 * px * a.x.cs_in * 2; break;  // skip + low-res tensor
+        case LM_U8: in_b = px * a.x.cin; break;
+        default: in_b = px * a.x.cs_in * 2;
+    }
+    double out_b = px * a.cs_out * 2;
+    if (a.epi == EP_MASK) out_b += px * a.cs_out * 2;
+    return in_b + out_b;
+}
+}  // namespace
+
+extern "C" int imk_prof_enable(int on) { g_prof_on = on != 0; return IMK_OK; }
+
+extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
+    IMK_CHECK_ARG(count && ms && bytes);
+    for (int v = 0; v < IMK_PROF_VARIANTS; ++v) { count[v] = 0; ms[v] = 0; bytes[v] = 0; }
+    for (auto &r : g_prof) {
+        IMK_HIP(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        IMK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+        count[r.variant] += 1; ms[r.variant] += t; bytes[r.variant] += r.bytes;
+        g_ev_pool.push_back(r.e0); g_ev_pool.push_back(r.e1);
+    }
+    g_prof.clear();
+    return IMK_OK;
 }
 
 template <int TH>
@@ -426,9 +522,29 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     if (lds < stats_bytes) lds = stats_bytes;
     const int mt = mt_total >= 4 ? 4 : (mt_total >= 2 ? 2 : 1);
     dim3 grid(a.B * tiles_x * tiles_y, imk_cdiv(mt_total, mt));
-    if (mt == 4) conv_mfma_kernel<TH, 4><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns);
-    else if (mt == 2) conv_mfma_kernel<TH, 2><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns);
-    else conv_mfma_kernel<TH, 1><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns);
+    if (lds > 160 * 1024) return IMK_EUNSUPPORTED;  // wider than ~384 input channels on a 3x3: needs K passes
+    auto launch = [&](auto kern) -> int {
+        if (lds > 64 * 1024)  // above the default dynamic-LDS limit: opt in (idempotent, no sync)
+            IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns);
+        return IMK_OK;
+    };
+    ProfRec pr{};
+    if (g_prof_on) {
+        pr.e0 = prof_event(); pr.e1 = prof_event();
+        pr.variant = (TH == 8 ? 3 : 0) + (mt == 4 ? 2 : (mt == 2 ? 1 : 0));
+        pr.bytes = conv_algorithmic_bytes(a);
+        IMK_HIP(hipEventRecord(pr.e0, stream));
+    }
+    int rc;
+    if (mt == 4) rc = launch(conv_mfma_kernel<TH, 4>);
+    else if (mt == 2) rc = launch(conv_mfma_kernel<TH, 2>);
+    else rc = launch(conv_mfma_kernel<TH, 1>);
+    if (rc) return rc;
+    if (g_prof_on) {
+        IMK_HIP(hipEventRecord(pr.e1, stream));
+        g_prof.push_back(pr);
+    }
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -455,7 +571,8 @@ int imk_wgrad_splits(int B, int H, int W, int cin, int cout) {
 size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout) {
     const int n_pairs = ((imk_pad8(cin) + 15) / 16) * ((imk_pad8(cout) + 15) / 16);
     const int T = ksize == 3 ? 9 : 1;
-    return (size_t)imk_wgrad_splits(B, H, W, cin, cout) * n_pairs * (T + 1) * 256;
+    const size_t ns = (size_t)imk_wgrad_splits(B, H, W, cin, cout);
+    return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch
 }
 
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
@@ -480,6 +597,15 @@ int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int 
     const int T = ksize == 3 ? 9 : 1;
     const int cit_n = (imk_pad8(cin) + 15) / 16, cot_n = (imk_pad8(cout) + 15) / 16;
     const int total = T * cin * cout + cout;
+    if (n_split > WG_RED_CHUNK) {  // two-stage: the second stage then walks at most 64 values per element
+        const int n_tiles = cit_n * cot_n * (T + 1);
+        const int n_chunks = imk_cdiv(n_split, WG_RED_CHUNK);
+        float *red = const_cast<float *>(partial) + (size_t)n_split * n_tiles * 256;  // scratch behind the partials
+        wgrad_reduce_kernel<<<dim3(n_tiles, n_chunks), 256, 0, stream>>>(partial, n_split, n_tiles, red);
+        IMK_LAUNCH_CHECK();
+        partial = red;
+        n_split = n_chunks;
+    }
     wgrad_finalize_kernel<<<imk_cdiv(total, 256), 256, 0, stream>>>(partial, n_split, T, cin, cout, cit_n, cot_n,
                                                                    inv_scale_ptr, dw, db, found_inf);
     IMK_LAUNCH_CHECK();

@@ -36,3 +36,9 @@ int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_ctl_begin(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream);
+
+// all BatchNorm layers of a model folded (moving statistics -> scale | shift) in one launch
+#define IMK_FOLD_MAX_JOBS 32
+struct ImkFoldJob { const float *gamma, *beta, *mean, *var; float *scale; int c, cs; };
+struct ImkFoldJobs { ImkFoldJob j[IMK_FOLD_MAX_JOBS]; int n; };
+int imk_launch_bn_fold_jobs(const ImkFoldJobs &jobs, hipStream_t stream);

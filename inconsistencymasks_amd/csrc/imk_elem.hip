@@ -66,6 +66,16 @@ __global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__r
     shift[ch] = beta[ch] - mean[ch] * sc;
 }
 
+__global__ void bn_fold_batched_kernel(ImkFoldJobs jobs) {
+    const ImkFoldJob &jb = jobs.j[blockIdx.y];
+    for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < jb.cs; ch += gridDim.x * blockDim.x) {
+        if (ch >= jb.c) { jb.scale[ch] = 0.f; jb.scale[jb.cs + ch] = 0.f; continue; }
+        const float sc = jb.gamma[ch] / sqrtf(jb.var[ch] + BN_EPS);
+        jb.scale[ch] = sc;
+        jb.scale[jb.cs + ch] = jb.beta[ch] - jb.mean[ch] * sc;
+    }
+}
+
 // ---- BatchNorm backward, pass 1: assemble dy (if it has more than one source) and reduce --------------
 // Each thread owns one 8-channel chunk index for its whole grid-stride walk (grid size is a multiple of
 // nc8), so the per-channel sums live in registers until one LDS reduction per block.
@@ -399,6 +409,13 @@ int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, doub
 int imk_launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, int c, int cs,
                        float *scale, float *shift, hipStream_t stream) {
     bn_fold_kernel<<<imk_cdiv(cs, 64), 64, 0, stream>>>(gamma, beta, mean, var, c, cs, scale, shift);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_bn_fold_jobs(const ImkFoldJobs &jobs, hipStream_t stream) {
+    if (jobs.n <= 0) return IMK_OK;
+    bn_fold_batched_kernel<<<dim3(2, jobs.n), 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

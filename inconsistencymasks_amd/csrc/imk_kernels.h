@@ -58,3 +58,9 @@ int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int 
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand.
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed);
 int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream);
+
+// batched variant: up to IMK_PACK_MAX_JOBS (layer, direction) jobs per launch, table passed by value
+#define IMK_PACK_MAX_JOBS 32
+struct ImkPackJob { const float *w; f16 *dst; int ksize, cin, cout, transposed; };
+struct ImkPackJobs { ImkPackJob j[IMK_PACK_MAX_JOBS]; int n; };
+int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream);

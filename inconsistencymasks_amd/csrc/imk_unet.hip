@@ -351,21 +351,26 @@ extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *par
     IMK_CHECK_ARG(plan && params && packed);
     uint8_t *pk = (uint8_t *)packed;
     const int out_idx = plan->find("out");
+    ImkPackJobs pj{};
+    ImkFoldJobs fj{};
+    auto flush_pack = [&]() -> int { int rc = imk_launch_pack_jobs(pj, stream); pj.n = 0; return rc; };
     for (size_t i = 0; i < plan->layers.size(); ++i) {
         const ImkLayer &l = plan->layers[i];
-        int rc = 0;
         if (l.kind == 0) {
-            if ((int)i != out_idx)
-                rc = imk_launch_pack_conv(params + l.off_w, l.ksize, l.cin, l.cout, 0, (f16 *)(pk + l.pk_fwd), stream);
-            if (!rc) rc = imk_launch_pack_conv(params + l.off_w, l.ksize, l.cin, l.cout, 1, (f16 *)(pk + l.pk_bwd), stream);
+            for (int tr = 0; tr < 2; ++tr) {
+                if (tr == 0 && (int)i == out_idx) continue;   // the head runs in fp32 from `params` directly
+                pj.j[pj.n++] = ImkPackJob{params + l.off_w, (f16 *)(pk + (tr ? l.pk_bwd : l.pk_fwd)), l.ksize, l.cin, l.cout, tr};
+                if (pj.n == IMK_PACK_MAX_JOBS) { int rc = flush_pack(); if (rc) return rc; }
+            }
         } else {
-            float *sc = (float *)(pk + l.pk_scale);
-            rc = imk_launch_bn_fold(params + l.off_w, params + l.off_b, params + l.off_mean, params + l.off_var, l.cout,
-                                    imk_pad8(l.cout), sc, sc + imk_pad8(l.cout), stream);
+            if (fj.n == IMK_FOLD_MAX_JOBS) return IMK_EUNSUPPORTED;
+            fj.j[fj.n++] = ImkFoldJob{params + l.off_w, params + l.off_b, params + l.off_mean, params + l.off_var,
+                                      (float *)(pk + l.pk_scale), l.cout, imk_pad8(l.cout)};
         }
-        if (rc) return rc;
     }
-    return IMK_OK;
+    int rc = flush_pack();
+    if (rc) return rc;
+    return imk_launch_bn_fold_jobs(fj, stream);
 }
 
 extern "C" int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode) {

@@ -1,0 +1,256 @@
+"""GPU parity of the HIP U-Net (through the C ABI) against the torch-CPU oracle.
+
+Tolerances (fp16 storage / fp32 accumulation on both sides; differences are summation order and 1-ulp
+fp16 flips that propagate):
+  * stored conv outputs, layer by layer:  relative L2 error <= 1e-2
+  * probabilities vs the fp16-emulating oracle: max |dp| <= 3e-2 at default init;  vs the fp32 oracle the
+    measured gap is reported (SURVEY §8c asks for |dp| <= 2e-3 "to be measured": it is the fp16 policy of the
+    reference itself that does not meet that on deep random nets)
+  * gradients, with the oracle's forward VALUES pinned to the GPU's (so ReLU masks / pool arg-maxes agree):
+    relative L2 error <= 2e-2 per tensor;  loss <= 1e-4 relative
+  * AdamW update given the GPU gradients: 1e-6;  BN moving statistics: 1e-5
+"""
+import struct
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as U  # noqa: E402
+
+CFGS = {
+    "isic": dict(h=64, w=64, c=3, k=1, alpha=0.5, act="sigmoid", loss="mse", b=4),
+    "suim": dict(h=48, w=64, c=3, k=9, alpha=1.0, act="softmax", loss="cce", b=2),
+    "hela": dict(h=32, w=48, c=1, k=3, alpha=1.0, act="sigmoid", loss="mse", b=3),
+    "odd": dict(h=48, w=80, c=3, k=35, alpha=1.25, act="softmax", loss="cce", b=2),
+    "wide": dict(h=32, w=32, c=3, k=9, alpha=1.5, act="softmax", loss="cce", b=2),
+}
+
+
+@pytest.fixture(scope="module")
+def UNet():
+    assert torch.cuda.is_available()
+    from inconsistencymasks_amd.unet import UNet as cls
+    return cls
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
+
+
+def make_input(cfg, seed=3):
+    rng = np.random.default_rng(seed)
+    h, w, c, b = cfg["h"], cfg["w"], cfg["c"], cfg["b"]
+    yy, xx = np.mgrid[0:h, 0:w]
+    x = (127 + 80 * np.sin(xx / 7.0)[None, :, :, None] * np.cos(yy / 5.0)[None, :, :, None]
+         + rng.integers(-30, 30, (b, h, w, c))).clip(0, 255).astype(np.uint8)
+    if cfg["loss"] == "mse":
+        y = (rng.random((b, h, w, cfg["k"])) > 0.6).astype(np.uint8)
+        tgt = y.astype(np.float32)
+    else:
+        y = rng.integers(0, cfg["k"], (b, h, w)).astype(np.uint8)
+        tgt = np.eye(cfg["k"], dtype=np.float32)[y]
+    return x, y, tgt
+
+
+def randomize_bn(sd, seed):
+    g = torch.Generator().manual_seed(seed)
+    for k in sd:
+        if k.endswith(".gamma"):
+            sd[k] = 0.8 + 0.4 * torch.rand(sd[k].shape, generator=g)
+        elif k.endswith(".beta"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith(".mean"):
+            sd[k] = 0.4 + 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith(".var"):
+            sd[k] = 0.5 + 0.5 * torch.rand(sd[k].shape, generator=g)
+        elif k.endswith(".b"):
+            sd[k] = 0.05 * torch.randn(sd[k].shape, generator=g)
+    return sd
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_inference_parity(UNet, name):
+    cfg = CFGS[name]
+    m = UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=1)
+    sd = randomize_bn(m.state_dict(), 2)
+    m.load_state_dict(sd)
+    x, _, _ = make_input(cfg)
+    probs = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    taps = {}
+    ref = U.forward(sd, x, cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], emulate_fp16=True, taps=taps).numpy()
+    for l in m.plan.layers:
+        if l["kind"] == 0 and l["name"] != "out":
+            got = m.intermediate(l["name"], cfg["b"], 0).numpy()
+            assert rel_l2(got, taps[l["name"]].numpy()) <= 1e-2, l["name"]
+    assert np.abs(probs - ref).max() <= 3e-2
+    assert rel_l2(probs, ref) <= 1e-2
+    if cfg["act"] == "softmax":
+        assert np.allclose(probs.sum(-1), 1.0, atol=1e-5)
+        flips = (probs.argmax(-1) != ref.argmax(-1)).mean()
+    else:
+        flips = ((probs > 0.5) != (ref > 0.5)).mean()
+    assert flips <= 0.01, f"decision flip rate {flips}"
+    # predict() (numpy in / numpy out, batches) is the same computation
+    assert np.array_equal(m.predict([x], batch_size=3), probs)
+
+
+def test_inference_batch_invariance(UNet):
+    """Inference-mode outputs of one image do not depend on what else is in the batch (bit-exact): the
+    property that makes IM masks identical for any sharding of the image set over GPUs."""
+    cfg = CFGS["isic"]
+    m = UNet(cfg["h"], cfg["w"], 3, 1, 0.5, "sigmoid", seed=5)
+    x, _, _ = make_input(dict(cfg, b=7))
+    xd = torch.from_numpy(x).cuda()
+    full = m.predict_device(xd)
+    for lo, hi in [(0, 1), (1, 4), (4, 7)]:
+        assert torch.equal(m.predict_device(xd[lo:hi].contiguous()), full[lo:hi])
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_train_step_parity(UNet, name):
+    cfg = CFGS[name]
+    c, k, alpha, act, b = cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], cfg["b"]
+    m = UNet(cfg["h"], cfg["w"], c, k, alpha, act, seed=11)
+    sd = randomize_bn(m.state_dict(), 12)
+    m.load_state_dict(sd)
+    x, y, tgt = make_input(cfg, 13)
+    kind = 0 if cfg["loss"] == "mse" else 1
+    m.init_train_state()
+    for attempt in range(12):   # dynamic loss scaling: an overflowing step is skipped and the scale halved
+        m.fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), kind)
+        torch.cuda.synchronize()
+        stats = m.stats.cpu().numpy()
+        assert stats[2] == 32768.0 / 2 ** attempt
+        if stats[1] == 0.0:
+            break
+        before = m.params.clone()
+        m.adamw_step(3e-3, 1e-4)
+        assert torch.equal(before, m.params)
+        m.load_state_dict(sd)          # undo the moving-statistics update of the skipped step
+    assert stats[1] == 0.0
+    g1 = m.grads.clone()
+    # deterministic: a second pass from the same state gives bit-identical gradients
+    moving_after_1 = m.state_dict()
+    m.fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), kind)
+    assert torch.equal(g1, m.grads)
+
+    ov = {l["name"]: m.intermediate(l["name"], b, 1) for l in m.plan.layers if l["kind"] == 0 and l["name"] != "out"}
+    # training-mode forward parity (unpinned oracle)
+    taps = {}
+    U.forward(sd, x, c, k, alpha, act, training=True, emulate_fp16=True, taps=taps)
+    for n, t in taps.items():   # batch statistics of tiny batches amplify 1-ulp flips: looser than inference
+        assert rel_l2(ov[n].numpy(), t.numpy()) <= 3e-2, n
+    sd_ref = {kk: v.clone() for kk, v in sd.items()}
+    loss_ref, grads_ref = U.train_step(sd_ref, U.new_opt_state(sd_ref), x, tgt, c, k, alpha, act, cfg["loss"],
+                                       emulate_fp16=True, loss_scale=float(stats[2]), return_grads=True, override=ov)
+    assert abs(stats[0] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+    g = g1.cpu()
+    for l in m.plan.layers:
+        n = l["name"]
+        if l["kind"] == 0:
+            kk, ci, co = l["ksize"], l["cin"], l["cout"]
+            gw = g[l["off_w"]:l["off_w"] + kk * kk * ci * co].reshape(kk, kk, ci, co).numpy()
+            gb = g[l["off_b"]:l["off_b"] + co].numpy()
+            assert rel_l2(gw, grads_ref[n + ".w"].numpy()) <= 2e-2, n
+            assert rel_l2(gb, grads_ref[n + ".b"].numpy()) <= 2e-2, n
+        else:
+            cc = l["cout"]
+            assert rel_l2(g[l["off_w"]:l["off_w"] + cc].numpy(), grads_ref[n + ".gamma"].numpy()) <= 2e-2, n
+            assert rel_l2(g[l["off_b"]:l["off_b"] + cc].numpy(), grads_ref[n + ".beta"].numpy()) <= 2e-2, n
+    # BN moving statistics after one step (momentum 0.99)
+    for kk in sd_ref:
+        if kk.endswith(".mean") or kk.endswith(".var"):
+            assert torch.allclose(moving_after_1[kk], sd_ref[kk], atol=1e-5, rtol=1e-5), kk
+
+
+def test_adamw_matches_tfa_formula(UNet):
+    cfg = CFGS["isic"]
+    m = UNet(cfg["h"], cfg["w"], 3, 1, 0.5, "sigmoid", seed=21)
+    x, y, _ = make_input(cfg, 22)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.init_train_state()
+    n = m.plan.n_trainable
+    p = m.params[:n].clone().double()
+    mm = torch.zeros_like(p)
+    vv = torch.zeros_like(p)
+    lr, wd, b1, b2, eps = 3e-3, 1e-4, 0.9, 0.999, 1e-7
+    for step in range(1, 4):
+        m.fwd_bwd(xd, yd, 0)
+        g = m.grads.clone().double()
+        m.adamw_step(lr, wd)
+        p = p * (1 - wd)
+        mm = b1 * mm + (1 - b1) * g
+        vv = b2 * vv + (1 - b2) * g * g
+        lr_t = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
+        p = p - lr_t * mm / (vv.sqrt() + eps)
+        assert torch.allclose(m.params[:n].double(), p, atol=2e-6, rtol=1e-5), step
+        p = m.params[:n].clone().double()      # re-sync to avoid accumulating fp32-vs-fp64 drift
+        mm, vv = mm.float().double(), vv.float().double()
+
+
+def test_loss_decreases_and_bn_stats_move(UNet):
+    cfg = dict(CFGS["isic"], b=8)
+    m = UNet(cfg["h"], cfg["w"], 3, 1, 0.5, "sigmoid", seed=31)
+    x, _, _ = make_input(cfg, 32)
+    y = (x[..., :1] > 140).astype(np.uint8)           # learnable target
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    losses = []
+    for _ in range(40):
+        m.train_step(xd, yd, 0, 3e-3, 1e-4)
+        losses.append(float(m.stats[0]))
+    assert losses[-1] < 0.5 * losses[0], losses[::8]
+    sd = m.state_dict()
+    assert float((sd["in.bn.mean"]).abs().max()) > 0
+
+
+def test_overflow_skips_step_and_halves_scale(UNet):
+    cfg = CFGS["isic"]
+    m = UNet(cfg["h"], cfg["w"], 3, 1, 0.5, "sigmoid", seed=41)
+    x, y, _ = make_input(cfg, 42)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.init_train_state()
+    ctl_off = m.plan.state_bytes - 256
+    huge = torch.tensor(list(struct.pack("ff", 2.0 ** 40, 2.0 ** -40)), dtype=torch.uint8).cuda()
+    m.train_state[ctl_off:ctl_off + 8] = huge          # loss_scale, inv_loss_scale
+    before = m.params.clone()
+    m.fwd_bwd(xd, yd, 0)
+    m.adamw_step(3e-3, 1e-4)
+    torch.cuda.synchronize()
+    st = m.stats.cpu().numpy()
+    assert st[1] == 1.0, st
+    assert torch.equal(before[:m.plan.n_trainable], m.params[:m.plan.n_trainable])
+    scale = struct.unpack("f", bytes(m.train_state[ctl_off:ctl_off + 4].cpu().tolist()))[0]
+    assert scale == 2.0 ** 39
+
+
+def test_ensemble_forward_im_matches_unfused(UNet):
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd import im as imk_im
+    from oracle import im_oracle as O
+    for name in ("isic", "suim", "hela"):
+        cfg = CFGS[name]
+        models = [UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=50 + j) for j in range(3)]
+        x, _, _ = make_input(cfg, 51)
+        xd = torch.from_numpy(x).cuda()
+        r = F.EnsembleIM(models).run(xd, 0.5, name == "hela", True, True, want_presence=True)
+        probs = torch.stack([mm.predict_device(xd) for mm in models], 0)
+        pn = probs.cpu().numpy()
+        for i in range(cfg["b"]):
+            if cfg["act"] == "sigmoid":
+                e = O.im_binary(pn[:, i], 0.5, name == "hela")
+                eimg, emasks = O.block(x[i], list(e["final"]), e["im"], True, True)
+                assert np.array_equal(r["masks"][i].cpu().numpy(), np.stack(emasks))
+                assert r["im_size"][i].cpu().tolist() == e["im_size_ch"].tolist()
+                assert r["pred_size"][i].cpu().tolist() == e["pred_size_ch"].tolist()
+            else:
+                e = O.im_multiclass(pn[:, i])
+                eimg, (ef,) = O.block(x[i], [e["final"]], e["im"], True, True)
+                assert np.array_equal(r["masks"][i, 0].cpu().numpy(), ef)
+                assert int(r["im_size"][i, 0]) == int(e["im_size"])
+                assert np.array_equal(r["presence"][:, i].cpu().numpy(), e["presence"])
+            assert np.array_equal(r["im"][i].cpu().numpy(), e["im"])
+            assert np.array_equal(r["img_out"][i].cpu().numpy(), eimg)
