@@ -218,7 +218,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     imk_lib.imk_prof_enable(0)
-    pc = (ctypes.c_int64 * 6)(); pms = (ctypes.c_double * 6)(); pby = (ctypes.c_double * 6)()
+    pc = (ctypes.c_int64 * 7)(); pms = (ctypes.c_double * 7)(); pby = (ctypes.c_double * 7)()
     imk_lib.imk_prof_collect(pc, pms, pby)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -229,10 +229,10 @@ def main():
 
     # ---- roofline of the dominant kernel: conv_mfma_kernel, the variant with the largest summed time ---------
     names = ["conv_mfma_kernel<16,1>", "conv_mfma_kernel<16,2>", "conv_mfma_kernel<16,4>",
-             "conv_mfma_kernel<8,1>", "conv_mfma_kernel<8,2>", "conv_mfma_kernel<8,4>"]
-    v = max(range(6), key=lambda i: pms[i])
+             "conv_mfma_kernel<8,1>", "conv_mfma_kernel<8,2>", "conv_mfma_kernel<8,4>", "conv_pipe_kernel"]
+    v = max(range(7), key=lambda i: pms[i])
     conv_all = {names[i]: {"launches": int(pc[i]), "ms": round(pms[i], 3),
-                           "GBps": round(pby[i] / pms[i] / 1e6, 1) if pms[i] else None} for i in range(6) if pc[i]}
+                           "GBps": round(pby[i] / pms[i] / 1e6, 1) if pms[i] else None} for i in range(7) if pc[i]}
     achieved = pby[v] / pms[v] / 1e6 if pms[v] else 0.0      # bytes / ms / 1e6 = GB/s
     roofline = {"bound": "hbm", "kernel": names[v], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

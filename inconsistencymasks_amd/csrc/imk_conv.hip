@@ -18,6 +18,7 @@
 //
 // Reference layers replaced: Conv2D / BatchNormalization / MaxPooling2D / UpSampling2D+add / Lambda of
 // unet.py:4-43 and their gradients inside model.fit (functions.py:218).
+#include <cstdlib>
 #include "imk_kernels.h"
 
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
@@ -247,6 +248,227 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
 }
 
 // =====================================================================================================
+// forward / dgrad, persistent + register-prefetch pipelined variant for the wide, shallow layers
+// (<= 16 input channels, <= 16 output channels: levels 0/1 at alpha <= 1, where 80 % of the bytes are).
+// Those layers are pure streaming (a 16x16x8 tile is 4 KB in, 4 KB out, 12 MFMAs), so what limits them
+// is memory latency per workgroup, not bandwidth or math.  Differences to conv_mfma_kernel:
+//   * grid = (resident workgroups), each walks tiles blockIdx.x, +gridDim.x, ... ;
+//   * the global loads of tile i+1 are issued into registers BEFORE the MFMAs / stores of tile i, so every
+//     resident workgroup always has a tile of loads in flight;
+//   * the packed weights (<= 5 k-steps) and the per-lane LDS offsets are loaded once per workgroup.
+// =====================================================================================================
+template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : (LM == LM_UPADD ? 2 : 1)]; };
+template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
+
+template <int LM>
+__device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x, int H, int W, int c8, RawChunk<LM> &r) {
+    const int cs = in.cs_in;
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE) {
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
+    } else if constexpr (LM == LM_POOL) {
+        const int W2 = 2 * W;
+        const f16 *p = (const f16 *)in.in + ((size_t)(b * 2 * H + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
+        r.v[0] = *(const f16x8 *)p;
+        r.v[1] = *(const f16x8 *)(p + cs);
+        r.v[2] = *(const f16x8 *)(p + (size_t)W2 * cs);
+        r.v[3] = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
+    } else if constexpr (LM == LM_UPADD) {
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * cs + c8 * 8);
+        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
+    } else {
+        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < in.cin) ? p[j] : 0;
+    }
+}
+
+template <int LM>
+__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin) {
+    if constexpr (LM == LM_RAW) {
+        return r.v[0];
+    } else if constexpr (LM == LM_AFFINE) {
+        return affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
+    } else if constexpr (LM == LM_POOL) {
+        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)r.v[0][j] * sc[j] + sh[j], bq = (float)r.v[1][j] * sc[j] + sh[j];
+            const float c = (float)r.v[2][j] * sc[j] + sh[j], d = (float)r.v[3][j] * sc[j] + sh[j];
+            o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
+        }
+        return o;
+    } else if constexpr (LM == LM_UPADD) {
+        const f16x8 lo = affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
+        const f16x8 sk = affine8(r.v[1], s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
+        return o;
+    } else {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / 255.0f : 0.0f);
+        return o;
+    }
+}
+
+template <int LM, int NC8>
+__global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int P = 4;                        // tile rows per wave (16 x 16 tile)
+    constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
+    constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
+    constexpr int MAX_NS = (9 * NC8 + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int ks3 = (a.ksize == 3);
+    const int halo = ks3 ? 1 : 0;
+    const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
+    const int n_items = HT * WT * NC8;
+    const int nq = (ks3 ? 9 : 1) * NC8, ns = (nq + 3) / 4;
+    uint8_t *s_tile = smem;
+    float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);
+    float *s_red = s_aff + 4 * 16;              // [4 waves][2][16]
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int cs_in = a.x.cs_in;
+
+    stage_affine_table(a.x, s_aff);
+
+    // packed weights and per-lane LDS offsets of every k-step: once per workgroup
+    f16x8 af[MAX_NS];
+    int off[MAX_NS];
+    bool vq[MAX_NS];
+#pragma unroll
+    for (int s = 0; s < MAX_NS; ++s) {
+        const int q = 4 * s + g;
+        vq[s] = (s < ns) && (q < nq);
+        const int tap = q / NC8, c8 = q - tap * NC8;
+        const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
+        off[s] = vq[s] ? ((ty * WT + tx) * PS + c8) * 16 : 0;
+        af[s] = (s < ns) ? *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)s * 64 + lane) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    int base[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) base[p] = ((wave * P + p) * WT + n) * PS * 16;
+    // this thread's staging items (constant over tiles): LDS offset and position inside the halo tile
+    int it_lds[MAX_ITEMS], it_py[MAX_ITEMS], it_px[MAX_ITEMS], it_c8[MAX_ITEMS];
+#pragma unroll
+    for (int k = 0; k < MAX_ITEMS; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i / NC8;
+        it_c8[k] = i - pix * NC8;
+        it_py[k] = pix / WT;
+        it_px[k] = pix - it_py[k] * WT;
+        it_lds[k] = (i < n_items) ? (pix * PS + it_c8[k]) * 16 : -1;
+    }
+    float bias[4] = {0, 0, 0, 0};
+    const int co0 = 4 * g;
+    if (a.epi == EP_RELU && a.bias)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
+    const bool want_stats = (a.epi == EP_RELU) && a.stats_partial;
+
+    RawChunk<LM> raw[MAX_ITEMS];
+    unsigned valid = 0;
+    auto issue = [&](int tile) {
+        const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
+        valid = 0;
+#pragma unroll
+        for (int k = 0; k < MAX_ITEMS; ++k) {
+            const int y = tc.ty0 + it_py[k] - halo, x = tc.tx0 + it_px[k] - halo;
+            if (it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
+                raw_load<LM>(a.x, tc.b, y, x, H, W, it_c8[k], raw[k]);
+                valid |= 1u << k;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) issue(tile);
+    __syncthreads();  // affine table visible
+    while (tile < n_tiles) {
+        // registers -> LDS (BN / pool / up+add / u8 conversion applied here)
+#pragma unroll
+        for (int k = 0; k < MAX_ITEMS; ++k) {
+            if (it_lds[k] >= 0) {
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (valid & (1u << k)) v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
+                *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
+            }
+        }
+        const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
+        const int x = tc.tx0 + n;
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) issue(next);          // in flight during the MFMAs and stores below
+        f16x4 mk[P];
+        if (a.epi == EP_MASK) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int y = tc.ty0 + wave * P + p;
+                mk[p] = f16x4{0, 0, 0, 0};
+                if (y < H && x < W && co0 < a.cs_out)
+                    mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
+            }
+        }
+        f32x4 acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < MAX_NS; ++s) {
+            if (s < ns) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off[s]);
+                    if (!vq[s]) bf = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], bf, acc[p], 0, 0, 0);
+                }
+            }
+        }
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        if (co0 < a.cs_out) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int y = tc.ty0 + wave * P + p;
+                if (y >= H || x >= W) continue;
+                const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0;
+                f16x4 v;
+                if (a.epi == EP_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
+                } else if (a.epi == EP_MASK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ((float)mk[p][r] > 0.f) ? (f16)acc[p][r] : (f16)0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (f16)acc[p][r];
+                }
+                *reinterpret_cast<f16x4 *>(a.out + o) = v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = wave_sum<16>(s1[r]), v2 = wave_sum<16>(s2[r]);
+                if (n == 0) { s_red[(wave * 2 + 0) * 16 + 4 * g + r] = v1; s_red[(wave * 2 + 1) * 16 + 4 * g + r] = v2; }
+            }
+        }
+        __syncthreads();   // tile reads done (LDS may be overwritten), s_red complete
+        if (want_stats && t < 32) {
+            const int which = t >> 4, c = t & 15;
+            if (c < a.cs_out)
+                a.stats_partial[(size_t)tile * 2 * a.cs_out + which * a.cs_out + c] =
+                    (s_red[(0 * 2 + which) * 16 + c] + s_red[(1 * 2 + which) * 16 + c]) +
+                    (s_red[(2 * 2 + which) * 16 + c] + s_red[(3 * 2 + which) * 16 + c]);
+        }
+        tile = next;
+    }
+}
+
+// =====================================================================================================
 // wgrad
 // =====================================================================================================
 constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 channels + 8 pad = 48 B)
@@ -414,6 +636,69 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
     dst[i] = (f16)v;
 }
 
+// ---- batched, deterministic reduction of all layers' weight-gradient partials -----------------------------
+__device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx, bool stage1) {
+    int j = 0;
+    for (int k = 1; k < jobs.n; ++k) {
+        const int begin = stage1 ? jobs.j[k].work1_begin : jobs.j[k].tile_begin;
+        if (idx >= begin) j = k;
+    }
+    return j;
+}
+
+__global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
+    const int jn = wgf_find_job(jobs, blockIdx.x, true);
+    const ImkWgFinalJob &jb = jobs.j[jn];
+    const int local = blockIdx.x - jb.work1_begin;
+    const int tile = local / jb.n_chunks, chunk = local - tile * jb.n_chunks;
+    const int t = threadIdx.x;
+    const int s0 = chunk * WG_RED_CHUNK, s1 = min(jb.n_split, s0 + WG_RED_CHUNK);
+    const size_t stride = (size_t)jb.n_tiles * 256;
+    const float *p = jb.partial + (size_t)tile * 256 + t;
+    float v[WG_RED_CHUNK];
+#pragma unroll
+    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = (s0 + i < s1) ? p[(size_t)(s0 + i) * stride] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += v[i];
+    jb.red[((size_t)chunk * jb.n_tiles + tile) * 256 + t] = acc;
+}
+
+__global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, const float *__restrict__ inv_scale_ptr,
+                                                          float *__restrict__ found_inf) {
+    __shared__ float s_p[4][256];
+    const int jn = wgf_find_job(jobs, blockIdx.x, false);
+    const ImkWgFinalJob &jb = jobs.j[jn];
+    const int tile = blockIdx.x - jb.tile_begin;
+    const int e = threadIdx.x & 255, sg = threadIdx.x >> 8;
+    const size_t stride = (size_t)jb.n_tiles * 256;
+    const float *p = jb.red + (size_t)tile * 256 + e;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = sg + 4 * i; v[i] = (c < jb.n_chunks) ? p[(size_t)c * stride] : 0.f; }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += v[i];
+    s_p[sg][e] = acc;
+    __syncthreads();
+    if (sg != 0) return;
+    float s = ((s_p[0][e] + s_p[1][e]) + (s_p[2][e] + s_p[3][e])) * *inv_scale_ptr;
+    const int pair = tile / (jb.T + 1), tap = tile - pair * (jb.T + 1);
+    const int cit = pair / jb.cot_n, cot = pair - cit * jb.cot_n;
+    const int r = e >> 6, lane = e & 63;
+    const int m = 4 * (lane >> 4) + r, nn = lane & 15;
+    const int ci = cit * 16 + m, co = cot * 16 + nn;
+    if (tap < jb.T) {
+        if (ci < jb.cin && co < jb.cout) {
+            if (!isfinite(s)) *found_inf = 1.0f;
+            jb.dw[((size_t)tap * jb.cin + ci) * jb.cout + co] = s;
+        }
+    } else if (cit == 0 && m == 0 && co < jb.cout) {
+        if (!isfinite(s)) *found_inf = 1.0f;
+        jb.db[co] = s;
+    }
+}
+
 // all conv layers of a model in one launch: blockIdx.y = job
 __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs) {
     const ImkPackJob &jb = jobs.j[blockIdx.y];
@@ -440,6 +725,35 @@ __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs
 }
 
 }  // namespace
+
+int imk_wgf_add_job(ImkWgFinalJobs &jobs, float *partial, int n_split, int ksize, int cin, int cout, float *dw, float *db) {
+    if (jobs.n >= IMK_WGF_MAX_JOBS) return IMK_EUNSUPPORTED;
+    const int T = ksize == 3 ? 9 : 1;
+    const int cit_n = (imk_pad8(cin) + 15) / 16, cot_n = (imk_pad8(cout) + 15) / 16;
+    ImkWgFinalJob &jb = jobs.j[jobs.n++];
+    jb.partial = partial;
+    jb.n_split = n_split;
+    jb.n_chunks = imk_cdiv(n_split, WG_RED_CHUNK);
+    if (jb.n_chunks > 64) return IMK_EUNSUPPORTED;
+    jb.n_tiles = cit_n * cot_n * (T + 1);
+    jb.red = partial + (size_t)n_split * jb.n_tiles * 256;
+    jb.T = T; jb.cin = cin; jb.cout = cout; jb.cot_n = cot_n;
+    jb.dw = dw; jb.db = db;
+    jb.work1_begin = jobs.total_work1;
+    jb.tile_begin = jobs.total_tiles;
+    jobs.total_work1 += jb.n_tiles * jb.n_chunks;
+    jobs.total_tiles += jb.n_tiles;
+    return IMK_OK;
+}
+
+int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_scale_ptr, float *found_inf, hipStream_t stream) {
+    if (jobs.n <= 0) return IMK_OK;
+    wgf_stage1_kernel<<<jobs.total_work1, 256, 0, stream>>>(jobs);
+    IMK_LAUNCH_CHECK();
+    wgf_stage2_kernel<<<jobs.total_tiles, 1024, 0, stream>>>(jobs, inv_scale_ptr, found_inf);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
 
 int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
     if (jobs.n <= 0) return IMK_OK;
@@ -549,12 +863,60 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
+template <int LM, int NC8>
+static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
+    static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float);
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+        blocks_per_cu = nb > 8 ? 8 : nb;
+    }
+    const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
+    const int n_tiles = a.B * tiles_x * tiles_y;
+    int grid = 256 * blocks_per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    ProfRec pr{};
+    if (g_prof_on) {
+        pr.e0 = prof_event(); pr.e1 = prof_event();
+        pr.variant = 6;
+        pr.bytes = conv_algorithmic_bytes(a);
+        IMK_HIP(hipEventRecord(pr.e0, stream));
+    }
+    conv_pipe_kernel<LM, NC8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles);
+    IMK_LAUNCH_CHECK();
+    if (g_prof_on) {
+        IMK_HIP(hipEventRecord(pr.e1, stream));
+        g_prof.push_back(pr);
+    }
+    return IMK_OK;
+}
+
+template <int NC8>
+static int launch_conv_pipe_lm(const ImkConvArgs &a, hipStream_t stream) {
+    switch (a.x.lmode) {
+        case LM_RAW: return launch_conv_pipe<LM_RAW, NC8>(a, stream);
+        case LM_AFFINE: return launch_conv_pipe<LM_AFFINE, NC8>(a, stream);
+        case LM_POOL: return launch_conv_pipe<LM_POOL, NC8>(a, stream);
+        case LM_UPADD: return launch_conv_pipe<LM_UPADD, NC8>(a, stream);
+        default: return launch_conv_pipe<LM_U8, NC8>(a, stream);
+    }
+}
+
+static bool g_use_pipe = true;   // IMK_CONV_PIPE=0 in the environment falls back to the per-tile kernel (A/B runs)
+
 int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream) {
     IMK_CHECK_ARG(a.x.in && a.wpk && a.out && a.B > 0 && a.H > 0 && a.W > 0);
     IMK_CHECK_ARG(a.ksize == 1 || a.ksize == 3);
     IMK_CHECK_ARG(a.x.cs_in % 8 == 0 && a.cs_out % 8 == 0 && a.x.cs_in >= a.x.cin && a.cs_out >= a.cout);
     IMK_CHECK_ARG(a.x.lmode != LM_U8 || (a.x.cs_in == 8 && a.x.cin <= 8));
     if (a.x.cs_in > 512) return IMK_EUNSUPPORTED;
+    static const bool env_checked = []() { const char *e = getenv("IMK_CONV_PIPE"); if (e && e[0] == '0') g_use_pipe = false; return true; }();
+    (void)env_checked;
+    if (g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4)) {
+        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1>(a, stream);
+        return launch_conv_pipe_lm<2>(a, stream);
+    }
     if (conv_tile_h(a.x.cs_in, a.ksize) == 16) return launch_conv_th<16>(a, stream);
     return launch_conv_th<8>(a, stream);
 }

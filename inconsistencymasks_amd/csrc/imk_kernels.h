@@ -64,3 +64,18 @@ int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int trans
 struct ImkPackJob { const float *w; f16 *dst; int ksize, cin, cout, transposed; };
 struct ImkPackJobs { ImkPackJob j[IMK_PACK_MAX_JOBS]; int n; };
 int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream);
+
+// All weight-gradient reductions of a training step in two launches (stage 1: 16 splits -> 1 chunk, coalesced;
+// stage 2: <= 64 chunks -> 1, scale by 1/loss_scale, non-finite check, scatter into the flat gradient vector).
+#define IMK_WGF_MAX_JOBS 32
+struct ImkWgFinalJob {
+    const float *partial;   // [n_split][n_tiles][256]
+    float *red;             // [n_chunks][n_tiles][256]
+    float *dw, *db;
+    int n_split, n_chunks, n_tiles, T, cin, cout, cot_n;
+    int work1_begin;        // prefix sum of n_tiles * n_chunks
+    int tile_begin;         // prefix sum of n_tiles
+};
+struct ImkWgFinalJobs { ImkWgFinalJob j[IMK_WGF_MAX_JOBS]; int n, total_work1, total_tiles; };
+int imk_wgf_add_job(ImkWgFinalJobs &jobs, float *partial, int n_split, int ksize, int cin, int cout, float *dw, float *db);
+int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_scale_ptr, float *found_inf, hipStream_t stream);

@@ -1,5 +1,6 @@
 // Host-side description of the tiny U-Net (unet.py:4-67) shared by the forward / training code.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 #include "imk_common.h"
@@ -22,6 +23,13 @@ struct imk_unet_plan {
     std::vector<ImkLayer> layers;
     int64_t n_total, n_trainable;
     int64_t packed_bytes;
+    // Side stream for the weight-gradient kernels (off the dependency chain of the backward pass), forked
+    // from / joined to the caller's stream with events.  Created on the first training call.
+    mutable std::once_flag side_once;
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork[40] = {};
+    mutable hipEvent_t ev_join = nullptr;
+    mutable bool side_ok = false;
     int find(const char *name) const {
         for (size_t i = 0; i < layers.size(); ++i) if (layers[i].name == name) return (int)i;
         return -1;

@@ -90,6 +90,7 @@ struct LayerWs {
     size_t save = 0;           // bn (train): mean[cs], invstd[cs]
     size_t bwd_partial = 0;    // bn (train)
     size_t coef = 0;           // bn (train): [3][cs]
+    size_t wg_partial = 0;     // conv (train): this layer's weight-gradient partials (+ stage-1 scratch)
     int n_stats_tiles = 0;
 };
 
@@ -97,7 +98,7 @@ struct Ws {
     std::vector<LayerWs> L;
     size_t dU[4] = {0, 0, 0, 0};   // train: gradient w.r.t. decoder j's upsample+add output
     size_t dP[4] = {0, 0, 0, 0};   // train: gradient w.r.t. the pooled input of encoder i+1 / bottleneck
-    size_t probs = 0, dlogit = 0, loss_partial = 0, wgrad_partial = 0;
+    size_t probs = 0, dlogit = 0, loss_partial = 0;
     size_t total = 0;
 };
 
@@ -150,7 +151,6 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
     const int n = (int)p->layers.size();
-    size_t wg_max = 0;
     for (int i = 0; i < n; ++i) {
         const ImkLayer &l = p->layers[i];
         const Dim d = res_dim(p->cfg, l.res);
@@ -159,8 +159,7 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
             if (i != t.out) w.L[i].out = take(px * imk_pad8(l.cout) * 2);
             if (mode == 1) {
                 w.L[i].dA = take(px * imk_pad8(l.cout) * 2);
-                const size_t f = imk_wgrad_partial_floats(B, d.h, d.w, l.ksize, l.cin, l.cout) * sizeof(float);
-                if (f > wg_max) wg_max = f;
+                w.L[i].wg_partial = take(imk_wgrad_partial_floats(B, d.h, d.w, l.ksize, l.cin, l.cout) * sizeof(float));
             }
         } else if (mode == 1) {
             const int cs = imk_pad8(l.cout);
@@ -188,7 +187,6 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
         const size_t px = (size_t)B * p->cfg.h * p->cfg.w;
         w.dlogit = take(px * imk_pad8(p->cfg.n_out) * 2);
         w.loss_partial = take((size_t)imk_loss_blocks((long long)px) * sizeof(float));
-        w.wgrad_partial = take(wg_max);
         w.probs = take(px * p->cfg.n_out * sizeof(float));
     }
     w.total = off;
@@ -323,7 +321,16 @@ extern "C" int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out
     return IMK_OK;
 }
 
-extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) { delete plan; }
+extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) {
+    if (!plan) return;
+    if (plan->side) {
+        (void)hipStreamSynchronize(plan->side);
+        (void)hipStreamDestroy(plan->side);
+        for (auto &e : plan->ev_fork) if (e) (void)hipEventDestroy(e);
+        if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+    }
+    delete plan;
+}
 
 extern "C" int imk_unet_param_count(const imk_unet_plan *plan, int64_t *total, int64_t *trainable) {
     IMK_CHECK_ARG(plan);
@@ -450,7 +457,9 @@ struct Bwd {
     const uint8_t *x;
     float *grads;
     ImkCtl *ctl;
-    float *wg_partial;
+    hipStream_t side;       // weight-gradient work runs here (== c.stream if no side stream is available)
+    ImkWgFinalJobs jobs{};
+    int n_fork = 0;
 
     // dgrad of `conv`: input dA[conv] -> dst, optionally masked by the ReLU of the tensor `mask`
     int dgrad(int conv, f16 *dst, const f16 *mask) {
@@ -466,19 +475,35 @@ struct Bwd {
         a.epi = mask ? EP_MASK : EP_PLAIN;
         return imk_launch_conv(a, c.stream);
     }
+    // Weight/bias gradient of `conv`: depends only on dA[conv] (just produced on the main stream) and on forward
+    // tensors, and nothing downstream in the backward pass depends on it -> fork it onto the side stream.
     int wgrad(int conv, const f16 *dA_override = nullptr) {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
+        if (side != c.stream) {
+            hipEvent_t ev = c.p->ev_fork[n_fork++];
+            IMK_HIP(hipEventRecord(ev, c.stream));
+            IMK_HIP(hipStreamWaitEvent(side, ev, 0));
+        }
         ImkWgradArgs a{};
         a.x = conv_input(c, conv, x);
         a.dA = dA_override ? dA_override : c.dA(conv);
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
-        a.partial = wg_partial;
+        a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
         a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
-        int rc = imk_launch_wgrad(a, c.stream);
+        int rc = imk_launch_wgrad(a, side);
         if (rc) return rc;
-        return imk_launch_wgrad_finalize(wg_partial, a.n_split, l.ksize, l.cin, l.cout, &ctl->inv_loss_scale,
-                                         grads + l.off_w, grads + l.off_b, &ctl->found_inf, c.stream);
+        return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+    }
+    // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
+    int finish_wgrads() {
+        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, side);
+        if (rc) return rc;
+        if (side != c.stream) {
+            IMK_HIP(hipEventRecord(c.p->ev_join, side));
+            IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join, 0));
+        }
+        return IMK_OK;
     }
     // BN backward for `bn` whose output gradient is dy[bn] (already assembled unless mode != 0), producing
     // dA of the conv that feeds it.
@@ -542,7 +567,13 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     OK(imk_launch_loss_grad(probs, y, cf.n_out, imk_pad8(cf.n_out), loss_kind, n_pix, sv.ctl, dlogit, loss_partial, stats,
                             stream));
 
-    Bwd b{c, x, grads, sv.ctl, reinterpret_cast<float *>(c.base + c.ws.wgrad_partial)};
+    std::call_once(plan->side_once, [plan]() {
+        bool ok = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) == hipSuccess;
+        for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) == hipSuccess;
+        plan->side_ok = ok;
+    });
+    Bwd b{c, x, grads, sv.ctl, plan->side_ok ? plan->side : stream};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
     {
@@ -584,6 +615,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));
+    OK(b.finish_wgrads());
     OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, sv.ctl, stats, stream));
 #undef OK
     return IMK_OK;
