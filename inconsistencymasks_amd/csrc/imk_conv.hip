@@ -111,7 +111,7 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
 // =====================================================================================================
 template <int TH, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int mt_total,
-                                                        int nc8, int ps, int nq, int ns) {
+                                                        int nc8, int ps, int nq, int ns, int w_in_lds) {
     constexpr int P = TH / 4;  // pixel groups (tile rows) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
@@ -119,23 +119,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     const int HT = TH + 2 * halo, WT = TW + 2 * halo;
     uint8_t *s_tile = smem;
     float *s_aff = reinterpret_cast<float *>(smem + (size_t)HT * WT * ps * 16);
+    f16 *s_w = reinterpret_cast<f16 *>(s_aff + 4 * a.x.cs_in);   // [MT][ns][512] packed weight fragments (optional)
     const int t = threadIdx.x;
     const TileCoord tc = tile_coord(blockIdx.x, tiles_x, tiles_y, TH);
     const int H = a.H, W = a.W;
 
     stage_affine_table(a.x, s_aff);
+    if (w_in_lds) {
+        // One cooperative copy of this workgroup's weight fragments into LDS: the k-loop then never waits for L2
+        // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
+        const int n16 = MT * ns * 64;   // 16-byte chunks
+        for (int i = t; i < n16; i += 256) {
+            const int m = i / (ns * 64);
+            const int ct = blockIdx.y * MT + m;
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ct < mt_total) v = *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)ct * ns * 64 + (i - m * ns * 64)) * 8);
+            *reinterpret_cast<f16x8 *>(s_w + (size_t)i * 8) = v;
+        }
+    }
     if (a.x.lmode != LM_RAW && a.x.lmode != LM_U8) __syncthreads();
 
     // ---- stage the input tile -------------------------------------------------------------------
     const int n_items = HT * WT * nc8;
-    for (int i = t; i < n_items; i += 256) {
-        const int pix = i / nc8;
-        const int c8 = i - pix * nc8;
-        const int py = pix / WT, px = pix - py * WT;
-        const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (y >= 0 && y < H && x >= 0 && x < W) v = load_chunk(a.x, tc.b, y, x, H, W, c8, s_aff);
-        *reinterpret_cast<f16x8 *>(s_tile + ((size_t)pix * ps + c8) * 16) = v;
+    // batches of 4 items per thread: the 4 (or more) global loads of a batch are issued back to back, so a
+    // thread pays one memory latency per batch instead of one per item
+    for (int i0 = t; i0 < n_items; i0 += 4 * 256) {
+        f16x8 v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            dst[u] = -1;
+            v[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < n_items) {
+                const int pix = i / nc8;
+                const int c8 = i - pix * nc8;
+                const int py = pix / WT, px = pix - py * WT;
+                const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
+                dst[u] = (pix * ps + c8) * 16;
+                if (y >= 0 && y < H && x >= 0 && x < W) v[u] = load_chunk(a.x, tc.b, y, x, H, W, c8, s_aff);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v[u];
     }
     __syncthreads();
 
@@ -156,6 +183,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     int c8 = q - tap * nc8;
     int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
     const f16 *wp = a.wpk + (size_t)lane * 8;
+    // weight fragments are prefetched two k-steps ahead (L2 latency is longer than one k-step of MFMAs)
     for (int s = 0; s < ns; ++s) {
         const bool vq = q < nq;
         const int off = vq ? ((ty * WT + tx) * ps + c8) * 16 : 0;
@@ -163,8 +191,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int ct = ct0 + m;
-            af[m] = (ct < mt_total) ? *reinterpret_cast<const f16x8 *>(wp + ((size_t)ct * ns + s) * 512)
-                                    : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (w_in_lds) af[m] = *reinterpret_cast<const f16x8 *>(s_w + ((size_t)(m * ns + s) * 64 + lane) * 8);
+            else af[m] = (ct < mt_total) ? *reinterpret_cast<const f16x8 *>(wp + ((size_t)ct * ns + s) * 512)
+                                         : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -369,6 +398,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
     const bool want_stats = (a.epi == EP_RELU) && a.stats_partial;
 
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // BN statistics, accumulated over all tiles of this workgroup
     RawChunk<LM> raw[MAX_ITEMS];
     unsigned valid = 0;
     auto issue = [&](int tile) {
@@ -426,7 +456,6 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 }
             }
         }
-        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
         if (co0 < a.cs_out) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -449,22 +478,23 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
             }
         }
-        if (want_stats) {
+        __syncthreads();   // tile reads done: the LDS tile may be overwritten
+        tile = next;
+    }
+    if (want_stats) {      // one partial row per workgroup
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v1 = wave_sum<16>(s1[r]), v2 = wave_sum<16>(s2[r]);
-                if (n == 0) { s_red[(wave * 2 + 0) * 16 + 4 * g + r] = v1; s_red[(wave * 2 + 1) * 16 + 4 * g + r] = v2; }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float v1 = wave_sum<16>(s1[r]), v2 = wave_sum<16>(s2[r]);
+            if (n == 0) { s_red[(wave * 2 + 0) * 16 + 4 * g + r] = v1; s_red[(wave * 2 + 1) * 16 + 4 * g + r] = v2; }
         }
-        __syncthreads();   // tile reads done (LDS may be overwritten), s_red complete
-        if (want_stats && t < 32) {
+        __syncthreads();
+        if (t < 32) {
             const int which = t >> 4, c = t & 15;
             if (c < a.cs_out)
-                a.stats_partial[(size_t)tile * 2 * a.cs_out + which * a.cs_out + c] =
+                a.stats_partial[(size_t)blockIdx.x * 2 * a.cs_out + which * a.cs_out + c] =
                     (s_red[(0 * 2 + which) * 16 + c] + s_red[(1 * 2 + which) * 16 + c]) +
                     (s_red[(2 * 2 + which) * 16 + c] + s_red[(3 * 2 + which) * 16 + c]);
         }
-        tile = next;
     }
 }
 
@@ -834,13 +864,27 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     const size_t stats_bytes = 4 * 2 * 16 * 4 * sizeof(float);
     size_t lds = tile_bytes + 4 * (size_t)a.x.cs_in * sizeof(float);
     if (lds < stats_bytes) lds = stats_bytes;
-    const int mt = mt_total >= 4 ? 4 : (mt_total >= 2 ? 2 : 1);
-    dim3 grid(a.B * tiles_x * tiles_y, imk_cdiv(mt_total, mt));
+    const size_t lds_base = lds;
+    // output-channel tiles per workgroup: as many as possible while the grid still has >= 512 workgroups
+    // (deep layers have few tiles; they are latency-bound, so parallelism beats operand reuse there)
+    const int n_sp = a.B * tiles_x * tiles_y;
+    int mt = mt_total >= 4 ? 4 : (mt_total >= 2 ? 2 : 1);
+    while (mt > 1 && n_sp * imk_cdiv(mt_total, mt) < 512) mt >>= 1;
+    // weight fragments through LDS when they fit next to the tile (1 KB per (channel tile, k-step))
+    int w_in_lds = 0;
+    while (true) {
+        const size_t wbytes = (size_t)mt * ns * 1024;
+        if (wbytes <= 64 * 1024 && lds_base + wbytes <= 128 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
+        if (mt > 1) { mt >>= 1; continue; }
+        break;
+    }
+    if (ns <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
+    dim3 grid(n_sp, imk_cdiv(mt_total, mt));
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;  // wider than ~384 input channels on a 3x3: needs K passes
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)  // above the default dynamic-LDS limit: opt in (idempotent, no sync)
             IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns);
+        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns, w_in_lds);
         return IMK_OK;
     };
     ProfRec pr{};
@@ -855,6 +899,7 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     else if (mt == 2) rc = launch(conv_mfma_kernel<TH, 2>);
     else rc = launch(conv_mfma_kernel<TH, 1>);
     if (rc) return rc;
+    if (a.stats_rows) *a.stats_rows = n_sp;
     if (g_prof_on) {
         IMK_HIP(hipEventRecord(pr.e1, stream));
         g_prof.push_back(pr);
@@ -885,6 +930,7 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
     }
     conv_pipe_kernel<LM, NC8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles);
     IMK_LAUNCH_CHECK();
+    if (a.stats_rows) *a.stats_rows = grid;
     if (g_prof_on) {
         IMK_HIP(hipEventRecord(pr.e1, stream));
         g_prof.push_back(pr);

@@ -90,83 +90,124 @@ struct BnPrepArgs {
     int B, H, W, cs;
 };
 
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
+    // thread -> (pixel slot, chunk): 256 threads = (256 / nc8p) pixel slots x nc8p chunk lanes, nc8p = nc8 rounded up
+    // to a power of two <= 256 (lanes with chunk >= nc8 idle).  No division in the hot loop.
     const int nc8 = a.cs / 8;
-    const long long n_items = (long long)a.B * a.H * a.W * nc8;
-    const long long G = (long long)gridDim.x * 256;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c8 = (int)(gid % nc8);
+    int sh = 0;
+    while ((1 << sh) < nc8) ++sh;
+    const int nc8p = 1 << sh;
+    const int c8 = threadIdx.x & (nc8p - 1);
+    const int slot = threadIdx.x >> sh;
+    const int slots = 256 >> sh;
+    const unsigned n_pix = (unsigned)a.B * a.H * a.W;
+    const unsigned pix_stride = (unsigned)gridDim.x * slots;
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    float sc[8], sh[8];
-    if (a.mode == 1)
+    if (c8 < nc8) {
+        float sc[8], shf[8];
+        if (MODE == 1)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c8 * 8 + j]; sh[j] = a.sh[c8 * 8 + j]; }
-    for (long long it = gid; it < n_items; it += G) {
-        const long long pix = it / nc8;
-        const f16x8 z = *reinterpret_cast<const f16x8 *>(a.z + it * 8);
-        f16x8 dy;
-        if (a.mode == 0) {
-            dy = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
-        } else if (a.mode == 1) {
-            const int x = (int)(pix % a.W);
-            const long long r = pix / a.W;
-            const int y = (int)(r % a.H);
-            const int b = (int)(r / a.H);
-            const int Hh = a.H / 2, Wh = a.W / 2;
-            const f16x8 dp = *reinterpret_cast<const f16x8 *>(a.g_other + (((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * nc8 + c8) * 8);
-            // window elements in row-major order; the first maximum takes the gradient
-            const size_t w00 = (((size_t)(b * a.H + (y & ~1)) * a.W + (x & ~1)) * nc8 + c8) * 8;
-            const f16x8 z00 = *reinterpret_cast<const f16x8 *>(a.z + w00);
-            const f16x8 z01 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.cs);
-            const f16x8 z10 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.W * a.cs);
-            const f16x8 z11 = *reinterpret_cast<const f16x8 *>(a.z + w00 + (size_t)a.W * a.cs + a.cs);
-            const int me = (y & 1) * 2 + (x & 1);
-            f16x8 gd = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (a.g_direct) gd = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
+            for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c8 * 8 + j]; shf[j] = a.sh[c8 * 8 + j]; }
+        constexpr int UB = 2;   // pixels in flight per thread: all loads of a batch are issued before any use
+        for (unsigned pix0 = blockIdx.x * slots + slot; pix0 < n_pix; pix0 += UB * pix_stride) {
+            f16x8 zz[UB], d0[UB], d1[UB], w1[UB], w2[UB], w3[UB];
+            unsigned xs[UB], ys[UB];
+            bool ok[UB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f16 v0 = (f16)((float)z00[j] * sc[j] + sh[j]), v1 = (f16)((float)z01[j] * sc[j] + sh[j]);
-                const f16 v2 = (f16)((float)z10[j] * sc[j] + sh[j]), v3 = (f16)((float)z11[j] * sc[j] + sh[j]);
-                int best = 0;
-                f16 bv = v0;
-                if (v1 > bv) { bv = v1; best = 1; }
-                if (v2 > bv) { bv = v2; best = 2; }
-                if (v3 > bv) { bv = v3; best = 3; }
-                dy[j] = (f16)((float)gd[j] + (best == me ? (float)dp[j] : 0.f));
+            for (int u = 0; u < UB; ++u) {
+                const unsigned pix = pix0 + u * pix_stride;
+                ok[u] = pix < n_pix;
+                if (!ok[u]) continue;
+                const size_t it = (size_t)pix * nc8 + c8;
+                zz[u] = *reinterpret_cast<const f16x8 *>(a.z + it * 8);
+                if (MODE == 0) {
+                    d0[u] = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
+                } else {
+                    const unsigned x = pix % (unsigned)a.W;
+                    const unsigned r = pix / (unsigned)a.W;
+                    const unsigned y = r % (unsigned)a.H;
+                    const unsigned b = r / (unsigned)a.H;
+                    xs[u] = x; ys[u] = y;
+                    if (MODE == 1) {
+                        const int Hh = a.H / 2, Wh = a.W / 2;
+                        d1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + (((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * nc8 + c8) * 8);
+                        d0[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (a.g_direct) d0[u] = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
+                        // the other three elements of the 2x2 pooling window (row-major order kept below)
+                        const size_t w00 = (((size_t)(b * a.H + (y & ~1u)) * a.W + (x & ~1u)) * nc8 + c8) * 8;
+                        const int me = (y & 1) * 2 + (x & 1);
+                        const size_t o1 = (size_t)a.cs, o2 = (size_t)a.W * a.cs;
+                        const int e0 = 0 < me ? 0 : 1, e1 = 1 < me ? 1 : 2, e2 = 2 < me ? 2 : 3;   // window indices != me
+                        w1[u] = *reinterpret_cast<const f16x8 *>(a.z + w00 + (e0 >> 1) * o2 + (e0 & 1) * o1);
+                        w2[u] = *reinterpret_cast<const f16x8 *>(a.z + w00 + (e1 >> 1) * o2 + (e1 & 1) * o1);
+                        w3[u] = *reinterpret_cast<const f16x8 *>(a.z + w00 + (e2 >> 1) * o2 + (e2 & 1) * o1);
+                    } else {
+                        const int W2 = a.W * 2;
+                        const size_t u00 = (((size_t)(b * a.H * 2 + 2 * y) * W2 + 2 * x) * nc8 + c8) * 8;
+                        d0[u] = *reinterpret_cast<const f16x8 *>(a.g_other + u00);
+                        w1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)a.cs);
+                        w2[u] = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs);
+                        w3[u] = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs + a.cs);
+                    }
+                }
             }
-            *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
-        } else {
-            const int x = (int)(pix % a.W);
-            const long long r = pix / a.W;
-            const int y = (int)(r % a.H);
-            const int b = (int)(r / a.H);
-            const int H2 = a.H * 2, W2 = a.W * 2;
-            const size_t u00 = (((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * nc8 + c8) * 8;
-            const f16x8 u0 = *reinterpret_cast<const f16x8 *>(a.g_other + u00);
-            const f16x8 u1 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)a.cs);
-            const f16x8 u2 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs);
-            const f16x8 u3 = *reinterpret_cast<const f16x8 *>(a.g_other + u00 + (size_t)W2 * a.cs + a.cs);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dy[j] = (f16)(((float)u0[j] + (float)u1[j]) + ((float)u2[j] + (float)u3[j]));
-            *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
+            for (int u = 0; u < UB; ++u) {
+                if (!ok[u]) continue;
+                const unsigned pix = pix0 + u * pix_stride;
+                const size_t it = (size_t)pix * nc8 + c8;
+                f16x8 dy;
+                if (MODE == 0) {
+                    dy = d0[u];
+                } else if (MODE == 1) {
+                    // this pixel takes the pooled gradient iff it is the FIRST maximum of its window in row-major
+                    // order: strictly greater than the elements before it, greater or equal to those after it
+                    const int me = (ys[u] & 1) * 2 + (xs[u] & 1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f16 vm = (f16)((float)zz[u][j] * sc[j] + shf[j]);
+                        const f16 o[3] = {(f16)((float)w1[u][j] * sc[j] + shf[j]), (f16)((float)w2[u][j] * sc[j] + shf[j]),
+                                          (f16)((float)w3[u][j] * sc[j] + shf[j])};
+                        bool win = true;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int e = k < me ? k : k + 1;           // window index of the k-th "other" element
+                            win = win && (e < me ? (vm > o[k]) : (vm >= o[k]));
+                        }
+                        dy[j] = (f16)((float)d0[u][j] + (win ? (float)d1[u][j] : 0.f));
+                    }
+                    *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        dy[j] = (f16)(((float)d0[u][j] + (float)w1[u][j]) + ((float)w2[u][j] + (float)w3[u][j]));
+                    *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = (float)dy[j]; s1[j] += d; s2[j] += d * (float)zz[u][j]; }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)dy[j]; s1[j] += d; s2[j] += d * (float)z[j]; }
     }
-    // block reduction: threads with equal c8 are summed in thread order (deterministic)
+    // block reduction over the pixel slots (fixed tree => deterministic): s_r[slot][chunk lane][16]
     __shared__ float s_r[256][17];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s_r[threadIdx.x][j] = s1[j]; s_r[threadIdx.x][8 + j] = s2[j]; }
     __syncthreads();
-    for (int o = threadIdx.x; o < 2 * a.cs; o += 256) {
-        const int which = o / a.cs, ch = o - which * a.cs;
-        const int want = ch >> 3, j = ch & 7;
-        const int first = (int)(((long long)want - ((long long)blockIdx.x * 256) % nc8 + nc8) % nc8);
-        float v = 0.f;
-        for (int tt = first; tt < 256; tt += nc8) v += s_r[tt][which * 8 + j];
-        a.partial[(size_t)blockIdx.x * 2 * a.cs + o] = v;
+    for (int o = slots >> 1; o > 0; o >>= 1) {
+        if (slot < o)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s_r[threadIdx.x][j] += s_r[threadIdx.x + (o << sh)][j];
+        __syncthreads();
+    }
+    if (slot == 0 && c8 < nc8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a.partial[(size_t)blockIdx.x * 2 * a.cs + c8 * 8 + j] = s_r[threadIdx.x][j];
+            a.partial[(size_t)blockIdx.x * 2 * a.cs + a.cs + c8 * 8 + j] = s_r[threadIdx.x][8 + j];
+        }
     }
 }
 
@@ -220,19 +261,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f16 *__restrict
     __syncthreads();
     const int nc8 = cs / 8;
     const long long G = (long long)gridDim.x * 256;
-    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < n_items; it += G) {
-        const int c8 = (int)(it % nc8);
-        const f16x8 d = *reinterpret_cast<const f16x8 *>(dy + it * 8);
-        const f16x8 zz = *reinterpret_cast<const f16x8 *>(z + it * 8);
-        f16x8 o;
+    constexpr int UB = 4;
+    for (long long it0 = (long long)blockIdx.x * 256 + threadIdx.x; it0 < n_items; it0 += UB * G) {
+        f16x8 d[UB], zz[UB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ch = c8 * 8 + j;
-            const float zf = (float)zz[j];
-            const float v = s_c[ch] * (float)d[j] + s_c[cs + ch] * zf + s_c[2 * cs + ch];
-            o[j] = (zf > 0.f) ? (f16)v : (f16)0.f;
+        for (int u = 0; u < UB; ++u) {
+            const long long it = it0 + u * G;
+            if (it < n_items) {
+                d[u] = *reinterpret_cast<const f16x8 *>(dy + it * 8);
+                zz[u] = *reinterpret_cast<const f16x8 *>(z + it * 8);
+            }
         }
-        *reinterpret_cast<f16x8 *>(dA + it * 8) = o;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const long long it = it0 + u * G;
+            if (it >= n_items) continue;
+            const int c8 = (int)((unsigned)it % (unsigned)nc8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = c8 * 8 + j;
+                const float zf = (float)zz[u][j];
+                const float v = s_c[ch] * (float)d[u][j] + s_c[cs + ch] * zf + s_c[2 * cs + ch];
+                o[j] = (zf > 0.f) ? (f16)v : (f16)0.f;
+            }
+            *reinterpret_cast<f16x8 *>(dA + it * 8) = o;
+        }
     }
 }
 
@@ -421,18 +475,26 @@ int imk_launch_bn_fold_jobs(const ImkFoldJobs &jobs, hipStream_t stream) {
 }
 
 int imk_bn_prep_blocks(int B, int H, int W, int cs) {
+    // Small tensors are latency-bound: one batch (2 pixels) per thread and as many blocks as that gives.
+    // Large ones: at most 4096 blocks (= 2 rounds of full occupancy), more pixels per thread.
     const int nc8 = cs / 8;
-    const long long items = (long long)B * H * W * nc8;
-    long long nb = (items + 256 * 8 - 1) / (256 * 8);  // about 8 items per thread
-    if (nb > 2048) nb = 2048;
-    nb = (nb + nc8 - 1) / nc8 * nc8;                    // multiple of nc8: fixed chunk index per thread
+    int nc8p = 1;
+    while (nc8p < nc8) nc8p <<= 1;
+    const int slots = 256 / nc8p;                      // pixels per block per sweep
+    const long long pix = (long long)B * H * W;
+    long long nb = (pix + (long long)slots * 2 - 1) / ((long long)slots * 2);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
     return (int)nb;
 }
 
 int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
                            const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream) {
     BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs};
-    bn_bwd_prep_kernel<<<imk_bn_prep_blocks(B, H, W, cs), 256, 0, stream>>>(a);
+    const int nb = imk_bn_prep_blocks(B, H, W, cs);
+    if (mode == 0) bn_bwd_prep_kernel<0><<<nb, 256, 0, stream>>>(a);
+    else if (mode == 1) bn_bwd_prep_kernel<1><<<nb, 256, 0, stream>>>(a);
+    else bn_bwd_prep_kernel<2><<<nb, 256, 0, stream>>>(a);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -449,7 +511,7 @@ int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, doub
 int imk_launch_bn_bwd_apply(const f16 *dy, const f16 *z, const float *coef, int cs, long long n_pix, f16 *dA,
                             hipStream_t stream) {
     const long long items = n_pix * (cs / 8);
-    long long nb = (items + 256 * 4 - 1) / (256 * 4);
+    long long nb = (items + 256 * 4 - 1) / (256 * 4);   // one batch of 4 per thread up to 4096 blocks
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     bn_bwd_apply_kernel<<<(int)nb, 256, 3 * cs * sizeof(float), stream>>>(dy, z, coef, cs, items, dA);

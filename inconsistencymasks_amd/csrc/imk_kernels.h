@@ -34,7 +34,8 @@ struct ImkConvArgs {
     const float *bias;     // [cout], EP_RELU only
     f16 *out;              // [B,H,W,cs_out]
     const f16 *mask;       // EP_MASK: [B,H,W,cs_out]
-    float *stats_partial;  // EP_RELU, optional: [n_tiles][2*cs_out] (sum, sumsq of the fp16-rounded outputs)
+    float *stats_partial;  // EP_RELU, optional: [rows][2*cs_out] (sum, sumsq of the fp16-rounded outputs)
+    int *stats_rows;       // host, optional: receives the number of partial rows this launch writes
     int epi;
 };
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize);  // rows of stats_partial

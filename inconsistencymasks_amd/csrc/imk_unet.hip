@@ -2,6 +2,7 @@
 // imk_elem.hip: parameter layout, weight packing, workspace layout, batched inference, ensemble
 // inference + IM, and the training step (forward with batch statistics, loss, backward, AdamW).
 // Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "imk_elem.h"
@@ -267,7 +268,11 @@ int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw) {
     a.out = c.act(conv);
     a.epi = EP_RELU;
     const int bn = bn_of_conv(c.t, conv);
-    if (c.train && bn >= 0) a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].stats_partial);
+    int rows = 0;
+    if (c.train && bn >= 0) {
+        a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].stats_partial);
+        a.stats_rows = &rows;
+    }
     int rc = imk_launch_conv(a, c.stream);
     if (rc) return rc;
     if (c.train && bn >= 0) {
@@ -275,7 +280,8 @@ int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw) {
         const int cs = imk_pad8(b.cout);
         float *sc = reinterpret_cast<float *>(c.base + c.ws.L[bn].scale);
         float *sv = reinterpret_cast<float *>(c.base + c.ws.L[bn].save);
-        rc = imk_launch_bn_finalize(a.stats_partial, c.ws.L[bn].n_stats_tiles, b.cout, cs, (double)c.B * d.h * d.w,
+        if (rows <= 0 || rows > c.ws.L[bn].n_stats_tiles) return IMK_EWORKSPACE;
+        rc = imk_launch_bn_finalize(a.stats_partial, rows, b.cout, cs, (double)c.B * d.h * d.w,
                                     c.params + b.off_w, c.params + b.off_b, params_rw + b.off_mean, params_rw + b.off_var,
                                     sc, sc + cs, sv, sv + cs, c.stream);
     }
@@ -573,7 +579,11 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         ok = ok && hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) == hipSuccess;
         plan->side_ok = ok;
     });
-    Bwd b{c, x, grads, sv.ctl, plan->side_ok ? plan->side : stream};
+    // Measured (profiles/README.md): every kernel of the step is wide enough to fill the chip, so running the
+    // weight-gradient kernels concurrently on the side stream only adds contention and event waits
+    // (1.91 ms vs 1.76 ms per step).  Single stream by default; IMK_SIDE_STREAM=1 re-enables the fork/join.
+    static const bool use_side = []() { const char *e = getenv("IMK_SIDE_STREAM"); return e && e[0] == '1'; }();
+    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && use_side) ? plan->side : stream};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
     {
