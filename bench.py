@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--infer-batch", type=int, default=128)
     ap.add_argument("--images", type=int, default=U_UNLABELED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="no per-launch event timing (roofline fields empty)")
+    ap.add_argument("--prof-period", type=int, default=5, help="time every k-th conv launch with HIP events")
     ap.add_argument("--pretrain-steps", type=int, default=300)
     ap.add_argument("--bn-settle-steps", type=int, default=600)
     args = ap.parse_args()
@@ -211,9 +213,12 @@ def main():
         generation()
     barrier()
     rec = []
-    imk_lib.imk_prof_enable(1)          # HIP events around every conv launch, on the launch stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # HIP events (on the launch stream) around every 5th conv launch of the timed region: sampling keeps the cost of
+    # the event records (~10 % of a training step if every launch is bracketed) near 2 %.  5 is coprime to the 39
+    # conv launches of a training step and the 17 of a forward, so every layer is sampled equally often.
+    imk_lib.imk_prof_enable(0 if args.no_prof else args.prof_period)
+    for k in range(args.steps):
         generation(rec)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -238,7 +243,8 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
                 "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
-                "share_of_step_time": round(pms[v] / (1000 * elapsed), 3), "all_conv_variants": conv_all}
+                "share_of_step_time": round(pms[v] * args.prof_period / (1000 * elapsed), 3), "sampling": f"every {args.prof_period}th conv launch of the timed region",
+                "all_conv_variants": conv_all}
 
     # ---- the fused IM kernel on the same shapes (HBM-bound; SURVEY 8d: 1 MiB / image) ------------------------
     probs = torch.stack([m.predict_device(x_unl[:args.infer_batch]) for m in models], 0)

@@ -172,7 +172,7 @@ int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, 
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the convolution kernel, on the stream the
- * kernel is launched on.  imk_prof_enable(1) makes every conv launch record an event pair; 
+ * kernel is launched on.  imk_prof_enable(k) makes every k-th conv launch record an event pair (0 = off);
  * imk_prof_collect synchronises those events and returns, per kernel variant v (0..IMK_PROF_VARIANTS-1:
  * v = 3*(tile_h==8) + log2(MT) for conv_mfma_kernel, v = 6 for conv_pipe_kernel), the launch count, the summed duration in ms and the summed ALGORITHMIC
  * bytes (input tensor(s) read once + output tensor written once + mask read once), then resets.

@@ -41,6 +41,24 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles
     return c;
 }
 
+// n / d for n < 2^23 via a float reciprocal (exact after one correction step): ~6 VALU ops instead of ~35
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float inv_d) {
+    unsigned q = (unsigned)((float)n * inv_d);
+    const int r = (int)n - (int)(q * d);
+    if (r < 0) --q; else if (r >= (int)d) ++q;
+    return q;
+}
+
+__device__ __forceinline__ TileCoord tile_coord_fast(int tile, int tiles_x, int per_img, float inv_tx, float inv_pi) {
+    TileCoord c;
+    c.b = (int)fast_div((unsigned)tile, (unsigned)per_img, inv_pi);
+    const int r = tile - c.b * per_img;
+    const int ty = (int)fast_div((unsigned)r, (unsigned)tiles_x, inv_tx);
+    c.ty0 = ty * 16;
+    c.tx0 = (r - ty * tiles_x) * TW;
+    return c;
+}
+
 __device__ __forceinline__ f16x8 affine8(f16x8 z, const float *sc, const float *sh) {
     f16x8 o;
 #pragma unroll
@@ -197,8 +215,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);
-            if (!vq) bf = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);  // invalid k-slots: zero weights
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][p], 0, 0, 0);
         }
@@ -343,7 +360,8 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 }
 
 template <int LM, int NC8>
-__global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+__global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
+                                                        float inv_tx, float inv_pi) {
     constexpr int P = 4;                        // tile rows per wave (16 x 16 tile)
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -361,20 +379,22 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int H = a.H, W = a.W;
     const int cs_in = a.x.cs_in;
+    const int per_img = tiles_x * tiles_y;
 
     stage_affine_table(a.x, s_aff);
 
     // packed weights and per-lane LDS offsets of every k-step: once per workgroup
     f16x8 af[MAX_NS];
     int off[MAX_NS];
-    bool vq[MAX_NS];
+    // k-slots beyond the real taps carry zero WEIGHTS; their pixel operand may be any finite tile data, so
+    // those lanes simply read offset 0 (no per-read select).
 #pragma unroll
     for (int s = 0; s < MAX_NS; ++s) {
         const int q = 4 * s + g;
-        vq[s] = (s < ns) && (q < nq);
+        const bool vq = (s < ns) && (q < nq);
         const int tap = q / NC8, c8 = q - tap * NC8;
         const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
-        off[s] = vq[s] ? ((ty * WT + tx) * PS + c8) * 16 : 0;
+        off[s] = vq ? ((ty * WT + tx) * PS + c8) * 16 : 0;
         af[s] = (s < ns) ? *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)s * 64 + lane) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     int base[P];
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     RawChunk<LM> raw[MAX_ITEMS];
     unsigned valid = 0;
     auto issue = [&](int tile) {
-        const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
+        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
             }
         }
-        const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
+        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
         const int x = tc.tx0 + n;
         __syncthreads();
         const int next = tile + gridDim.x;
@@ -450,8 +470,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             if (s < ns) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off[s]);
-                    if (!vq[s]) bf = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off[s]);
                     acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], bf, acc[p], 0, 0, 0);
                 }
             }
@@ -474,8 +493,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     for (int r = 0; r < 4; ++r) v[r] = (f16)acc[p][r];
                 }
                 *reinterpret_cast<f16x4 *>(a.out + o) = v;
+                if (want_stats)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                    for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
             }
         }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
@@ -503,6 +523,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // =====================================================================================================
 constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 channels + 8 pad = 48 B)
 
+// LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
+// tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
+template <int LM>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                          int cit_n, int cot_n, int nc8_in, int nc8_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
     const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
     const int T = ks3 ? 9 : 1;
     f16 *s_x = reinterpret_cast<f16 *>(smem);
-    f16 *s_d = s_x + HT * WT * WG_STRIDE_H;
+    f16 *s_d = s_x + 18 * 18 * WG_STRIDE_H;
     float *s_aff = reinterpret_cast<float *>(s_d + 256 * WG_STRIDE_H);
     const int t = threadIdx.x;
     const int pair = blockIdx.y;
@@ -528,31 +551,74 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (f16)(i16 == 0 ? 1.0f : 0.0f);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // staging items of this thread (constant over tiles): 3 chunks of the x slice, 2 of the dA slice
+    constexpr int NX = 3, ND = 2;
+    const int n_x = HT * WT * 2;
+    int x_lds[NX], x_py[NX], x_px[NX], x_c8[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i >> 1;
+        x_c8[k] = 2 * cit + (i & 1);
+        x_py[k] = pix / WT;
+        x_px[k] = pix - x_py[k] * WT;
+        x_lds[k] = (i < n_x) ? pix * WG_STRIDE_H + (i & 1) * 8 : -1;
+    }
+    int d_lds[ND], d_py[ND], d_px[ND], d_c8[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i >> 1;
+        d_c8[k] = 2 * cot + (i & 1);
+        d_py[k] = pix >> 4;
+        d_px[k] = pix & 15;
+        d_lds[k] = pix * WG_STRIDE_H + (i & 1) * 8;
+    }
+    RawChunk<LM> xr[NX];
+    f16x8 dr[ND];
+    unsigned vx = 0, vd = 0;
+    auto issue = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
-        __syncthreads();  // previous tile's reads are done (also covers the affine table on the first pass)
-        // x slice: 16 channels (2 chunks) of every halo-tile pixel
-        for (int i = t; i < HT * WT * 2; i += 256) {
-            const int pix = i >> 1, c8l = i & 1;
-            const int py = pix / WT, px = pix - py * WT;
-            const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
-            const int c8 = 2 * cit + c8l;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (c8 < nc8_in && y >= 0 && y < H && x >= 0 && x < W) v = load_chunk(a.x, tc.b, y, x, H, W, c8, s_aff);
-            *reinterpret_cast<f16x8 *>(s_x + pix * WG_STRIDE_H + c8l * 8) = v;
+        vx = vd = 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int y = tc.ty0 + x_py[k] - halo, x = tc.tx0 + x_px[k] - halo;
+            if (x_lds[k] >= 0 && x_c8[k] < nc8_in && y >= 0 && y < H && x >= 0 && x < W) {
+                raw_load<LM>(a.x, tc.b, y, x, H, W, x_c8[k], xr[k]);
+                vx |= 1u << k;
+            }
         }
-        // dA slice
-        for (int i = t; i < 256 * 2; i += 256) {
-            const int pix = i >> 1, c8l = i & 1;
-            const int py = pix >> 4, px = pix & 15;
-            const int y = tc.ty0 + py, x = tc.tx0 + px;
-            const int c8 = 2 * cot + c8l;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int y = tc.ty0 + d_py[k], x = tc.tx0 + d_px[k];
+            if (d_c8[k] < nc8_out && y < H && x < W) {
+                dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + d_c8[k] * 8);
+                vd |= 1u << k;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) issue(tile);
+    __syncthreads();   // affine table visible
+    while (tile < n_tiles) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            if (x_lds[k] >= 0) {
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (vx & (1u << k)) v = raw_transform<LM>(xr[k], s_aff, a.x.cs_in, x_c8[k], a.x.cin);
+                *reinterpret_cast<f16x8 *>(s_x + x_lds[k]) = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
             f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (c8 < nc8_out && y < H && x < W)
-                v = *reinterpret_cast<const f16x8 *>(a.dA + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + c8 * 8);
-            *reinterpret_cast<f16x8 *>(s_d + pix * WG_STRIDE_H + c8l * 8) = v;
+            if (vd & (1u << k)) v = dr[k];
+            *reinterpret_cast<f16x8 *>(s_d + d_lds[k]) = v;
         }
         __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) issue(next);     // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 2 * (wave + 4 * kk);          // tile rows r0, r0+1 form this k-step's 32 pixels
@@ -581,9 +647,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
             }
             acc[9] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bf, acc[9], 0, 0, 0);  // column sums -> bias grad
         }
+        __syncthreads();   // tile reads done before the next tile overwrites LDS
+        tile = next;
     }
     // ---- reduce the 4 waves' accumulators through LDS, write this workgroup's partial ----------------
-    __syncthreads();
     float *s_acc = reinterpret_cast<float *>(smem);  // [4][10][256]
 #pragma unroll
     for (int i = 0; i < 10; ++i)
@@ -810,7 +877,8 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int variant; double bytes; };
-bool g_prof_on = false;
+int g_prof_period = 0;   // 0 = off, k = time every k-th conv launch
+long g_prof_counter = 0;
 std::vector<ProfRec> g_prof;       // recorded launches since the last collect
 std::vector<hipEvent_t> g_ev_pool; // recycled events
 
@@ -836,7 +904,8 @@ double conv_algorithmic_bytes(const ImkConvArgs &a) {
 }
 }  // namespace
 
-extern "C" int imk_prof_enable(int on) { g_prof_on = on != 0; return IMK_OK; }
+extern "C" int imk_prof_enable(int on) { g_prof_period = on < 0 ? 0 : on; return IMK_OK; }
+static inline bool prof_sample() { return g_prof_period > 0 && (g_prof_counter++ % g_prof_period) == 0; }
 
 extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
     IMK_CHECK_ARG(count && ms && bytes);
@@ -888,7 +957,8 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
         return IMK_OK;
     };
     ProfRec pr{};
-    if (g_prof_on) {
+    const bool prof = prof_sample();
+    if (prof) {
         pr.e0 = prof_event(); pr.e1 = prof_event();
         pr.variant = (TH == 8 ? 3 : 0) + (mt == 4 ? 2 : (mt == 2 ? 1 : 0));
         pr.bytes = conv_algorithmic_bytes(a);
@@ -900,7 +970,7 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     else rc = launch(conv_mfma_kernel<TH, 1>);
     if (rc) return rc;
     if (a.stats_rows) *a.stats_rows = n_sp;
-    if (g_prof_on) {
+    if (prof) {
         IMK_HIP(hipEventRecord(pr.e1, stream));
         g_prof.push_back(pr);
     }
@@ -922,16 +992,18 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     ProfRec pr{};
-    if (g_prof_on) {
+    const bool prof = prof_sample();
+    if (prof) {
         pr.e0 = prof_event(); pr.e1 = prof_event();
         pr.variant = 6;
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    conv_pipe_kernel<LM, NC8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles);
+    conv_pipe_kernel<LM, NC8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
+                                                          1.0f / (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
-    if (g_prof_on) {
+    if (prof) {
         IMK_HIP(hipEventRecord(pr.e1, stream));
         g_prof.push_back(pr);
     }
@@ -970,7 +1042,7 @@ int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream) {
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout) {
     const int n_tiles = B * imk_cdiv(H, 16) * imk_cdiv(W, TW);
     const int n_pairs = ((imk_pad8(cin) + 15) / 16) * ((imk_pad8(cout) + 15) / 16);
-    int s = 1024 / n_pairs;
+    int s = 768 / n_pairs;   // ~3 resident workgroups per CU; each walks its tiles with prefetch
     if (s < 1) s = 1;
     if (s > n_tiles) s = n_tiles;
     return s;
@@ -991,11 +1063,20 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     const int cit_n = (a.x.cs_in + 15) / 16, cot_n = (a.cs_out + 15) / 16;
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
     const int n_tiles = a.B * tiles_x * tiles_y;
-    size_t lds = ((size_t)(16 + 2 * halo) * (TW + 2 * halo) + 256) * WG_STRIDE_H * sizeof(f16) + 4 * (size_t)a.x.cs_in * sizeof(float);
+    (void)halo;
+    size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + 4 * (size_t)a.x.cs_in * sizeof(float);
     const size_t red = 4 * 10 * 256 * sizeof(float);
     if (lds < red) lds = red;
     dim3 grid(a.n_split, cit_n * cot_n);
-    wgrad_mfma_kernel<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, a.x.cs_in / 8, a.cs_out / 8);
+    if (a.x.lmode == LM_U8 && a.x.cin > 4) return IMK_EUNSUPPORTED;
+    const int nci = a.x.cs_in / 8, nco = a.cs_out / 8;
+    switch (a.x.lmode) {
+        case LM_RAW: wgrad_mfma_kernel<LM_RAW><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        case LM_AFFINE: wgrad_mfma_kernel<LM_AFFINE><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        case LM_POOL: wgrad_mfma_kernel<LM_POOL><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        case LM_UPADD: wgrad_mfma_kernel<LM_UPADD><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        default: wgrad_mfma_kernel<LM_U8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+    }
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
