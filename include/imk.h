@@ -170,6 +170,11 @@ int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, 
                         const float *grads, const float *stats, float grad_scale,
                         float lr, float wd, float beta1, float beta2, float eps, void *stream);
 
+/* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
+ * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on
+ * every layer.  Global flag; training always stores them (the backward pass needs them). */
+int imk_debug_materialize(int on);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the convolution kernel, on the stream the
  * kernel is launched on.  imk_prof_enable(k) makes every k-th conv launch record an event pair (0 = off);

@@ -106,6 +106,18 @@ __device__ __forceinline__ f16x8 load_chunk(const ImkInput &in, int b, int y, in
             for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
             return o;
         }
+        case LM_BNBWD: {
+            const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
+            const f16x8 dy = *(const f16x8 *)((const f16 *)in.in + o), z = *(const f16x8 *)((const f16 *)in.in2 + o);
+            const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
+            f16x8 o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float zf = (float)z[j];
+                o8[j] = zf > 0.f ? (f16)(A[j] * (float)dy[j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
+            }
+            return o8;
+        }
         default: {  // LM_U8: cin <= 8 bytes per pixel, single chunk
             const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
             f16x8 o;
@@ -122,6 +134,8 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
         for (int i = threadIdx.x; i < cs; i += 256) { s_aff[i] = in.sc[i]; s_aff[cs + i] = in.sh[i]; }
     if (in.lmode == LM_UPADD)
         for (int i = threadIdx.x; i < cs; i += 256) { s_aff[2 * cs + i] = in.sc2[i]; s_aff[3 * cs + i] = in.sh2[i]; }
+    if (in.lmode == LM_BNBWD)
+        for (int i = threadIdx.x; i < 3 * cs; i += 256) s_aff[i] = in.sc[i];
 }
 
 // =====================================================================================================
@@ -234,7 +248,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
-    const bool want_stats = (a.epi == EP_RELU) && a.stats_partial;
+    const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
+    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int co0 = (ct0 + m) * 16 + 4 * g;
@@ -261,9 +276,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
                 for (int r = 0; r < 4; ++r) v[r] = (f16)acc[m][p][r];
             }
             *reinterpret_cast<f16x4 *>(a.out + o) = v;
-            if (want_stats)
+            if (dystat) {
+                const f16x4 zz = *reinterpret_cast<const f16x4 *>(a.dystat_z + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * (float)zz[r]; }
+            } else if (want_stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * f; }
+            }
         }
     }
     if (want_stats) {  // workgroup-uniform branch
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
 //     resident workgroup always has a tile of loads in flight;
 //   * the packed weights (<= 5 k-steps) and the per-lane LDS offsets are loaded once per workgroup.
 // =====================================================================================================
-template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : (LM == LM_UPADD ? 2 : 1)]; };
+template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 2 : 1)]; };
 template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
 
 template <int LM>
@@ -321,6 +341,10 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
     } else if constexpr (LM == LM_UPADD) {
         r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * cs + c8 * 8);
         r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
+    } else if constexpr (LM == LM_BNBWD) {
+        const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + o);
+        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + o);
     } else {
         const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
 #pragma unroll
@@ -351,6 +375,15 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
         return o;
+    } else if constexpr (LM == LM_BNBWD) {
+        const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zf = (float)r.v[1][j];
+            o[j] = zf > 0.f ? (f16)(A[j] * (float)r.v[0][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
+        }
+        return o;
     } else {
         f16x8 o;
 #pragma unroll
@@ -359,7 +392,7 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
     }
 }
 
-template <int LM, int NC8>
+template <int LM, int NC8, bool CHAIN>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         float inv_tx, float inv_pi) {
     constexpr int P = 4;                        // tile rows per wave (16 x 16 tile)
@@ -411,12 +444,19 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         it_px[k] = pix - it_py[k] * WT;
         it_lds[k] = (i < n_items) ? (pix * PS + it_c8[k]) * 16 : -1;
     }
-    float bias[4] = {0, 0, 0, 0};
+    float bias[4] = {0, 0, 0, 0}, bias2[4] = {0, 0, 0, 0};
     const int co0 = 4 * g;
     if (a.epi == EP_RELU && a.bias)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
-    const bool want_stats = (a.epi == EP_RELU) && a.stats_partial;
+    f16x8 af2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (CHAIN) {
+        af2 = *reinterpret_cast<const f16x8 *>(a.wpk2 + (size_t)lane * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias2[r] = (co0 + r < a.cout2) ? a.bias2[co0 + r] : 0.f;
+    }
+    const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
+    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
 
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // BN statistics, accumulated over all tiles of this workgroup
     RawChunk<LM> raw[MAX_ITEMS];
@@ -462,6 +502,16 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
             }
         }
+        f16x4 zq[P];
+        if (dystat) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int y = tc.ty0 + wave * P + p;
+                zq[p] = f16x4{0, 0, 0, 0};
+                if (y < H && x < W && co0 < a.cs_out)
+                    zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
+            }
+        }
         f32x4 acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = f32x4{0, 0, 0, 0};
@@ -475,6 +525,31 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 }
             }
         }
+        if (CHAIN) {
+            // stage 1: h = relu(acc + b) in fp16 (stored only if the caller wants it); stage 2 on the register tile:
+            // the lane's 4 channels of pixel n are exactly k-slots (g, 0..3) of the next MFMA's B operand.
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int y = tc.ty0 + wave * P + p;
+                const bool inb = (y < H) && (x < W);
+                f16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
+                const size_t pix = (size_t)(tc.b * H + y) * W + x;
+                if (a.out && inb && co0 < a.cs_out) *reinterpret_cast<f16x4 *>(a.out + pix * a.cs_out + co0) = hv;
+                const f16x8 bf2 = {hv[0], hv[1], hv[2], hv[3], 0, 0, 0, 0};
+                const f32x4 a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2, bf2, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                if (inb && co0 < a.cs_out2) {
+                    f16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(a2[r] + bias2[r], 0.f);
+                    *reinterpret_cast<f16x4 *>(a.out2 + pix * a.cs_out2 + co0) = v;
+                    if (want_stats)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                }
+            }
+        } else
         if (co0 < a.cs_out) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -493,9 +568,13 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     for (int r = 0; r < 4; ++r) v[r] = (f16)acc[p][r];
                 }
                 *reinterpret_cast<f16x4 *>(a.out + o) = v;
-                if (want_stats)
+                if (dystat) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * (float)zq[p][r]; }
+                } else if (want_stats) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                }
             }
         }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
@@ -510,8 +589,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         __syncthreads();
         if (t < 32) {
             const int which = t >> 4, c = t & 15;
-            if (c < a.cs_out)
-                a.stats_partial[(size_t)blockIdx.x * 2 * a.cs_out + which * a.cs_out + c] =
+            const int cs_st = CHAIN ? a.cs_out2 : a.cs_out;
+            if (c < cs_st)
+                a.stats_partial[(size_t)blockIdx.x * 2 * cs_st + which * cs_st + c] =
                     (s_red[(0 * 2 + which) * 16 + c] + s_red[(1 * 2 + which) * 16 + c]) +
                     (s_red[(2 * 2 + which) * 16 + c] + s_red[(3 * 2 + which) * 16 + c]);
         }
@@ -543,6 +623,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
     const int lane = t & 63, wave = t >> 6, g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
 
     stage_affine_table(a.x, s_aff);
+    float *s_coef = s_aff + 4 * a.x.cs_in;          // [A | B | C] of the dA-side BatchNorm backward (optional)
+    const bool bnbwd = a.dA_z != nullptr;
+    if (bnbwd)
+        for (int i = t; i < 3 * a.cs_out; i += 256) s_coef[i] = a.dA_coef[i];
 
     f32x4 acc[10];
 #pragma unroll
@@ -575,7 +659,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
         d_lds[k] = pix * WG_STRIDE_H + (i & 1) * 8;
     }
     RawChunk<LM> xr[NX];
-    f16x8 dr[ND];
+    f16x8 dr[ND], dz[ND];
     unsigned vx = 0, vd = 0;
     auto issue = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_x, tiles_y, 16);
@@ -592,7 +676,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
         for (int k = 0; k < ND; ++k) {
             const int y = tc.ty0 + d_py[k], x = tc.tx0 + d_px[k];
             if (d_c8[k] < nc8_out && y < H && x < W) {
-                dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + d_c8[k] * 8);
+                const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + d_c8[k] * 8;
+                dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + o);
+                if (bnbwd) dz[k] = *reinterpret_cast<const f16x8 *>(a.dA_z + o);
                 vd |= 1u << k;
             }
         }
@@ -613,7 +699,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (vd & (1u << k)) v = dr[k];
+            if (vd & (1u << k)) {
+                v = dr[k];
+                if (bnbwd) {
+                    const float *A = s_coef + d_c8[k] * 8, *Bc = A + a.cs_out, *Cc = Bc + a.cs_out;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float zf = (float)dz[k][j];
+                        v[j] = zf > 0.f ? (f16)(A[j] * (float)dr[k][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
+                    }
+                }
+            }
             *reinterpret_cast<f16x8 *>(s_d + d_lds[k]) = v;
         }
         __syncthreads();
@@ -799,6 +895,17 @@ __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, c
 // all conv layers of a model in one launch: blockIdx.y = job
 __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs) {
     const ImkPackJob &jb = jobs.j[blockIdx.y];
+    if (jb.transposed == 2) {   // chain operand of a 1x1 conv: one k-step, lane (m, g), j < 4 <-> W[ci = 4g + j][co = m]
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < 512; i += gridDim.x * 256) {
+            const int j = i & 7, lane = (i >> 3) & 63;
+            const int m = lane & 15, g = lane >> 4;
+            const int ci = 4 * g + j;
+            float v = 0.f;
+            if (j < 4 && ci < jb.cin && m < jb.cout) v = jb.w[(size_t)ci * jb.cout + m];
+            jb.dst[i] = (f16)v;
+        }
+        return;
+    }
     const int T = jb.ksize == 3 ? 9 : 1;
     const int m_dim = jb.transposed ? jb.cin : jb.cout, k_dim = jb.transposed ? jb.cout : jb.cin;
     const int nc8 = ((k_dim + 7) & ~7) / 8;
@@ -895,11 +1002,14 @@ double conv_algorithmic_bytes(const ImkConvArgs &a) {
     switch (a.x.lmode) {
         case LM_POOL: in_b = 4.0 * px * a.x.cs_in * 2; break;                     // reads the 2H x 2W tensor
         case LM_UPADD: in_b = px * a.x.cs_in * 2 + 0.25 * px * a.x.cs_in * 2; break;  // skip + low-res tensor
+        case LM_BNBWD: in_b = 2.0 * px * a.x.cs_in * 2; break;                        // dy and z
         case LM_U8: in_b = px * a.x.cin; break;
         default: in_b = px * a.x.cs_in * 2;
     }
-    double out_b = px * a.cs_out * 2;
+    double out_b = (a.wpk2 && !a.out) ? 0.0 : px * a.cs_out * 2;
+    if (a.wpk2) out_b += px * a.cs_out2 * 2;
     if (a.epi == EP_MASK) out_b += px * a.cs_out * 2;
+    if (a.epi != EP_RELU && a.dystat_z) out_b += px * a.cs_out * 2;
     return in_b + out_b;
 }
 }  // namespace
@@ -978,13 +1088,13 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8>
+template <int LM, int NC8, bool CHAIN>
 static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float);
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8, CHAIN>, 256, lds) != hipSuccess || nb < 1) nb = 4;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
@@ -999,7 +1109,7 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    conv_pipe_kernel<LM, NC8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
+    conv_pipe_kernel<LM, NC8, CHAIN><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
                                                           1.0f / (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -1010,30 +1120,44 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int NC8>
+template <int NC8, bool CHAIN>
 static int launch_conv_pipe_lm(const ImkConvArgs &a, hipStream_t stream) {
     switch (a.x.lmode) {
-        case LM_RAW: return launch_conv_pipe<LM_RAW, NC8>(a, stream);
-        case LM_AFFINE: return launch_conv_pipe<LM_AFFINE, NC8>(a, stream);
-        case LM_POOL: return launch_conv_pipe<LM_POOL, NC8>(a, stream);
-        case LM_UPADD: return launch_conv_pipe<LM_UPADD, NC8>(a, stream);
-        default: return launch_conv_pipe<LM_U8, NC8>(a, stream);
+        case LM_RAW: return launch_conv_pipe<LM_RAW, NC8, CHAIN>(a, stream);
+        case LM_AFFINE: return launch_conv_pipe<LM_AFFINE, NC8, CHAIN>(a, stream);
+        case LM_POOL: return launch_conv_pipe<LM_POOL, NC8, CHAIN>(a, stream);
+        case LM_UPADD: return launch_conv_pipe<LM_UPADD, NC8, CHAIN>(a, stream);
+        case LM_BNBWD: return launch_conv_pipe<LM_BNBWD, NC8, CHAIN>(a, stream);
+        default: return launch_conv_pipe<LM_U8, NC8, CHAIN>(a, stream);
     }
+}
+
+bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
+    static const bool off = []() { const char *e = getenv("IMK_CONV_CHAIN"); return e && e[0] == '0'; }();
+    const char *e = getenv("IMK_CONV_PIPE");
+    if (off || (e && e[0] == '0')) return false;
+    return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
 
 static bool g_use_pipe = true;   // IMK_CONV_PIPE=0 in the environment falls back to the per-tile kernel (A/B runs)
 
 int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream) {
-    IMK_CHECK_ARG(a.x.in && a.wpk && a.out && a.B > 0 && a.H > 0 && a.W > 0);
+    IMK_CHECK_ARG(a.x.in && a.wpk && (a.out || a.wpk2) && a.B > 0 && a.H > 0 && a.W > 0);
     IMK_CHECK_ARG(a.ksize == 1 || a.ksize == 3);
     IMK_CHECK_ARG(a.x.cs_in % 8 == 0 && a.cs_out % 8 == 0 && a.x.cs_in >= a.x.cin && a.cs_out >= a.cout);
     IMK_CHECK_ARG(a.x.lmode != LM_U8 || (a.x.cs_in == 8 && a.x.cin <= 8));
     if (a.x.cs_in > 512) return IMK_EUNSUPPORTED;
     static const bool env_checked = []() { const char *e = getenv("IMK_CONV_PIPE"); if (e && e[0] == '0') g_use_pipe = false; return true; }();
     (void)env_checked;
-    if (g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4)) {
-        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1>(a, stream);
-        return launch_conv_pipe_lm<2>(a, stream);
+    const bool pipe_ok = g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
+    if (a.wpk2) {   // fused second stage: only the pipelined kernel implements it (callers check imk_conv_can_chain)
+        if (!pipe_ok || a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cout2 > 16 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
+        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1, true>(a, stream);
+        return launch_conv_pipe_lm<2, true>(a, stream);
+    }
+    if (pipe_ok) {
+        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1, false>(a, stream);
+        return launch_conv_pipe_lm<2, false>(a, stream);
     }
     if (conv_tile_h(a.x.cs_in, a.ksize) == 16) return launch_conv_th<16>(a, stream);
     return launch_conv_th<8>(a, stream);
@@ -1064,7 +1188,7 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
     const int n_tiles = a.B * tiles_x * tiles_y;
     (void)halo;
-    size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + 4 * (size_t)a.x.cs_in * sizeof(float);
+    size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + (4 * (size_t)a.x.cs_in + 3 * (size_t)a.cs_out) * sizeof(float);
     const size_t red = 4 * 10 * 256 * sizeof(float);
     if (lds < red) lds = red;
     dim3 grid(a.n_split, cit_n * cot_n);
@@ -1075,6 +1199,7 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
         case LM_AFFINE: wgrad_mfma_kernel<LM_AFFINE><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
         case LM_POOL: wgrad_mfma_kernel<LM_POOL><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
         case LM_UPADD: wgrad_mfma_kernel<LM_UPADD><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        case LM_BNBWD: return IMK_EUNSUPPORTED;   // the x side of a wgrad is always a forward tensor
         default: wgrad_mfma_kernel<LM_U8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
     }
     IMK_LAUNCH_CHECK();
@@ -1102,6 +1227,7 @@ int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int 
 }
 
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed) {
+    if (transposed == 2) return 512;
     const int T = ksize == 3 ? 9 : 1;
     const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
     const int nc8 = imk_pad8(k_dim) / 8;

@@ -9,6 +9,8 @@ enum ImkLoadMode {
     LM_POOL = 2,    // 2x2 max of fp16(z*sc + sh), z at [B,2H,2W,cs]     (BN + MaxPooling2D, unet.py:16-17)
     LM_UPADD = 3,   // fp16( fp16(zlo*sc+sh)[y/2,x/2] + fp16(zsk*sc2+sh2) )  (UpSampling2D + add, unet.py:32-33)
     LM_U8 = 4,      // fp16(u8/255), [B,H,W,cin] bytes                   (Lambda x/255, unet.py:5)
+    LM_BNBWD = 5,   // (A*dy + B*z + C) * [z > 0]: BatchNorm backward + ReLU backward applied on load;
+                    // in = dy, in2 = z (the BN's input), sc = per-channel coefficients [A | B | C] (3*cs floats)
 };
 enum ImkEpilogue {
     EP_RELU = 0,   // fp16(max(acc + bias, 0)); optional per-channel sum / sum-of-squares partials
@@ -34,7 +36,16 @@ struct ImkConvArgs {
     const float *bias;     // [cout], EP_RELU only
     f16 *out;              // [B,H,W,cs_out]
     const f16 *mask;       // EP_MASK: [B,H,W,cs_out]
-    float *stats_partial;  // EP_RELU, optional: [rows][2*cs_out] (sum, sumsq of the fp16-rounded outputs)
+    // optional fused second stage (EP_RELU only): out2 = relu(W2 . relu(W . x + bias) + bias2), a 1x1 conv chained on
+    // the accumulator tile inside the same kernel (unet.py:12-13 / 37-38: Conv3x3+ReLU -> Conv1x1+ReLU).  `out` (the
+    // intermediate) is then written only if non-null; statistics are taken on out2.
+    const f16 *wpk2;       // chain-packed 1x1 weights (imk_launch_pack_conv mode 2)
+    const float *bias2;
+    f16 *out2;             // [B,H,W,cs_out2]
+    int cout2, cs_out2;
+    const f16 *dystat_z;   // EP_PLAIN / EP_MASK, optional: the output is a BatchNorm's output gradient dy; accumulate
+                           // (sum dy, sum dy*z) with z = this tensor [B,H,W,cs_out] into stats_partial
+    float *stats_partial;  // optional: [rows][2*cs] (EP_RELU: sum, sumsq of the fp16-rounded outputs)
     int *stats_rows;       // host, optional: receives the number of partial rows this launch writes
     int epi;
 };
@@ -43,7 +54,9 @@ int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream);
 
 struct ImkWgradArgs {
     ImkInput x;            // the conv's input, same modes as forward
-    const f16 *dA;         // [B,H,W,cs_out] gradient w.r.t. the conv's pre-activation output (loss-scaled)
+    const f16 *dA;         // [B,H,W,cs_out] gradient w.r.t. the conv's pre-activation output (loss-scaled) ...
+    const f16 *dA_z;       // ... or, if non-null: dA is the following BatchNorm's output gradient dy, dA_z its input z,
+    const float *dA_coef;  //     and the pre-activation gradient (A*dy + B*z + C)*[z > 0] is formed on load
     int B, H, W, ksize, cout, cs_out;
     float *partial;        // [n_split][n_pairs][taps+1][256] fp32 scratch
     int n_split;
@@ -56,7 +69,9 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int cin, int cout,
                               const float *inv_scale_ptr, float *dw, float *db, float *found_inf, hipStream_t stream);
 
-// weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand.
+// weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
+// "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
+bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed);
 int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream);
 

@@ -15,6 +15,7 @@ struct ImkLayer {
     // packed (fp16, MFMA fragment order) weights, byte offsets into the packed buffer
     int64_t pk_fwd, pk_bwd;      // conv only
     int64_t pk_bytes_fwd, pk_bytes_bwd;
+    int64_t pk_chain;            // 1x1 convs: chain operand (fused behind the preceding 3x3), else -1
     int64_t pk_scale;            // bn: fp32 scale[cpad], shift[cpad] for inference (folded moving stats)
 };
 

@@ -74,6 +74,8 @@ void build_layers(imk_unet_plan *p) {
             l.pk_bytes_bwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 1) * 2;
             l.pk_fwd = (int64_t)pk; pk = up(pk + l.pk_bytes_fwd);
             l.pk_bwd = (int64_t)pk; pk = up(pk + l.pk_bytes_bwd);
+            l.pk_chain = -1;
+            if (l.ksize == 1 && l.cin <= 16 && l.cout <= 16) { l.pk_chain = (int64_t)pk; pk = up(pk + 1024); }
         } else {
             l.pk_scale = (int64_t)pk; pk = up(pk + 2 * (size_t)imk_pad8(l.cout) * sizeof(float));
         }
@@ -93,6 +95,7 @@ struct LayerWs {
     size_t coef = 0;           // bn (train): [3][cs]
     size_t wg_partial = 0;     // conv (train): this layer's weight-gradient partials (+ stage-1 scratch)
     int n_stats_tiles = 0;
+    int n_bwd_rows = 0;        // bn (train): capacity of bwd_partial in rows
 };
 
 struct Ws {
@@ -169,7 +172,10 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
             w.L[i].stats_partial = take((size_t)w.L[i].n_stats_tiles * 2 * cs * sizeof(float));
             w.L[i].scale = take(2 * (size_t)cs * sizeof(float));
             w.L[i].save = take(2 * (size_t)cs * sizeof(float));
-            w.L[i].bwd_partial = take((size_t)imk_bn_prep_blocks(B, d.h, d.w, cs) * 2 * cs * sizeof(float));
+            w.L[i].n_bwd_rows = imk_bn_prep_blocks(B, d.h, d.w, cs);
+            const int conv_rows = B * imk_cdiv(d.h, 8) * imk_cdiv(d.w, 16);   // most rows a dgrad epilogue can write
+            if (conv_rows > w.L[i].n_bwd_rows) w.L[i].n_bwd_rows = conv_rows;
+            w.L[i].bwd_partial = take((size_t)w.L[i].n_bwd_rows * 2 * cs * sizeof(float));
             w.L[i].coef = take(3 * (size_t)cs * sizeof(float));
             w.L[i].dy = take(px * cs * 2);
         }
@@ -256,7 +262,11 @@ int bn_of_conv(const Topo &t, int conv) {  // the BN that directly follows a con
     return -1;
 }
 
-int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw) {
+bool g_materialize = false;   // imk_debug_materialize(1): inference also stores the intermediates of fused kernels
+
+// conv2 >= 0: fuse the 1x1 conv `conv2` (whose only input is conv's output) into the same kernel when possible.
+// Returns 1 in *fused if it did.
+int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw, int conv2 = -1, bool *fused = nullptr) {
     const ImkLayer &l = c.p->layers[conv];
     const Dim d = res_dim(c.p->cfg, l.res);
     ImkConvArgs a{};
@@ -267,7 +277,21 @@ int run_conv_fwd(Ctx &c, int conv, const uint8_t *x_u8, float *params_rw) {
     a.bias = c.params + l.off_b;
     a.out = c.act(conv);
     a.epi = EP_RELU;
-    const int bn = bn_of_conv(c.t, conv);
+    int stat_conv = conv;
+    if (fused) *fused = false;
+    if (conv2 >= 0) {
+        const ImkLayer &l2 = c.p->layers[conv2];
+        if (l2.pk_chain >= 0 && imk_conv_can_chain(a, l2.cout)) {
+            a.wpk2 = reinterpret_cast<const f16 *>(c.packed + l2.pk_chain);
+            a.bias2 = c.params + l2.off_b;
+            a.out2 = c.act(conv2);
+            a.cout2 = l2.cout; a.cs_out2 = imk_pad8(l2.cout);
+            if (!c.train && !g_materialize) a.out = nullptr;   // the intermediate never leaves the chip
+            stat_conv = conv2;
+            if (fused) *fused = true;
+        }
+    }
+    const int bn = bn_of_conv(c.t, stat_conv);
     int rows = 0;
     if (c.train && bn >= 0) {
         a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].stats_partial);
@@ -292,10 +316,14 @@ int run_forward(Ctx &c, const uint8_t *x, float *probs, float *params_rw) {
     const Topo &t = c.t;
     int rc;
 #define RUN(conv) do { rc = run_conv_fwd(c, (conv), x, params_rw); if (rc) return rc; } while (0)
+    // Conv3x3+ReLU -> Conv1x1+ReLU pairs run as one kernel where the channel counts allow it
+#define RUN_PAIR(c3, c1) do { bool f_ = false; rc = run_conv_fwd(c, (c3), x, params_rw, (c1), &f_); if (rc) return rc; \
+                              if (!f_) RUN(c1); } while (0)
     RUN(t.in_c);
-    for (int i = 0; i < 4; ++i) { RUN(t.e_c3[i]); RUN(t.e_c1[i]); }
-    RUN(t.b_c3); RUN(t.b_c1);
-    for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN(t.d_c3[j]); RUN(t.d_c1[j]); }
+    for (int i = 0; i < 4; ++i) RUN_PAIR(t.e_c3[i], t.e_c1[i]);
+    RUN_PAIR(t.b_c3, t.b_c1);
+    for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN_PAIR(t.d_c3[j], t.d_c1[j]); }
+#undef RUN_PAIR
 #undef RUN
     const ImkLayer &o = c.p->layers[t.out];
     const int bn = t.d_bnb[3];
@@ -357,6 +385,8 @@ extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer
     return IMK_OK;
 }
 
+extern "C" int imk_debug_materialize(int on) { g_materialize = on != 0; return IMK_OK; }
+
 extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return plan ? plan->packed_bytes : IMK_EINVAL; }
 
 extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream_) {
@@ -370,9 +400,11 @@ extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *par
     for (size_t i = 0; i < plan->layers.size(); ++i) {
         const ImkLayer &l = plan->layers[i];
         if (l.kind == 0) {
-            for (int tr = 0; tr < 2; ++tr) {
+            for (int tr = 0; tr < 3; ++tr) {
                 if (tr == 0 && (int)i == out_idx) continue;   // the head runs in fp32 from `params` directly
-                pj.j[pj.n++] = ImkPackJob{params + l.off_w, (f16 *)(pk + (tr ? l.pk_bwd : l.pk_fwd)), l.ksize, l.cin, l.cout, tr};
+                if (tr == 2 && (l.pk_chain < 0 || (int)i == out_idx)) continue;
+                f16 *dst = (f16 *)(pk + (tr == 2 ? l.pk_chain : (tr ? l.pk_bwd : l.pk_fwd)));
+                pj.j[pj.n++] = ImkPackJob{params + l.off_w, dst, l.ksize, l.cin, l.cout, tr};
                 if (pj.n == IMK_PACK_MAX_JOBS) { int rc = flush_pack(); if (rc) return rc; }
             }
         } else {
@@ -464,55 +496,98 @@ struct Bwd {
     float *grads;
     ImkCtl *ctl;
     hipStream_t side;       // weight-gradient work runs here (== c.stream if no side stream is available)
+    long long side_max_pixels;   // layers with at most this many pixels run their wgrad on the side stream
     ImkWgFinalJobs jobs{};
     int n_fork = 0;
+    bool used_side = false;
 
-    // dgrad of `conv`: input dA[conv] -> dst, optionally masked by the ReLU of the tensor `mask`
-    int dgrad(int conv, f16 *dst, const f16 *mask) {
+    int dy_rows[64] = {};   // per BN: statistics rows written by the kernel that produced dy (0 = none, run the prep pass)
+
+    // Where the pre-activation gradient of `conv` comes from: convs that feed a BatchNorm get it on load from that
+    // BN's (dy, z, coefficients); the 3x3 convs get the materialised, ReLU-masked dgrad output of the following 1x1.
+    void grad_input(int conv, ImkInput &in) const {
+        const ImkLayer &l = c.p->layers[conv];
+        in.cin = l.cout; in.cs_in = imk_pad8(l.cout);
+        const int bn = bn_of_conv(c.t, conv);
+        if (bn >= 0) {
+            in.in = c.dy(bn); in.in2 = c.act(conv); in.lmode = LM_BNBWD;
+            in.sc = reinterpret_cast<const float *>(c.base + c.ws.L[bn].coef);
+        } else {
+            in.in = c.dA(conv); in.lmode = LM_RAW;
+        }
+    }
+    // dgrad of `conv` -> dst, optionally masked by the ReLU of the tensor `mask`.  If dst is the output gradient of
+    // a BatchNorm whose only gradient source this is (stat_bn >= 0), the kernel also emits that BN's backward
+    // statistics (sum dy, sum dy*z), which saves the separate reduction pass.
+    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
         ImkConvArgs a{};
-        a.x.in = c.dA(conv); a.x.lmode = LM_RAW; a.x.cin = l.cout; a.x.cs_in = imk_pad8(l.cout);
+        grad_input(conv, a.x);
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
         a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
         a.wpk = c.wbwd(conv);
         a.out = dst;
         a.mask = mask;
         a.epi = mask ? EP_MASK : EP_PLAIN;
-        return imk_launch_conv(a, c.stream);
+        int rows = 0;
+        if (stat_bn >= 0) {
+            a.dystat_z = c.act(bn_producer(c.t, stat_bn));
+            a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[stat_bn].bwd_partial);
+            a.stats_rows = &rows;
+        }
+        int rc = imk_launch_conv(a, c.stream);
+        if (rc) return rc;
+        if (stat_bn >= 0) {
+            if (rows <= 0 || rows > c.ws.L[stat_bn].n_bwd_rows) return IMK_EWORKSPACE;
+            dy_rows[stat_bn] = rows;
+        }
+        return IMK_OK;
     }
     // Weight/bias gradient of `conv`: depends only on dA[conv] (just produced on the main stream) and on forward
     // tensors, and nothing downstream in the backward pass depends on it -> fork it onto the side stream.
     int wgrad(int conv, const f16 *dA_override = nullptr) {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
-        if (side != c.stream) {
+        // Deep (small-map) layers launch too few workgroups to fill the chip: only those are forked onto the side
+        // stream, where they overlap with the main chain; the wide layers stay in line (they would only contend).
+        const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
+        hipStream_t ws = (side != c.stream && small) ? side : c.stream;
+        if (ws != c.stream) {
             hipEvent_t ev = c.p->ev_fork[n_fork++];
             IMK_HIP(hipEventRecord(ev, c.stream));
             IMK_HIP(hipStreamWaitEvent(side, ev, 0));
+            used_side = true;
         }
         ImkWgradArgs a{};
         a.x = conv_input(c, conv, x);
-        a.dA = dA_override ? dA_override : c.dA(conv);
+        if (dA_override) {
+            a.dA = dA_override;
+        } else {
+            ImkInput gi{};
+            grad_input(conv, gi);
+            a.dA = reinterpret_cast<const f16 *>(gi.in);
+            if (gi.lmode == LM_BNBWD) { a.dA_z = reinterpret_cast<const f16 *>(gi.in2); a.dA_coef = gi.sc; }
+        }
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
         a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
         a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
-        int rc = imk_launch_wgrad(a, side);
+        int rc = imk_launch_wgrad(a, ws);
         if (rc) return rc;
         return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
     }
     // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
     int finish_wgrads() {
-        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, side);
-        if (rc) return rc;
-        if (side != c.stream) {
+        if (used_side) {   // join: the reductions below read the side stream's partials
             IMK_HIP(hipEventRecord(c.p->ev_join, side));
             IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join, 0));
         }
-        return IMK_OK;
+        return imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, c.stream);
     }
-    // BN backward for `bn` whose output gradient is dy[bn] (already assembled unless mode != 0), producing
-    // dA of the conv that feeds it.
+    // BN backward for `bn`: per-channel coefficients of  dz = A*dy + B*z + C  (+ gamma/beta gradients).  The
+    // reduction (sum dy, sum dy*z) comes from the kernel that produced dy when there was exactly one (dy_rows),
+    // else from a pass that also assembles dy from its sources (mode 1: skip gradient + max-pool scatter,
+    // mode 2: 2x2 sum of the upsampled branch).  The consumers apply the coefficients on load (LM_BNBWD).
     int bn_bwd(int bn, int mode, const f16 *g_direct, const f16 *g_other) {
         const ImkLayer &b = c.p->layers[bn];
         const Dim d = res_dim(c.p->cfg, b.res);
@@ -523,14 +598,15 @@ struct Bwd {
         float *coef = reinterpret_cast<float *>(c.base + lw.coef);
         const float *save = reinterpret_cast<const float *>(c.base + lw.save);
         const f16 *z = c.act(prod);
-        int rc = imk_launch_bn_bwd_prep(mode, mode == 0 ? c.dy(bn) : g_direct, g_other, z, c.bn_scale(bn), c.bn_shift(bn),
-                                        c.dy(bn), partial, c.B, d.h, d.w, cs, c.stream);
-        if (rc) return rc;
-        rc = imk_launch_bn_bwd_coef(partial, imk_bn_prep_blocks(c.B, d.h, d.w, cs), b.cout, cs, (double)c.B * d.h * d.w,
-                                    c.params + b.off_w, save, save + cs, &ctl->inv_loss_scale, coef, grads + b.off_w,
-                                    grads + b.off_b, &ctl->found_inf, c.stream);
-        if (rc) return rc;
-        return imk_launch_bn_bwd_apply(c.dy(bn), z, coef, cs, (long long)c.B * d.h * d.w, c.dA(prod), c.stream);
+        int rows = dy_rows[bn];
+        if (mode != 0 || rows == 0) {
+            int rc = imk_launch_bn_bwd_prep(mode, mode == 0 ? c.dy(bn) : g_direct, g_other, z, c.bn_scale(bn), c.bn_shift(bn),
+                                            c.dy(bn), partial, c.B, d.h, d.w, cs, c.stream);
+            if (rc) return rc;
+            rows = imk_bn_prep_blocks(c.B, d.h, d.w, cs);
+        }
+        return imk_launch_bn_bwd_coef(partial, rows, b.cout, cs, (double)c.B * d.h * d.w, c.params + b.off_w, save, save + cs,
+                                      &ctl->inv_loss_scale, coef, grads + b.off_w, grads + b.off_b, &ctl->found_inf, c.stream);
     }
 };
 }  // namespace
@@ -579,11 +655,11 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         ok = ok && hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) == hipSuccess;
         plan->side_ok = ok;
     });
-    // Measured (profiles/README.md): every kernel of the step is wide enough to fill the chip, so running the
-    // weight-gradient kernels concurrently on the side stream only adds contention and event waits
-    // (1.91 ms vs 1.76 ms per step).  Single stream by default; IMK_SIDE_STREAM=1 re-enables the fork/join.
-    static const bool use_side = []() { const char *e = getenv("IMK_SIDE_STREAM"); return e && e[0] == '1'; }();
-    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && use_side) ? plan->side : stream};
+    // Optional side stream for the deep, small-map layers (IMK_SIDE_PIXELS = largest B*H*W that is forked; default 0 =
+    // never: measured 1.54 ms per step with and without, so the simpler single-stream order is kept).
+    // Forking the wide layers too was measured slower (1.91 vs 1.76 ms per step): they fill the chip by themselves.
+    static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : 0LL; }();
+    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0) ? plan->side : stream, side_px};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
     {
@@ -592,7 +668,13 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         a.x.in = dlogit; a.x.lmode = LM_RAW; a.x.cin = l.cout; a.x.cs_in = imk_pad8(l.cout);
         a.B = batch; a.H = cf.h; a.W = cf.w; a.ksize = 1; a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
         a.wpk = c.wbwd(t.out); a.out = c.dy(t.d_bnb[3]); a.epi = EP_PLAIN;
+        int rows = 0;
+        a.dystat_z = c.act(t.d_c1[3]);
+        a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[t.d_bnb[3]].bwd_partial);
+        a.stats_rows = &rows;
         OK(imk_launch_conv(a, stream));
+        if (rows <= 0 || rows > c.ws.L[t.d_bnb[3]].n_bwd_rows) return IMK_EWORKSPACE;
+        b.dy_rows[t.d_bnb[3]] = rows;
     }
     // decoders 9..6
     for (int j = 3; j >= 0; --j) {
@@ -602,7 +684,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.wgrad(t.d_c1[j]));
         OK(b.dgrad(t.d_c1[j], c.dA(t.d_c3[j]), c.act(t.d_c3[j])));
         OK(b.wgrad(t.d_c3[j]));
-        OK(b.dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr));
+        OK(b.dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr, t.d_bna[j]));
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
         OK(b.wgrad(t.d_ca[j]));
         OK(b.dgrad(t.d_ca[j], dU, nullptr));
@@ -621,7 +703,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
         OK(b.wgrad(t.e_c3[i]));
         f16 *dst = i > 0 ? reinterpret_cast<f16 *>(c.base + c.ws.dP[i - 1]) : c.dy(t.in_bn);
-        OK(b.dgrad(t.e_c3[i], dst, nullptr));
+        OK(b.dgrad(t.e_c3[i], dst, nullptr, i > 0 ? -1 : t.in_bn));
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));

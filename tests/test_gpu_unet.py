@@ -79,7 +79,11 @@ def test_inference_parity(UNet, name):
     sd = randomize_bn(m.state_dict(), 2)
     m.load_state_dict(sd)
     x, _, _ = make_input(cfg)
+    from inconsistencymasks_amd._lib import lib
+    lib.imk_debug_materialize(1)            # keep the on-chip intermediates of fused kernels for the per-layer check
     probs = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    lib.imk_debug_materialize(0)
+    assert np.array_equal(probs, m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy())   # same result without
     taps = {}
     ref = U.forward(sd, x, cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], emulate_fp16=True, taps=taps).numpy()
     for l in m.plan.layers:
