@@ -1,4 +1,4 @@
-"""ISIC_2018 Inconsistency-Mask generations on MI355X: counterpart of the reference driver ISIC_2018/09_ISIC_2018_IM.py
+"""SUIM Inconsistency-Mask generations on MI355X: counterpart of the reference driver SUIM/10_SUIM_IM.py
 (same loops, file / model / CSV names); the loop body lives in inconsistencymasks_amd/im_driver.py."""
 import os
 import sys
@@ -8,4 +8,4 @@ sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inconsistencymasks_amd.im_driver import run  # noqa: E402
 
 if __name__ == "__main__":
-    run("ISIC_2018")
+    run("SUIM")

@@ -131,12 +131,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # IMK_BENCH_ONE_GPU=1 + IMK_BENCH_BACKEND=gloo: functional test of the multi-rank path on a single-GPU box
+    if os.environ.get("IMK_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("IMK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import ctypes
     from inconsistencymasks_amd import functions as F
@@ -188,6 +195,10 @@ def main():
         ty = torch.cat([(torch.cat(masks)[kidx] // 255)[..., None], y_lab])
         n_train = tx.shape[0]
         steps = n_train // BATCH
+        if world > 1:   # every rank must run the same number of gradient all-reduces: the smallest shard decides
+            st = torch.tensor([steps], device=dev)
+            dist.all_reduce(st, op=dist.ReduceOp.MIN)
+            steps = int(st.item())
         student.params.copy_(init_params)
         student._packed_ok = False
         student.init_train_state()

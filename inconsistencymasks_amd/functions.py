@@ -500,3 +500,319 @@ def train_ISIC_2018(train_images_dir, val_images_dir, val_masks_dir, test_images
                                             h, w, c, print_results=print_results)
     print(f"{modelname} mIoU_val: {mIoU_val}")
     return mIoU_val, mIoU_test, mIoU_unl, dice_val, dice_test, dice_unl
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-class training / evaluation (functions.py:275-316, 1265-1339, 51-102, 1791-1834)
+# ---------------------------------------------------------------------------------------------------
+def pixel_accuracy(pred_mask, gt_mask):
+    """functions.py:1820-1834."""
+    return np.sum(pred_mask == gt_mask) / np.prod(np.asarray(gt_mask).shape)
+
+
+def get_IoU_multi_unique(pred, gt):
+    """functions.py:1791-1816: mean IoU over the classes PRESENT in the ground truth."""
+    classes = np.unique(gt)
+    total = 0.0
+    for i in classes:
+        g, p = gt == i, pred == i
+        total += np.logical_and(g, p).sum() / (np.logical_or(g, p).sum() + 1e-7)
+    return total / len(classes)
+
+
+def convert_class_to_color_mask(class_mask, output_path, class_to_color_mapping):
+    """functions.py:6127-6149 (the mapping is colour -> class value; file written in RGB order on disk)."""
+    color = np.zeros(tuple(class_mask.shape) + (3,), dtype=np.uint8)
+    for col, cls in class_to_color_mapping.items():
+        color[class_mask == cls] = col
+    write_png(output_path, color)
+
+
+class MeanIoU:
+    """functions.py:51-102: running mean over batches of the per-class SOFT IoU between one-hot targets and
+    probabilities (the `val_mean_io_u` monitor of train_multiclass)."""
+
+    def __init__(self, num_classes):
+        self.num_classes = num_classes
+        self.reset_state()
+
+    def reset_state(self):
+        self.total, self.count = 0.0, 0.0
+
+    def update_state(self, y_true_ids, probs):
+        """y_true_ids [B,H,W] integer device tensor, probs [B,H,W,K] float device tensor."""
+        onehot = torch.nn.functional.one_hot(y_true_ids.long(), self.num_classes).to(probs.dtype)
+        inter = (onehot * probs).sum(dim=(0, 1, 2))
+        union = onehot.sum(dim=(0, 1, 2)) + probs.sum(dim=(0, 1, 2)) - inter
+        self.total += float((inter / union).mean())       # 0/0 -> nan propagates exactly like the reference
+        self.count += 1.0
+
+    def result(self):
+        return self.total / self.count
+
+
+def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_to_color_mapping, batch_size=64,
+                         create_images=True, print_results=True):
+    """functions.py:1265-1339: batch-64 predict, argmax, PNG dumps, per-image PA / IoU rounded to 4, means to 3."""
+    os.makedirs(pred_path, exist_ok=True)
+    names = os.listdir(image_path)
+    ious, pas = [], []
+    with _pool() as pool:
+        for i in range(0, len(names), batch_size):
+            chunk = names[i:i + batch_size]
+            imgs = list(pool.map(lambda n: read_png(os.path.join(image_path, n), c), chunk))
+            gts = list(pool.map(lambda n: read_png(os.path.join(gt_path, n), 1)[..., 0], chunk))
+            probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda())
+            pred = probs.argmax(-1).to(torch.uint8).cpu().numpy()
+            for j, n in enumerate(chunk):
+                if create_images:
+                    write_png(os.path.join(pred_path, n), pred[j])
+                    convert_class_to_color_mask(pred[j], os.path.join(pred_path, f"{n[:-4]}_color.png"), class_to_color_mapping)
+                pa = round(float(pixel_accuracy(pred[j], gts[j])), 4)
+                iou = round(float(get_IoU_multi_unique(pred[j], gts[j])), 4)
+                pas.append(pa); ious.append(iou)
+                if print_results:
+                    print(f"{n} IoU: {iou}    PA: {pa}")
+    mPA = round(float(np.sum(pas) / len(pas)), 3)
+    mIoU = round(float(np.sum(ious) / len(ious)), 3)
+    print(f"------------------------------------------------------------   mPA: {mPA}      mIoU: {mIoU}  "
+          "------------------------------------------------------------")
+    return mPA, mIoU
+
+
+def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_images_dir, test_masks_dir,
+                     unlabeled_images_dir, unlabeled_masks_dir, modelname, filepath_h5, model, loss_func, steps_per_epoch,
+                     h, w, c, n_classes, class_to_color_mapping, val_pred_dir, test_pred_dir, unlabeled_pred_dir,
+                     print_results=False):
+    """functions.py:275-316.  loss_func: anything (the SUIM / Cityscapes scripts pass CategoricalCrossentropy());
+    the fused loss kernel implements exactly that loss on class-id masks."""
+    files = shard_list(glob.glob(os.path.join(train_images_dir, "*.png")))
+    loader = _EpochLoader(files, lambda p: parse_image_multiclass(p, n_classes, c), BATCH_SIZE, SEED)
+    val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
+    best = {"miou": -1.0}
+
+    def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_mean_io_u', mode='max')
+        metric = MeanIoU(n_classes)
+        with _pool() as pool:
+            for i in range(0, len(val_files), BATCH_SIZE):
+                items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files[i:i + BATCH_SIZE]))
+                x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
+                y = torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda()
+                metric.update_state(y, model.predict_device(x))
+        v = metric.result()
+        if v > best["miou"]:
+            best["miou"] = v
+            if _rank_world()[0] == 0:
+                save_model(model, filepath_h5)
+
+    fit(model, loader, steps_per_epoch, NUM_EPOCHS, 1, on_epoch_end)
+    d = _dist()
+    if d:
+        d.barrier()
+    best_model = load_model(filepath_h5, custom_objects={"MeanIoU": MeanIoU})
+    mPA_val, mIoU_val = benchmark_multiclass(best_model, val_images_dir, val_masks_dir, val_pred_dir, h, w, c,
+                                             class_to_color_mapping, print_results=print_results)
+    mPA_test, mIoU_test = benchmark_multiclass(best_model, test_images_dir, test_masks_dir, test_pred_dir, h, w, c,
+                                               class_to_color_mapping, print_results=print_results)
+    mPA_unl, mIoU_unl = benchmark_multiclass(best_model, unlabeled_images_dir, unlabeled_masks_dir, unlabeled_pred_dir,
+                                             h, w, c, class_to_color_mapping, print_results=print_results)
+    print(f"{modelname} mIoU_val: {mIoU_val}")
+    return mPA_val, mPA_test, mPA_unl, mIoU_val, mIoU_test, mIoU_unl
+
+
+# ---------------------------------------------------------------------------------------------------
+# HeLa (functions.py:232-269, 980-1018, 1155-1260, 2895-2984, 6181-6371).  The position post-processing is
+# contour tracing + circle drawing in OpenCV in the reference; here scipy.ndimage connected components and an
+# explicit disc rasteriser stand in (host side, unpinned -- SURVEY 8a' marks this row so).
+# ---------------------------------------------------------------------------------------------------
+def _erode3(mask):
+    from scipy import ndimage
+    return ndimage.grey_erosion(mask, size=(3, 3), mode="constant", cval=255)
+
+
+def get_pos_contours(img, erode_kernel=3):
+    """functions.py:6181-6218: centres (x, y) of the blobs of a position mask (+1 offset like the reference)."""
+    from scipy import ndimage
+    a = np.asarray(img)
+    assert a.ndim in (2, 3), "Invalid image dimensions."
+    if a.ndim == 3:
+        a = a[..., 0] if a.shape[2] == 1 else (0.114 * a[..., 0] + 0.587 * a[..., 1] + 0.299 * a[..., 2]).astype(np.uint8)
+    if erode_kernel > 0:
+        a = ndimage.grey_erosion(a.astype(np.uint8), size=(erode_kernel, erode_kernel), mode="constant", cval=255)
+    lab, n = ndimage.label(a > 10, structure=np.ones((3, 3)))
+    pos = []
+    for cy, cx in ndimage.center_of_mass(a > 10, lab, range(1, n + 1)):
+        pos.append((int(cx) + 1, int(cy) + 1))
+    return pos
+
+
+def get_min_dist(xy, positions):
+    """functions.py:6221-6252."""
+    d = np.linalg.norm(np.array(positions) - np.array(xy), axis=1)
+    d = d[d > 0]
+    return 0 if d.size == 0 else float(np.min(d))
+
+
+def _disc(img, cx, cy, r, value):
+    h, w = img.shape[:2]
+    y0, y1, x0, x1 = max(cy - r, 0), min(cy + r, h - 1), max(cx - r, 0), min(cx + r, w - 1)
+    if y0 > y1 or x0 > x1:
+        return
+    yy, xx = np.mgrid[y0:y1 + 1, x0:x1 + 1]
+    img[y0:y1 + 1, x0:x1 + 1][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = value
+
+
+def mod_pos_size(gray_img, max_pos_circle_size=8, min_pos_circle_size=3):
+    """functions.py:6255-6292: redraw every position blob as a disc of radius clamp(min_dist // 4, 3, 8)."""
+    positions = get_pos_contours(gray_img)
+    out = np.zeros(gray_img.shape, np.uint8)
+    for p in positions:
+        r = int(get_min_dist(p, positions) // 4)
+        r = max(min(r, max_pos_circle_size), min_pos_circle_size)
+        _disc(out, p[0], p[1], r, 255)
+    return out
+
+
+def get_cell_count(positions, img_alive, img_dead, measuring_range=3):
+    """functions.py:6298-6371."""
+    a = (np.asarray(img_alive) > 10).astype(np.int64) * 255
+    dd = (np.asarray(img_dead) > 10).astype(np.int64) * 255
+    ih, iw = a.shape[:2]
+    alive = dead = unclear = 0
+    m = measuring_range
+    for x, y in positions:
+        if x - m <= 0:
+            x += m
+        if x + m > iw:
+            x = iw - m
+        if y - m < 0:
+            y += m
+        if y + m > ih:
+            y = ih - m
+        sa, sd = a[y - m:y + m, x - m:x + m].sum(), dd[y - m:y + m, x - m:x + m].sum()
+        alive += sa > sd
+        dead += sd > sa
+        unclear += sa == sd
+    return int(alive), int(dead), int(unclear)
+
+
+def parse_image_hela(path_brightfield, IMG_CHANNELS=1, Position_weight=3):
+    """functions.py:980-1018: targets alive/dead in {0,1}, position in {0, Position_weight}."""
+    bf = read_png(path_brightfield, IMG_CHANNELS)
+    chans = []
+    for name, wgt in (("alive", 1), ("dead", 1), ("mod_position", Position_weight)):
+        m = read_png(re.sub("brightfield", name, path_brightfield), 1)[..., 0]
+        chans.append(((m // 255) * wgt).astype(np.uint8))
+    return bf, np.stack(chans, -1)
+
+
+def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path, erode_kernel=5, dilate_kernel=5,
+                                 block_input=True, block_output=True, max_pos_circle_size=8, min_pos_circle_size=3):
+    """functions.py:2895-2984: three binary IMs (>=), combined IM = max; position mask re-drawn as discs on the host;
+    brightfield / alive / dead / mod_position / im written."""
+    if erode_kernel > 0:
+        raise NotImplementedError("dilate_mask of the alive/dead masks (erode_kernel > 0) is dead in the shipped configs")
+    out = {k: os.path.join(main_output_path, k) for k in ("brightfield", "alive", "dead", "mod_position", "im")}
+    for d in out.values():
+        os.makedirs(d, exist_ok=True)
+    mine = shard_list(os.listdir(images_path))
+    ens = EnsembleIM(models)
+    sum_im = count = 0
+    with _pool() as pool:
+        for i in range(0, len(mine), INFER_BATCH):
+            chunk = mine[i:i + INFER_BATCH]
+            imgs = list(pool.map(lambda n: read_png(os.path.join(images_path, n), c), chunk))
+            x = torch.from_numpy(np.stack(imgs, 0)).cuda()
+            r = ens.run(x, 0.5, True, False, False)          # blocking happens after the host-side position step
+            im = r["im"]
+            if dilate_kernel > 0:
+                im = _im.morph(im, dilate_kernel, "dilate")
+            masks_np, im_np = r["masks"].cpu().numpy(), im.cpu().numpy()
+            ims = r["im_size"].sum(1).cpu().numpy()
+            jobs = []
+            for j, name in enumerate(chunk):
+                sum_im += int(ims[j]); count += 1
+                pos = np.zeros((h, w, 3), np.uint8)
+                positions = get_pos_contours(masks_np[j, 2])
+                for p in positions:
+                    md = get_min_dist(p, positions) if len(positions) > 1 else 99
+                    rad = max(min(int(md // 4), max_pos_circle_size), min_pos_circle_size)
+                    _disc(pos, p[0], p[1], rad, (255, 255, 255))
+                bf, alive, dead = imgs[j][..., 0].copy(), masks_np[j, 0].copy(), masks_np[j, 1].copy()
+                hit = im_np[j] > 0
+                if block_input:
+                    bf[hit] = 0
+                if block_output:
+                    alive[hit] = 0; dead[hit] = 0; pos[hit] = 0
+                jobs += [(os.path.join(out["brightfield"], name), bf), (os.path.join(out["alive"], name), alive),
+                         (os.path.join(out["dead"], name), dead), (os.path.join(out["mod_position"], name), pos),
+                         (os.path.join(out["im"], name), im_np[j])]
+            list(pool.map(lambda a: write_png(*a), jobs))
+    tot_im, tot_n = _all_reduce_sum([sum_im, count])
+    return round(tot_im / tot_n, 0) if tot_n else 0.0
+
+
+def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_size=64, save_output=True, benchmark=True,
+                   mod_position=True):
+    """functions.py:1155-1260: returns (mIoU, mIoU_ad, mean_cell_count_error)."""
+    sub = "mod_position" if mod_position else "position"
+    for k in ("alive", "dead", sub):
+        os.makedirs(os.path.join(pred_dir, k), exist_ok=True)
+    names = os.listdir(os.path.join(gt_main_dir, "brightfield"))
+    mious, mious_ad, delta = [], [], 0
+    rd = lambda k, n: read_png(os.path.join(gt_main_dir, k, n), 1)[..., 0]
+    for i in range(0, len(names), batch_size):
+        chunk = names[i:i + batch_size]
+        x = torch.from_numpy(np.stack([read_png(os.path.join(gt_main_dir, "brightfield", n), c) for n in chunk], 0)).cuda()
+        probs = model.predict_device(x).cpu().numpy()
+        for j, n in enumerate(chunk):
+            a_u, d_u, p_u = [((probs[j, ..., k] > threshold) * 255).astype(np.uint8) for k in range(3)]
+            if mod_position:
+                p_u = mod_pos_size(p_u)
+            if benchmark:
+                ga, gd, gp = rd("alive", n), rd("dead", n), rd("mod_position", n)
+                ia, idd, ip = (round(float(get_IoU_binary(g, p)), 4) for g, p in ((ga, a_u), (gd, d_u), (gp, p_u)))
+                mious.append((ia + idd + ip) / 3); mious_ad.append((ia + idd) / 2)
+                pa, pd, _ = get_cell_count(get_pos_contours(p_u), a_u, d_u)
+                qa, qd, _ = get_cell_count(get_pos_contours(gp), ga, gd)
+                delta += abs(pa - qa) + abs(pd - qd)
+            if save_output:
+                write_png(os.path.join(pred_dir, "alive", n), a_u)
+                write_png(os.path.join(pred_dir, "dead", n), d_u)
+                write_png(os.path.join(pred_dir, sub, n), p_u)
+    return (round(float(np.sum(mious) / len(mious)), 3), round(float(np.sum(mious_ad) / len(mious_ad)), 3),
+            round(delta / len(mious), 3))
+
+
+def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabeled_gt_dir, modelname, filepath_h5, model,
+               loss_func, steps_per_epoch, h, w, c, val_pred_dir, test_pred_dir, unlabeled_pred_dir):
+    """functions.py:232-269: 'mse' on (alive, dead, 3 x position) targets, best epoch by val_loss (min)."""
+    if loss_func != "mse":
+        raise NotImplementedError("the HeLa scripts train with 'mse'")
+    files = shard_list(glob.glob(os.path.join(train_images_dir, "*.png")))
+    loader = _EpochLoader(files, lambda p: parse_image_hela(p, c), BATCH_SIZE, SEED)
+    val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
+    best = {"loss": float("inf")}
+
+    def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_loss', mode='min')
+        tot, n = 0.0, 0
+        for i in range(0, len(val_files), BATCH_SIZE):
+            items = [parse_image_hela(p, c) for p in val_files[i:i + BATCH_SIZE]]
+            x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
+            y = torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda().float()
+            tot += float(((model.predict_device(x) - y) ** 2).mean()); n += 1
+        if tot / max(n, 1) < best["loss"]:
+            best["loss"] = tot / max(n, 1)
+            if _rank_world()[0] == 0:
+                save_model(model, filepath_h5)
+
+    fit(model, loader, steps_per_epoch, NUM_EPOCHS, 0, on_epoch_end)
+    d = _dist()
+    if d:
+        d.barrier()
+    best_model = load_model(filepath_h5)
+    res = []
+    for gt, pd in ((val_gt_dir, val_pred_dir), (test_gt_dir, test_pred_dir), (unlabeled_gt_dir, unlabeled_pred_dir)):
+        res += list(benchmark_hela(best_model, gt, pd, h, w, c))
+    print(f"{modelname} mIoU_val: {res[0]}   mean_cell_count_error_val: {res[2]}")
+    return tuple(res)

@@ -1,0 +1,141 @@
+"""Generation loop of the per-dataset `*_IM.py` drivers of the reference (ISIC_2018/09_ISIC_2018_IM.py:47-153 and its
+siblings HeLa/09_HeLa_IM.py, SUIM/10_SUIM_IM.py, Cityscapes/09_Cityscapes_IM.py, which are copies of one template).
+Same loops, model / directory / CSV names and top-K hand-off; launch under torch.distributed.run for multi-GPU.
+Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES (comma-separated)."""
+import csv
+import os
+import shutil
+
+import torch
+
+from . import functions as F
+from . import paths
+from .unet import get_unet
+
+DATASETS = {
+    # prefix in paths/config, kind, CSV header, index of the ranking metric in the row (after the model name)
+    "ISIC_2018": dict(section="ISIC_2018", kind="isic", rank=1,
+                      header=["modelname", "mIoU_val", "mIoU_test", "mIoU_train_unlabeled", "dice_score_val",
+                              "dice_score_test", "dice_score_train_unlabeled"]),
+    "SUIM": dict(section="SUIM", kind="multi", rank=4,
+                 header=["modelname", "mPA_val", "mPA_test", "mPA_train_unlabeled", "mIoU_val", "mIoU_test",
+                         "mIoU_train_unlabeled"]),
+    "Cityscapes": dict(section="CITYSCAPES", kind="multi", rank=4,
+                       header=["modelname", "mPA_val", "mPA_test", "mPA_train_unlabeled", "mIoU_val", "mIoU_test",
+                               "mIoU_train_unlabeled"]),
+    # the reference ranks HeLa candidates by tuple index 4, which is mIoU_test (HeLa/09_HeLa_IM.py:130): kept
+    "HeLa": dict(section="HELA", kind="hela", rank=4,
+                 header=["modelname", "mIoU_val", "mIoU_ad_val", "mean_cell_count_error_val", "mIoU_test", "mIoU_ad_test",
+                         "mean_cell_count_error_test", "mIoU_unlabeled", "mIoU_ad_unlabeled",
+                         "mean_cell_count_error_unlabeled"]),
+}
+
+
+def default_color_mapping(n_classes):
+    """colour -> class id, deterministic palette (the reference's per-dataset colour tables are cosmetic)."""
+    return {((37 * k) % 256, (91 * k) % 256, (173 * k) % 256): k for k in range(n_classes)}
+
+
+def _ints(name, default):
+    v = os.environ.get(name)
+    return [int(x) for x in v.split(",")] if v else default
+
+
+def run(dataset, approach="IM"):
+    ds = DATASETS[dataset]
+    S = F.config[ds["section"]]
+    H, W, C = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"])
+    K, alpha = int(S["NUM_CLASSES"]), float(S["ALPHA"])
+    actifu, actifu_out = S["ACTIFU"], S["ACTIFU_OUTPUT"]
+    batch, top_k = int(F.config["DEFAULT"]["BATCH_SIZE"]), int(F.config["DEFAULT"]["TOP_Ks"])
+    EK, DK = int(S["ERODE_KERNEL"]), int(S["DILATE_KERNEL"])
+    if ds["kind"] == "isic":     # :38-39 -- bool(str) is always True in the reference's ISIC script; kept
+        BI, BO = bool(S["BLOCK_INPUT"]), bool(S["BLOCK_OUTPUT"])
+    else:
+        BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
+    filt = S.get("FILTER_INCONSISTENT_CLASS_PRED", "false").lower() == "true"
+    P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
+    base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        torch.distributed.init_process_group("nccl")
+    rank, world = F._rank_world()
+    tag = dataset if dataset != "ISIC_2018" else "ISIC_2018"
+
+    for runid in _ints("IM_RUNIDS", [1, 2, 3]):
+        for n in _ints("IM_NS", [2, 3, 4]):
+            for gen in _ints("IM_GENS", [0, 1, 2, 3, 4]):
+                name_of = lambda g: f"{tag}_{approach}_{runid}_n{n}_gen{g}_e{EK}_d{DK}_bi_{BI}_bo_{BO}" + \
+                    ("_filtered" if (filt and ds["kind"] == "multi") else "")
+                modelname = name_of(gen)
+                out = {k: os.path.join(base, f"{k}_predictions", approach, modelname) for k in ("val", "test", "train_unlabeled")}
+                if gen == 0:
+                    files = [os.path.join(model_dir, f"{tag}_subset_{runid}_topK_{j}.h5") for j in range(1, n + 1)]
+                else:
+                    files = [os.path.join(model_dir, f"{name_of(gen - 1)}_topK_{j}.h5") for j in range(1, n + 1)]
+                best_models = [F.load_model(f) for f in files]
+
+                means = []
+                for split, key in (("VAL", "val"), ("TEST", "test"), ("TRAIN_UNLABELED", "train_unlabeled")):
+                    if ds["kind"] == "isic":
+                        means.append(F.create_pseudo_labels_im_ISIC_2018(best_models, H, W, C, P(f"{split}_IMAGES_DIR"), out[key],
+                                                                         True, EK, DK, BI, BO, True))
+                    elif ds["kind"] == "multi":
+                        means.append(F.create_pseudo_labels_im_multiclass(best_models, H, W, C, P(f"{split}_IMAGES_DIR"), out[key],
+                                                                          True, EK, DK, BI, BO, filt))
+                    else:
+                        means.append(F.create_pseudo_labels_im_hela(best_models, H, W, C, os.path.join(P(f"{split}_DIR"), "brightfield"),
+                                                                    out[key], EK, DK, BI, BO))
+                unl = out["train_unlabeled"]
+                if rank == 0:    # labelled pairs join the pseudo-labelled directory
+                    if ds["kind"] == "hela":
+                        for sub in ("brightfield", "alive", "dead", "mod_position"):
+                            src = os.path.join(P("TRAIN_LABELED_DIR"), sub)
+                            for name in os.listdir(src):
+                                shutil.copy(os.path.join(src, name), os.path.join(unl, sub, name))
+                    else:
+                        for name in os.listdir(P("TRAIN_LABELED_IMAGES_DIR")):
+                            shutil.copy(os.path.join(P("TRAIN_LABELED_IMAGES_DIR"), name), os.path.join(unl, "images", name))
+                            shutil.copy(os.path.join(P("TRAIN_LABELED_MASKS_DIR"), name), os.path.join(unl, "masks", name))
+                if torch.distributed.is_initialized():
+                    torch.distributed.barrier()
+                train_dir = os.path.join(unl, "brightfield" if ds["kind"] == "hela" else "images")
+                steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+
+                rows = []
+                for i in _ints("IM_CANDIDATES", [0, 1, 2, 3, 4]):
+                    name_i = f"{modelname}_{i}"
+                    h5 = os.path.join(model_dir, name_i + ".h5")
+                    preds = [os.path.join(base, f"{k}_predictions", approach, name_i) for k in ("val", "test", "train_unlabeled")]
+                    model = get_unet(H, W, C, K, alpha, actifu, actifu_out, seed=1000 * runid + 100 * gen + i)
+                    if ds["kind"] == "isic":
+                        res = F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
+                                                P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
+                                                name_i, h5, model, "mse", steps, H, W, C, *preds)
+                    elif ds["kind"] == "multi":
+                        res = F.train_multiclass(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
+                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
+                                                 name_i, h5, model, "categorical_crossentropy", steps, H, W, C, K,
+                                                 default_color_mapping(K), *preds)
+                    else:
+                        res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
+                                           P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
+                    rows.append((name_i,) + tuple(res))
+                    del model
+
+                if rank == 0:
+                    top = sorted(rows, key=lambda r: r[ds["rank"]], reverse=True)[:top_k]
+                    print(top)
+                    for i, row in enumerate(top, start=1):
+                        os.rename(os.path.join(model_dir, f"{row[0]}.h5"), os.path.join(model_dir, f"{row[0][:-2]}_topK_{i}.h5"))
+                    os.makedirs(csv_dir, exist_ok=True)
+                    with open(os.path.join(csv_dir, f"results_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
+                        wr = csv.writer(f, delimiter=";")
+                        wr.writerow(ds["header"])
+                        wr.writerows(rows)
+                    with open(os.path.join(csv_dir, f"mean_im_size_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
+                        wr = csv.writer(f, delimiter=";")
+                        wr.writerow(["val_mean_im_size", "test_mean_im_size", "unlabeled_mean_im_size"])
+                        wr.writerow(means)
+                if torch.distributed.is_initialized():
+                    torch.distributed.barrier()

@@ -17,6 +17,7 @@ def _dataset(prefix, section):
         d = os.path.join(base, split.lower())
         g[f"{prefix}_{split}_IMAGES_DIR"] = os.path.join(d, "images")
         g[f"{prefix}_{split}_MASKS_DIR"] = os.path.join(d, "masks")
+        g[f"{prefix}_{split}_DIR"] = d
     g[f"{prefix}_MODEL_DIR"] = os.path.join(base, "models")
     g[f"{prefix}_CSV_DIR"] = os.path.join(base, "csv")
 
@@ -24,3 +25,4 @@ def _dataset(prefix, section):
 _dataset("ISIC_2018", "ISIC_2018")
 _dataset("SUIM", "SUIM")
 _dataset("CITYSCAPES", "CITYSCAPES")
+_dataset("HELA", "HELA")

@@ -352,6 +352,20 @@ def gen_metrics(F):
             out[k + "_iou"] = np.array([F.get_IoU_binary(gt, pr)], np.float64)
             out[k + "_dice"] = np.array([F.dice_score_numpy_binary(gt, pr)], np.float64)
             cases.append(k)
+    # multi-class helpers (functions.py:1791-1834) and the HeLa distance helper (functions.py:6221-6252)
+    mc = []
+    for i, K in enumerate((3, 9, 35)):
+        gt = rng.integers(0, K, (24, 40)).astype(np.uint8)
+        pr = np.where(rng.random((24, 40)) > 0.3, gt, rng.integers(0, K, (24, 40))).astype(np.uint8)
+        k = f"m{i}"
+        out[k + "_gt"], out[k + "_pr"] = gt, pr
+        out[k + "_iou"] = np.array([F.get_IoU_multi_unique(pr, gt)], np.float64)
+        out[k + "_pa"] = np.array([F.pixel_accuracy(pr, gt)], np.float64)
+        mc.append(k)
+    out["mc_cases"] = np.array(mc)
+    pts = rng.integers(0, 256, (12, 2))
+    out["dist_pts"] = pts
+    out["dist_min"] = np.array([F.get_min_dist(tuple(p), [tuple(q) for q in pts]) for p in pts], np.float64)
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
     print("metrics:", len(cases), "cases")

@@ -106,6 +106,38 @@ def test_metric_helpers_golden(golden_dir):
         assert F.dice_score_numpy_binary(g[k + "_gt"], g[k + "_pr"]) == pytest.approx(float(g[k + "_dice"][0]), abs=1e-7)
 
 
+def test_multiclass_and_hela_helpers_golden(golden_dir):
+    from inconsistencymasks_amd import functions as F
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for k in g["mc_cases"]:
+        assert F.get_IoU_multi_unique(g[k + "_pr"], g[k + "_gt"]) == pytest.approx(float(g[k + "_iou"][0]), abs=1e-12)
+        assert F.pixel_accuracy(g[k + "_pr"], g[k + "_gt"]) == pytest.approx(float(g[k + "_pa"][0]), abs=1e-12)
+    pts = [tuple(int(v) for v in p) for p in g["dist_pts"]]
+    for p, d in zip(pts, g["dist_min"]):
+        assert F.get_min_dist(p, pts) == pytest.approx(float(d), abs=1e-9)
+
+
+def test_hela_position_postprocessing_properties():
+    """The contour/circle step is unpinned (needs OpenCV in the reference): property checks only."""
+    from inconsistencymasks_amd import functions as F
+    m = np.zeros((96, 96), np.uint8)
+    centres = [(20, 20), (60, 30), (40, 70), (80, 80)]
+    yy, xx = np.mgrid[0:96, 0:96]
+    for cx, cy in centres:
+        m[(yy - cy) ** 2 + (xx - cx) ** 2 <= 16] = 255
+    pos = F.get_pos_contours(m)
+    assert len(pos) == len(centres)
+    for (px, py) in pos:
+        assert min(abs(px - 1 - cx) + abs(py - 1 - cy) for cx, cy in centres) <= 1      # centre (+1 offset of the reference)
+    out = F.mod_pos_size(m)
+    assert len(F.get_pos_contours(out)) == len(centres)                                  # one disc per blob
+    from scipy import ndimage
+    lab, n = ndimage.label(out > 0)
+    areas = ndimage.sum(out > 0, lab, range(1, n + 1))
+    assert all(np.pi * 2.5 ** 2 <= a <= np.pi * 8.6 ** 2 for a in areas)                # radius clamped to [3, 8]
+    assert F.get_cell_count(pos, m, np.zeros_like(m)) == (4, 0, 0)
+
+
 def test_parse_mask_rule(tmp_path):
     """functions.py:975: uint8(mask/255) keeps only 255."""
     from inconsistencymasks_amd import functions as F

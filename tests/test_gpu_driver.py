@@ -1,0 +1,100 @@
+"""End-to-end run of the ISIC IM driver on a toy dataset (1 run id, n = 2, generations 0 and 1, 2 candidates):
+the file/model/CSV naming and the top-K hand-off of ISIC_2018/09_ISIC_2018_IM.py:59-153."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONFIG = """[DEFAULT]
+SEED = 42
+NUM_EPOCHS = 2
+BATCH_SIZE = 8
+LR = 0.003
+WD = 1e-4
+THRESHOLD = 0.5
+TOP_Ks = 2
+
+[ISIC_2018]
+IMAGE_HEIGHT = 64
+IMAGE_WIDTH = 64
+IMAGE_CHANNELS = 3
+NUM_CLASSES = 1
+BASE_DIR = {base}/
+ALPHA = 0.5
+ACTIFU = relu
+ACTIFU_OUTPUT = sigmoid
+ERODE_KERNEL = 0
+DILATE_KERNEL = 0
+BLOCK_INPUT = True
+BLOCK_OUTPUT = True
+"""
+
+SETUP = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd import functions as F, paths
+from inconsistencymasks_amd.unet import get_unet
+rng = np.random.default_rng(0)
+def sample(n, d_img, d_mask):
+    os.makedirs(d_img, exist_ok=True); os.makedirs(d_mask, exist_ok=True)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in range(n):
+        cy, cx, r = rng.integers(20, 44), rng.integers(20, 44), rng.integers(8, 18)
+        ell = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        img = (170 + rng.integers(-10, 10, (64, 64, 3)) - ell[..., None] * 90).clip(0, 255).astype(np.uint8)
+        F.write_png(os.path.join(d_img, f"ISIC_{{i:05d}}.png"), img)
+        F.write_png(os.path.join(d_mask, f"ISIC_{{i:05d}}.png"), (ell * 255).astype(np.uint8))
+sample(16, paths.ISIC_2018_TRAIN_LABELED_IMAGES_DIR, paths.ISIC_2018_TRAIN_LABELED_MASKS_DIR)
+sample(24, paths.ISIC_2018_TRAIN_UNLABELED_IMAGES_DIR, paths.ISIC_2018_TRAIN_UNLABELED_MASKS_DIR)
+sample(8, paths.ISIC_2018_VAL_IMAGES_DIR, paths.ISIC_2018_VAL_MASKS_DIR)
+sample(8, paths.ISIC_2018_TEST_IMAGES_DIR, paths.ISIC_2018_TEST_MASKS_DIR)
+os.makedirs(paths.ISIC_2018_MODEL_DIR, exist_ok=True)
+import torch
+x = torch.from_numpy(np.stack([F.read_png(os.path.join(paths.ISIC_2018_TRAIN_LABELED_IMAGES_DIR, n), 3) for n in sorted(os.listdir(paths.ISIC_2018_TRAIN_LABELED_IMAGES_DIR))])).cuda()
+y = torch.from_numpy(np.stack([F.read_png(os.path.join(paths.ISIC_2018_TRAIN_LABELED_MASKS_DIR, n), 1) // 255 for n in sorted(os.listdir(paths.ISIC_2018_TRAIN_LABELED_MASKS_DIR))])).cuda()
+for j in (1, 2):      # the gen-0 ensemble (03_ISIC_2018_subset.py's product), trained long enough for the BN statistics
+    m = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", seed=j)
+    for it in range(700):
+        m.train_step(x, y, 0, 3e-3 if it < 200 else 0.0, 1e-4 if it < 200 else 0.0)
+    m.repack()
+    F.save_model(m, os.path.join(paths.ISIC_2018_MODEL_DIR, f"ISIC_2018_subset_1_topK_{{j}}.h5"))
+"""
+
+
+def test_isic_driver_toy_run(tmp_path):
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CONFIG.format(base=base))
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0,1", "IM_CANDIDATES": "0,1"}
+    subprocess.run([sys.executable, "-c", SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "09_ISIC_2018_IM.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    models = sorted(os.listdir(base / "models"))
+    csvs = sorted(os.listdir(base / "csv"))
+    stem = "ISIC_2018_IM_1_n2_gen{g}_e0_d0_bi_True_bo_True"
+    expect_models = ["ISIC_2018_subset_1_topK_1.h5", "ISIC_2018_subset_1_topK_2.h5"]
+    for g in (0, 1):          # both candidates survive (TOP_Ks = 2) and are renamed _topK_1 / _topK_2
+        expect_models += [stem.format(g=g) + f"_topK_{i}.h5" for i in (1, 2)]
+    assert models == sorted(expect_models)
+    assert csvs == sorted([f"{k}_{stem.format(g=g)}.csv" for g in (0, 1) for k in ("results", "mean_im_size")])
+    rows = (base / "csv" / f"results_{stem.format(g=1)}.csv").read_text().strip().splitlines()
+    assert rows[0] == "modelname;mIoU_val;mIoU_test;mIoU_train_unlabeled;dice_score_val;dice_score_test;dice_score_train_unlabeled"
+    assert len(rows) == 3 and rows[1].startswith(stem.format(g=1) + "_0;")
+    im_rows = (base / "csv" / f"mean_im_size_{stem.format(g=0)}.csv").read_text().strip().splitlines()
+    assert im_rows[0] == "val_mean_im_size;test_mean_im_size;unlabeled_mean_im_size" and len(im_rows[1].split(";")) == 3
+    # pseudo-label directory: im/ for every unlabeled image, images/ + masks/ for kept + copied labelled ones
+    unl = base / "train_unlabeled_predictions" / "IM" / stem.format(g=0)
+    assert len(os.listdir(unl / "im")) == 24
+    n_img = len(os.listdir(unl / "images"))
+    assert 16 <= n_img <= 40 and n_img == len(os.listdir(unl / "masks"))
+    miou_val = float(rows[1].split(";")[1])
+    assert 0.0 <= miou_val <= 1.0
