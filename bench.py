@@ -151,6 +151,15 @@ def main():
     from inconsistencymasks_amd._lib import lib as imk_lib
     from inconsistencymasks_amd.unet import UNet
 
+    NV = 7
+    def prof_collect():
+        pc = (ctypes.c_int64 * NV)(); pms = (ctypes.c_double * NV)(); pby = (ctypes.c_double * NV)()
+        imk_lib.imk_prof_collect(pc, pms, pby)
+        return [int(v) for v in pc], [float(v) for v in pms], [float(v) for v in pby]
+    # HIP events (on the launch stream) around every k-th conv launch, from process start: the setup phase is
+    # collected separately so that the whole-process average can be compared with `rocprofv3 --stats` of this command
+    imk_lib.imk_prof_enable(0 if args.no_prof else args.prof_period)
+
     # ---- synthetic, HBM-resident inputs (per rank: a full-size shard -> weak scaling) -----------------
     U = args.images
     x_unl, _ = synth_images(U, 42 + 1000 * rank, dev)
@@ -223,19 +232,17 @@ def main():
     for _ in range(args.warmup):
         generation()
     barrier()
+    setup_prof = prof_collect()
     rec = []
     t0 = time.perf_counter()
-    # HIP events (on the launch stream) around every 5th conv launch of the timed region: sampling keeps the cost of
-    # the event records (~10 % of a training step if every launch is bracketed) near 2 %.  5 is coprime to the 39
-    # conv launches of a training step and the 17 of a forward, so every layer is sampled equally often.
-    imk_lib.imk_prof_enable(0 if args.no_prof else args.prof_period)
+    # Sampling (every 5th launch) keeps the cost of the event records (~10 % of a training step if every launch is
+    # bracketed) near 2 %; 5 is coprime to the 39 conv launches of a training step and the 17 of a forward.
     for k in range(args.steps):
         generation(rec)
     barrier()
     elapsed = time.perf_counter() - t0
+    pc, pms, pby = prof_collect()
     imk_lib.imk_prof_enable(0)
-    pc = (ctypes.c_int64 * 7)(); pms = (ctypes.c_double * 7)(); pby = (ctypes.c_double * 7)()
-    imk_lib.imk_prof_collect(pc, pms, pby)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,8 +257,23 @@ def main():
     conv_all = {names[i]: {"launches": int(pc[i]), "ms": round(pms[i], 3),
                            "GBps": round(pby[i] / pms[i] / 1e6, 1) if pms[i] else None} for i in range(7) if pc[i]}
     achieved = pby[v] / pms[v] / 1e6 if pms[v] else 0.0      # bytes / ms / 1e6 = GB/s
+    # HBM traffic per launch from the PMC passes of profiles/collect.sh (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+    traffic = None
+    try:
+        import csv
+        fam = names[v].split("<")[0]
+        rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.csv"))) if r["kernel"].startswith(fam)]
+        nl = sum(int(r["launches"]) for r in rows)
+        if nl:
+            traffic = round(1e6 * sum(int(r["launches"]) * float(r["hbm_MB_per_launch_corrected(2*fetch+write)"]) for r in rows) / nl)
+    except Exception:
+        pass
+    whole_n = setup_prof[0][v] + pc[v]
+    whole_ms = setup_prof[1][v] + pms[v]
     roofline = {"bound": "hbm", "kernel": names[v], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, launch-weighted mean)",
+                "avg_us_per_launch_whole_process": round(1000 * whole_ms / max(whole_n, 1), 2),
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
                 "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
                 "share_of_step_time": round(pms[v] * args.prof_period / (1000 * elapsed), 3), "sampling": f"every {args.prof_period}th conv launch of the timed region",

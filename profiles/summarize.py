@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into small summaries (run on the GPU box by profiles/collect.sh; the raw
+per-dispatch CSVs are tens of MB and are deleted afterwards).
+  kernel_stats.csv      : per kernel (template arguments kept): calls, total ms, average us, share
+  pmc_traffic.csv       : per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch as reported (KB -> MB), and the
+                          gfx950-corrected HBM bytes per launch (FETCH x 2 for wide coalesced reads + WRITE;
+                          MI355X_MICROARCH.md, section HBM)
+"""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-zA-Z_0-9]+?)(I|E)", n)
+    if m:
+        return m.group(1)
+    return n.split("(")[0][:48]
+
+
+def main(out):
+    stats = glob.glob(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(stats[0])):
+            k = short(r["Name"])
+            agg[k][0] += int(r["Calls"])
+            agg[k][1] += float(r["TotalDurationNs"])
+        tot = sum(v[1] for v in agg.values())
+        with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                w.writerow([k, v[0], round(v[1] / 1e6, 3), round(v[1] / v[0] / 1e3, 3), round(100 * v[1] / tot, 2)])
+    tr = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(out, f"pmc_{cname}", "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        for r in csv.DictReader(open(files[0])):
+            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
+            d = tr.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n_FETCH_SIZE": 0, "n_WRITE_SIZE": 0})
+            d[cname] += float(r["Counter_Value"])
+            d["n_" + cname] += 1
+    if tr:
+        with open(os.path.join(out, "pmc_traffic.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "workgroups", "launches", "fetch_MB_per_launch_raw", "write_MB_per_launch",
+                        "hbm_MB_per_launch_corrected(2*fetch+write)"])
+            for k, d in sorted(tr.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
+                nf, nw = max(d["n_FETCH_SIZE"], 1), max(d["n_WRITE_SIZE"], 1)
+                fe, wr = d["FETCH_SIZE"] / nf / 1024, d["WRITE_SIZE"] / nw / 1024      # counters are in KB
+                w.writerow([k[0], k[1], nf, round(fe, 3), round(wr, 3), round(2 * fe + wr, 3)])
+    for big in glob.glob(os.path.join(out, "*", "*", "*_kernel_trace.csv")) + \
+            glob.glob(os.path.join(out, "*", "*", "*_counter_collection.csv")):
+        os.remove(big)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
