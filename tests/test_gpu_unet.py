@@ -258,3 +258,36 @@ def test_ensemble_forward_im_matches_unfused(UNet):
                 assert np.array_equal(r["presence"][:, i].cpu().numpy(), e["presence"])
             assert np.array_equal(r["im"][i].cpu().numpy(), e["im"])
             assert np.array_equal(r["img_out"][i].cpu().numpy(), eimg)
+
+
+BASELINE_SHAPES = {   # BASELINE.json configs at their real sizes (config.ini:18-26, 39-48, 61-69, 82-91 of the reference)
+    "isic_256": dict(h=256, w=256, c=3, k=1, alpha=0.5, act="sigmoid", loss="mse", b=2),
+    "hela_256": dict(h=256, w=256, c=1, k=3, alpha=1.0, act="sigmoid", loss="mse", b=2),
+    "suim_256": dict(h=256, w=256, c=3, k=9, alpha=1.0, act="softmax", loss="cce", b=2),
+    "cityscapes_208x416": dict(h=208, w=416, c=3, k=35, alpha=1.0, act="softmax", loss="cce", b=2),
+}
+
+
+@pytest.mark.parametrize("name", list(BASELINE_SHAPES))
+def test_baseline_shapes_full_size(UNet, name):
+    """Forward parity at the real sizes of the four datasets + one finite training step."""
+    cfg = BASELINE_SHAPES[name]
+    c, k, alpha, act = cfg["c"], cfg["k"], cfg["alpha"], cfg["act"]
+    m = UNet(cfg["h"], cfg["w"], c, k, alpha, act, seed=61)
+    sd = randomize_bn(m.state_dict(), 62)
+    m.load_state_dict(sd)
+    x, y, _ = make_input(cfg, 63)
+    xd = torch.from_numpy(x).cuda()
+    probs = m.predict_device(xd).cpu().numpy()
+    ref = U.forward(sd, x, c, k, alpha, act, emulate_fp16=True).numpy()
+    assert rel_l2(probs, ref) <= 1e-2
+    flips = ((probs.argmax(-1) != ref.argmax(-1)) if act == "softmax" else ((probs > 0.5) != (ref > 0.5))).mean()
+    assert flips <= 0.01, f"decision flip rate {flips}"
+    before = m.params.clone()
+    for _ in range(6):       # the dynamic loss scale may need a few halvings at these sizes
+        m.train_step(xd, torch.from_numpy(y).cuda(), 0 if cfg["loss"] == "mse" else 1, 3e-3, 1e-4)
+        if float(m.stats[1]) == 0.0:
+            break
+    st = m.stats.cpu().numpy()
+    assert st[1] == 0.0 and np.isfinite(st[0]), st
+    assert not torch.equal(before, m.params) and bool(torch.isfinite(m.params).all())
