@@ -41,6 +41,14 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles
     return c;
 }
 
+// chunks (of 8 channels) per K pass: everything in one pass up to 256 channels, else equal passes of <= 32 chunks
+__host__ __device__ inline int imk_cdiv_d(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int imk_pass_chunks(int nc8) {
+    if (nc8 <= 32) return nc8;
+    const int n_pass = imk_cdiv_d(nc8, 32);
+    return imk_cdiv_d(nc8, n_pass);
+}
+
 // n / d for n < 2^23 via a float reciprocal (exact after one correction step): ~6 VALU ops instead of ~35
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float inv_d) {
     unsigned q = (unsigned)((float)n * inv_d);
@@ -141,64 +149,29 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
 // =====================================================================================================
 // forward / dgrad
 // =====================================================================================================
+// Channel passes: layers with more than 256 input channels (alpha > 1 bottleneck, IM+ at alpha = 2) do not fit one LDS
+// tile; their K dimension is walked in n_pass passes of nc8p chunks (<= 32 chunks = 256 channels), each pass staging its
+// channel slice of the tile and of the packed weights.  k order = (pass, tap, chunk in pass) -- see pack_conv_kernel.
 template <int TH, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int mt_total,
-                                                        int nc8, int ps, int nq, int ns, int w_in_lds) {
+                                                        int nc8, int nc8p, int n_pass, int ps, int nsp, int w_in_lds) {
     constexpr int P = TH / 4;  // pixel groups (tile rows) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
+    const int T = ks3 ? 9 : 1;
     const int HT = TH + 2 * halo, WT = TW + 2 * halo;
     uint8_t *s_tile = smem;
     float *s_aff = reinterpret_cast<float *>(smem + (size_t)HT * WT * ps * 16);
-    f16 *s_w = reinterpret_cast<f16 *>(s_aff + 4 * a.x.cs_in);   // [MT][ns][512] packed weight fragments (optional)
+    f16 *s_w = reinterpret_cast<f16 *>(s_aff + 4 * a.x.cs_in);   // [MT][nsp][512] packed weight fragments of one pass
     const int t = threadIdx.x;
     const TileCoord tc = tile_coord(blockIdx.x, tiles_x, tiles_y, TH);
     const int H = a.H, W = a.W;
+    const int ns_total = n_pass * nsp;
 
     stage_affine_table(a.x, s_aff);
-    if (w_in_lds) {
-        // One cooperative copy of this workgroup's weight fragments into LDS: the k-loop then never waits for L2
-        // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
-        const int n16 = MT * ns * 64;   // 16-byte chunks
-        for (int i = t; i < n16; i += 256) {
-            const int m = i / (ns * 64);
-            const int ct = blockIdx.y * MT + m;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ct < mt_total) v = *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)ct * ns * 64 + (i - m * ns * 64)) * 8);
-            *reinterpret_cast<f16x8 *>(s_w + (size_t)i * 8) = v;
-        }
-    }
     if (a.x.lmode != LM_RAW && a.x.lmode != LM_U8) __syncthreads();
 
-    // ---- stage the input tile -------------------------------------------------------------------
-    const int n_items = HT * WT * nc8;
-    // batches of 4 items per thread: the 4 (or more) global loads of a batch are issued back to back, so a
-    // thread pays one memory latency per batch instead of one per item
-    for (int i0 = t; i0 < n_items; i0 += 4 * 256) {
-        f16x8 v[4];
-        int dst[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
-            dst[u] = -1;
-            v[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (i < n_items) {
-                const int pix = i / nc8;
-                const int c8 = i - pix * nc8;
-                const int py = pix / WT, px = pix - py * WT;
-                const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
-                dst[u] = (pix * ps + c8) * 16;
-                if (y >= 0 && y < H && x >= 0 && x < W) v[u] = load_chunk(a.x, tc.b, y, x, H, W, c8, s_aff);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (dst[u] >= 0) *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v[u];
-    }
-    __syncthreads();
-
-    // ---- MFMA main loop -------------------------------------------------------------------------
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int ct0 = blockIdx.y * MT;
     int base[P];
@@ -209,35 +182,81 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[m][p] = f32x4{0, 0, 0, 0};
-
-    int q = g;
-    int tap = q / nc8;
-    int c8 = q - tap * nc8;
-    int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
     const f16 *wp = a.wpk + (size_t)lane * 8;
-    // weight fragments are prefetched two k-steps ahead (L2 latency is longer than one k-step of MFMAs)
-    for (int s = 0; s < ns; ++s) {
-        const bool vq = q < nq;
-        const int off = vq ? ((ty * WT + tx) * ps + c8) * 16 : 0;
-        f16x8 af[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int ct = ct0 + m;
-            if (w_in_lds) af[m] = *reinterpret_cast<const f16x8 *>(s_w + ((size_t)(m * ns + s) * 64 + lane) * 8);
-            else af[m] = (ct < mt_total) ? *reinterpret_cast<const f16x8 *>(wp + ((size_t)ct * ns + s) * 512)
-                                         : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int c8_lo = pass * nc8p;
+        const int nc8_cur = min(nc8p, nc8 - c8_lo);
+        if (pass) __syncthreads();   // everyone is done with the previous pass's tile and weights
+        if (w_in_lds) {
+            // One cooperative copy of this workgroup's weight fragments into LDS: the k-loop then never waits for L2
+            // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
+            const int n16 = MT * nsp * 64;   // 16-byte chunks
+            for (int i = t; i < n16; i += 256) {
+                const int m = i / (nsp * 64);
+                const int ct = blockIdx.y * MT + m;
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ct < mt_total)
+                    v = *reinterpret_cast<const f16x8 *>(a.wpk + (((size_t)ct * ns_total + (size_t)pass * nsp) * 64 + (i - m * nsp * 64)) * 8);
+                *reinterpret_cast<f16x8 *>(s_w + (size_t)i * 8) = v;
+            }
         }
+        // ---- stage this pass's channel slice of the input tile ------------------------------------------
+        const int n_items = HT * WT * nc8_cur;
+        // batches of 4 items per thread: the 4 (or more) global loads of a batch are issued back to back, so a
+        // thread pays one memory latency per batch instead of one per item
+        for (int i0 = t; i0 < n_items; i0 += 4 * 256) {
+            f16x8 v[4];
+            int dst[4];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);  // invalid k-slots: zero weights
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                dst[u] = -1;
+                v[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (i < n_items) {
+                    const int pix = i / nc8_cur;
+                    const int c8 = i - pix * nc8_cur;
+                    const int py = pix / WT, px = pix - py * WT;
+                    const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
+                    dst[u] = (pix * ps + c8) * 16;
+                    if (y >= 0 && y < H && x >= 0 && x < W) v[u] = load_chunk(a.x, tc.b, y, x, H, W, c8_lo + c8, s_aff);
+                }
+            }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][p], 0, 0, 0);
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v[u];
         }
-        q += 4;
-        c8 += 4;
-        while (c8 >= nc8) {
-            c8 -= nc8;
-            if (++tx == 3) { tx = 0; ++ty; }
+        __syncthreads();
+
+        // ---- MFMA loop over (tap, chunk) of this pass ----------------------------------------------------------
+        const int nq = T * nc8p;          // the packing pads every pass to nc8p chunks (zero weights beyond nc8_cur)
+        int q = g;
+        int tap = q / nc8p;
+        int c8 = q - tap * nc8p;
+        int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
+        for (int s = 0; s < nsp; ++s) {
+            const bool vq = (q < nq) && (c8 < nc8_cur);
+            const int off = vq ? ((ty * WT + tx) * ps + c8) * 16 : 0;
+            f16x8 af[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int ct = ct0 + m;
+                if (w_in_lds) af[m] = *reinterpret_cast<const f16x8 *>(s_w + ((size_t)(m * nsp + s) * 64 + lane) * 8);
+                else af[m] = (ct < mt_total) ? *reinterpret_cast<const f16x8 *>(wp + ((size_t)ct * ns_total + (size_t)pass * nsp + s) * 512)
+                                             : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);  // invalid k-slots: zero weights
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][p], 0, 0, 0);
+            }
+            q += 4;
+            c8 += 4;
+            while (c8 >= nc8p) {
+                c8 -= nc8p;
+                if (++tx == 3) { tx = 0; ++ty; }
+            }
         }
     }
 
@@ -818,9 +837,10 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
     const int cs = i >> 9;
     const int s = cs % ns, ct = cs / ns;
     const int m = lane & 15, g = lane >> 4;
-    const int q = 4 * s + g;
-    const int tap = q / nc8, c8 = q - tap * nc8;
-    const int mi = ct * 16 + m, ki = c8 * 8 + j;
+    const int nc8p = imk_pass_chunks(nc8), nsp = (T * nc8p + 3) / 4;   // ns = n_pass * nsp
+    const int pass = s / nsp, q = 4 * (s - pass * nsp) + g;
+    const int tap = q / nc8p, c8 = pass * nc8p + (q - tap * nc8p);
+    const int mi = ct * 16 + m, ki = (c8 < nc8 && (q - tap * nc8p) < nc8p) ? c8 * 8 + j : k_dim;
     float v = 0.f;
     if (tap < T && mi < m_dim && ki < k_dim) {
         if (!transposed) v = w[((size_t)tap * cin + ki) * cout + mi];                 // m = co, k = ci
@@ -909,16 +929,17 @@ __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs
     const int T = jb.ksize == 3 ? 9 : 1;
     const int m_dim = jb.transposed ? jb.cin : jb.cout, k_dim = jb.transposed ? jb.cout : jb.cin;
     const int nc8 = ((k_dim + 7) & ~7) / 8;
-    const int ns = (T * nc8 + 3) / 4;
+    const int nc8p = imk_pass_chunks(nc8), nsp = (T * nc8p + 3) / 4;
+    const int ns = imk_cdiv_d(nc8, nc8p) * nsp;
     const int total = ((m_dim + 15) / 16) * ns * 512;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int j = i & 7, lane = (i >> 3) & 63;
         const int cs = i >> 9;
         const int s = cs % ns, ct = cs / ns;
         const int m = lane & 15, g = lane >> 4;
-        const int q = 4 * s + g;
-        const int tap = q / nc8, c8 = q - tap * nc8;
-        const int mi = ct * 16 + m, ki = c8 * 8 + j;
+        const int pass = s / nsp, q = 4 * (s - pass * nsp) + g;
+        const int tap = q / nc8p, c8 = pass * nc8p + (q - tap * nc8p);
+        const int mi = ct * 16 + m, ki = c8 < nc8 ? c8 * 8 + j : k_dim;
         float v = 0.f;
         if (tap < T && mi < m_dim && ki < k_dim) {
             if (!jb.transposed) v = jb.w[((size_t)tap * jb.cin + ki) * jb.cout + mi];
@@ -972,7 +993,7 @@ static inline int odd_ps(int nc8) { return nc8 | 1; }
 // Tile height: 16 rows unless the LDS tile would exceed 64 KB (wide layers), then 8.
 static inline int conv_tile_h(int cs_in, int ksize) {
     const int halo = ksize == 3 ? 1 : 0;
-    const size_t b16 = (size_t)(16 + 2 * halo) * (TW + 2 * halo) * odd_ps(cs_in / 8) * 16;
+    const size_t b16 = (size_t)(16 + 2 * halo) * (TW + 2 * halo) * odd_ps(imk_pass_chunks(cs_in / 8)) * 16;
     return b16 > 64 * 1024 ? 8 : 16;
 }
 
@@ -1034,9 +1055,11 @@ extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
 template <int TH>
 static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     const int halo = a.ksize == 3 ? 1 : 0;
-    const int nc8 = a.x.cs_in / 8, ps = odd_ps(nc8);
+    const int nc8 = a.x.cs_in / 8;
+    const int nc8p = imk_pass_chunks(nc8), n_pass = imk_cdiv_d(nc8, nc8p);
+    const int ps = odd_ps(nc8p);
     const int T = a.ksize == 3 ? 9 : 1;
-    const int nq = T * nc8, ns = (nq + 3) / 4;
+    const int nsp = (T * nc8p + 3) / 4;
     const int mt_total = (a.cout + 15) / 16;
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, TH);
     const size_t tile_bytes = (size_t)(TH + 2 * halo) * (TW + 2 * halo) * ps * 16;
@@ -1049,21 +1072,21 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     const int n_sp = a.B * tiles_x * tiles_y;
     int mt = mt_total >= 4 ? 4 : (mt_total >= 2 ? 2 : 1);
     while (mt > 1 && n_sp * imk_cdiv(mt_total, mt) < 512) mt >>= 1;
-    // weight fragments through LDS when they fit next to the tile (1 KB per (channel tile, k-step))
+    // weight fragments (of one pass) through LDS when they fit next to the tile (1 KB per (channel tile, k-step))
     int w_in_lds = 0;
     while (true) {
-        const size_t wbytes = (size_t)mt * ns * 1024;
-        if (wbytes <= 64 * 1024 && lds_base + wbytes <= 128 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
+        const size_t wbytes = (size_t)mt * nsp * 1024;
+        if (wbytes <= 64 * 1024 && lds_base + wbytes <= 150 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
         if (mt > 1) { mt >>= 1; continue; }
         break;
     }
-    if (ns <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
+    if (nsp * n_pass <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
     dim3 grid(n_sp, imk_cdiv(mt_total, mt));
-    if (lds > 160 * 1024) return IMK_EUNSUPPORTED;  // wider than ~384 input channels on a 3x3: needs K passes
+    if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)  // above the default dynamic-LDS limit: opt in (idempotent, no sync)
             IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, ps, nq, ns, w_in_lds);
+        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds);
         return IMK_OK;
     };
     ProfRec pr{};
@@ -1231,7 +1254,8 @@ size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed) {
     const int T = ksize == 3 ? 9 : 1;
     const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
     const int nc8 = imk_pad8(k_dim) / 8;
-    const int ns = (T * nc8 + 3) / 4;
+    const int nc8p = imk_pass_chunks(nc8);
+    const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
     return (size_t)((m_dim + 15) / 16) * ns * 512;
 }
 
@@ -1239,7 +1263,8 @@ int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int trans
     const int T = ksize == 3 ? 9 : 1;
     const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
     const int nc8 = imk_pad8(k_dim) / 8;
-    const int ns = (T * nc8 + 3) / 4;
+    const int nc8p = imk_pass_chunks(nc8);
+    const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
     const int total = (int)imk_packed_conv_halfs(ksize, cin, cout, transposed);
     pack_conv_kernel<<<imk_cdiv(total, 256), 256, 0, stream>>>(w, T, cin, cout, transposed, m_dim, k_dim, nc8, ns, total, dst);
     IMK_LAUNCH_CHECK();

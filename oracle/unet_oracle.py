@@ -143,7 +143,7 @@ def _bn(x, p, name, training, f16, stats_out):
 
 
 def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_fp16=False,
-            stats_out=None, taps=None, override=None, return_logits=False):
+            stats_out=None, taps=None, override=None, return_logits=False, grad_taps=None):
     """x uint8 [B,H,W,C] (numpy or torch) -> probabilities float32 [B,H,W,K] (torch).
     `taps`, if a dict, receives every stored intermediate in NHWC float32 (pre-BN conv outputs).
     `override`, if a dict name -> NHWC float32 tensor, replaces the VALUE of that conv output while
@@ -159,12 +159,18 @@ def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_f
             taps[name] = t.detach().permute(0, 2, 3, 1).contiguous()
 
     def c(name, t, relu=True):
-        y = _conv(t, p[name + ".w"], p[name + ".b"], relu, f16)
         if override is not None and name in override:
+            # value := the overriding tensor; gradient := that of (pre-activation * [override > 0]): the ReLU decision
+            # follows the overriding values ONLY (not also this oracle's own pre-activation sign)
             ov = torch.as_tensor(override[name]).float().permute(0, 3, 1, 2)
-            mask = (ov > 0).float() if relu else 1.0          # the ReLU decision follows the overriding values
-            y = y * mask + (ov - y * mask).detach()
+            pre = _conv(t, p[name + ".w"], p[name + ".b"], False, f16)   # fp16 weights, gradient rounded like a stored tensor
+            mask = (ov > 0).float() if relu else 1.0
+            y = pre * mask + (ov - pre * mask).detach()
+        else:
+            y = _conv(t, p[name + ".w"], p[name + ".b"], relu, f16)
         tap(name, y)
+        if grad_taps is not None and y.requires_grad:   # gradient w.r.t. this conv's (post-ReLU) output, NHWC
+            y.register_hook(lambda g, n=name: grad_taps.__setitem__(n, g.detach().permute(0, 2, 3, 1).contiguous()))
         return y
 
     def bn(name, t):
@@ -218,7 +224,7 @@ def new_opt_state(p):
 
 def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
                lr=3e-3, wd=1e-4, b1=0.9, b2=0.999, eps=1e-7, emulate_fp16=False, loss_scale=1.0,
-               return_grads=False, override=None):
+               return_grads=False, override=None, grad_taps=None):
     """One step of forward(train) -> loss -> backward -> tfa-AdamW, in place on p / opt.
     Returns (loss, grads?)"""
     names = trainable_names(p)
@@ -227,7 +233,7 @@ def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
     q.update(leaves)
     stats = {}
     probs, logits = forward(q, x_u8, c_in, n_out, alpha, act_out, training=True, emulate_fp16=emulate_fp16,
-                            stats_out=stats, override=override, return_logits=True)
+                            stats_out=stats, override=override, return_logits=True, grad_taps=grad_taps)
     t = torch.as_tensor(np.asarray(target)).float()
     loss = loss_fn(probs, t, loss_kind, logits if act_out == "softmax" else None)
     (loss * loss_scale).backward()

@@ -16,6 +16,8 @@ CFGS = {
     "suim": dict(h=48, w=64, c=3, k=9, alpha=1.0, act="softmax", loss="cce", b=2),
     "hela": dict(h=32, w=32, c=1, k=3, alpha=1.0, act="sigmoid", loss="mse", b=2),
     "odd": dict(h=48, w=80, c=3, k=35, alpha=1.25, act="softmax", loss="cce", b=2),
+    "alpha2": dict(h=32, w=48, c=3, k=1, alpha=2.0, act="sigmoid", loss="mse", b=2),
+    "alpha15": dict(h=32, w=48, c=3, k=1, alpha=1.5, act="sigmoid", loss="mse", b=2),
 }
 
 
@@ -45,10 +47,16 @@ def run(name, cfg):
     print(f"=== {name}: {cfg}")
     torch.manual_seed(0)
     h, w, c, k, alpha, act, b = cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], cfg["b"]
-    m = UNet(h, w, c, k, alpha, act, seed=1)
-    sd = randomize_bn(m.state_dict(), 2)
+    ts = os.environ.get("DIAG_TESTSEEDS") == "1"
+    m = UNet(h, w, c, k, alpha, act, seed=11 if ts else 1)
+    if ts:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gpu_unet as T
+        sd = T.randomize_bn(m.state_dict(), 12)
+    else:
+        sd = randomize_bn(m.state_dict(), 2)
     m.load_state_dict(sd)
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(13 if ts else 3)
     yy, xx = np.mgrid[0:h, 0:w]
     x = (127 + 80 * np.sin(xx / 7.0)[None, :, :, None] * np.cos(yy / 5.0)[None, :, :, None]
          + rng.integers(-30, 30, (b, h, w, c))).clip(0, 255).astype(np.uint8)
@@ -75,6 +83,11 @@ def run(name, cfg):
         tgt = np.eye(k, dtype=np.float32)[y]
         kind = 1
     m.init_train_state()
+    if os.environ.get("DIAG_SCALE"):
+        import struct
+        sc = float(os.environ["DIAG_SCALE"])
+        off = m.plan.state_bytes - 256
+        m.train_state[off:off + 8] = torch.tensor(list(struct.pack("ff", sc, 1.0 / sc)), dtype=torch.uint8).cuda()
     m.fwd_bwd(xd, torch.from_numpy(y).cuda(), kind)
     torch.cuda.synchronize()
     stats = m.stats.cpu().numpy()
@@ -87,8 +100,16 @@ def run(name, cfg):
     # gradients are compared with the oracle's forward VALUES pinned to the GPU's (straight-through), so that
     # fp16 rounding noise is not amplified through ReLU masks / pool arg-maxes
     ov = {l["name"]: m.intermediate(l["name"], b, 1) for l in m.plan.layers if l["kind"] == 0 and l["name"] != "out"}
+    gt = {}
     loss_ref, grads_ref = U.train_step(sd_ref, opt, x, tgt, c, k, alpha, act, cfg["loss"], emulate_fp16=True,
-                                       loss_scale=float(stats[2]), return_grads=True, override=ov)
+                                       loss_scale=float(stats[2]), return_grads=True, override=ov, grad_taps=gt)
+    if os.environ.get("DIAG_DA"):
+        for l in m.plan.layers:   # pre-activation gradients of the 3x3 convs (materialised on the GPU): dh * [h > 0]
+            if l["kind"] == 0 and l["name"].endswith(".c3"):
+                got = m.intermediate(l["name"], b, 1, which=1).numpy()
+                ref = (gt[l["name"]] * (ov[l["name"]] > 0)).numpy()
+                e = err(got, ref)
+                print(f"  dA {l['name']:7s} max|d|={e[0]:.4g} relL2={e[1]:.3g} max|ref|={e[2]:.3g}")
     print(f"  train loss got={stats[0]:.6f} ref={loss_ref:.6f} found_inf={stats[1]} scale={stats[2]}")
     for l in m.plan.layers:
         if l["kind"] == 0 and l["name"] != "out":

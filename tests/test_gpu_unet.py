@@ -26,6 +26,7 @@ CFGS = {
     "hela": dict(h=32, w=48, c=1, k=3, alpha=1.0, act="sigmoid", loss="mse", b=3),
     "odd": dict(h=48, w=80, c=3, k=35, alpha=1.25, act="softmax", loss="cce", b=2),
     "wide": dict(h=32, w=32, c=3, k=9, alpha=1.5, act="softmax", loss="cce", b=2),
+    "alpha2": dict(h=32, w=48, c=3, k=1, alpha=2.0, act="sigmoid", loss="mse", b=2),   # 512-channel bottleneck: 2 K passes
 }
 
 
@@ -153,18 +154,21 @@ def test_train_step_parity(UNet, name):
                                        emulate_fp16=True, loss_scale=float(stats[2]), return_grads=True, override=ov)
     assert abs(stats[0] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
     g = g1.cpu()
+    errs = {}
     for l in m.plan.layers:
         n = l["name"]
         if l["kind"] == 0:
             kk, ci, co = l["ksize"], l["cin"], l["cout"]
             gw = g[l["off_w"]:l["off_w"] + kk * kk * ci * co].reshape(kk, kk, ci, co).numpy()
             gb = g[l["off_b"]:l["off_b"] + co].numpy()
-            assert rel_l2(gw, grads_ref[n + ".w"].numpy()) <= 2e-2, n
-            assert rel_l2(gb, grads_ref[n + ".b"].numpy()) <= 2e-2, n
+            errs[n + ".w"] = rel_l2(gw, grads_ref[n + ".w"].numpy())
+            errs[n + ".b"] = rel_l2(gb, grads_ref[n + ".b"].numpy())
         else:
             cc = l["cout"]
-            assert rel_l2(g[l["off_w"]:l["off_w"] + cc].numpy(), grads_ref[n + ".gamma"].numpy()) <= 2e-2, n
-            assert rel_l2(g[l["off_b"]:l["off_b"] + cc].numpy(), grads_ref[n + ".beta"].numpy()) <= 2e-2, n
+            errs[n + ".gamma"] = rel_l2(g[l["off_w"]:l["off_w"] + cc].numpy(), grads_ref[n + ".gamma"].numpy())
+            errs[n + ".beta"] = rel_l2(g[l["off_b"]:l["off_b"] + cc].numpy(), grads_ref[n + ".beta"].numpy())
+    bad = {k: round(v, 4) for k, v in errs.items() if not v <= 2e-2}
+    assert not bad, f"gradient tensors off by more than 2e-2 rel-L2: {bad}; all: { {k: round(v, 4) for k, v in errs.items()} }"
     # BN moving statistics after one step (momentum 0.99)
     for kk in sd_ref:
         if kk.endswith(".mean") or kk.endswith(".var"):
