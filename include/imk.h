@@ -170,6 +170,25 @@ int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, 
                         const float *grads, const float *stats, float grad_scale,
                         float lr, float wd, float beta1, float beta2, float eps, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Noisy-Student augmentation (IM+ / AIM+ drivers)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct imk_aug_params {   /* one per image, device array */
+    int flip_v, flip_h;           /* cv2.flip(.., 0) / cv2.flip(.., 1)                (functions.py:2796-2803) */
+    int rot;                      /* 0 none, 1 = 90 CW, 2 = 180, 3 = 90 CCW           (functions.py:2805-2818) */
+    int bright_on;                /* apply convertScaleAbs(alpha, beta)               (functions.py:2820-2824) */
+    float alpha, beta;
+    int blur_k;                   /* 0/1 none, 3, 5, 7: GaussianBlur((k,k), 0)        (functions.py:1495-1501) */
+    int noise_max;                /* uniform integer noise in [-m, m), then clip      (functions.py:1463-1478) */
+    uint32_t seed;                /* per-image seed of the counter-based noise generator */
+} imk_aug_params;
+
+/* Replaces augment_image_and_mask (functions.py:2779-2826) + add_noise_and_blur (:1481-1506) for a batch.
+ *   img  [B,H,W,C] u8 -> img_out;  mask [B,H,W,Cm] u8 (or NULL) -> mask_out (geometric part only).
+ * 90-degree turns need h == w (set any_quarter_turn if any params[i].rot is 1 or 3).  Not in place. */
+int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w, int c, int cm,
+                const imk_aug_params *params, uint8_t *img_out, uint8_t *mask_out, int any_quarter_turn, void *stream);
+
 /* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
  * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on
  * every layer.  Global flag; training always stores them (the backward pass needs them). */

@@ -14,6 +14,11 @@ class UnetCfg(ctypes.Structure):
                 ("ch", c_int * 5), ("act_out", c_int)]
 
 
+class AugParams(ctypes.Structure):
+    _fields_ = [("flip_v", c_int), ("flip_h", c_int), ("rot", c_int), ("bright_on", c_int), ("alpha", c_float),
+                ("beta", c_float), ("blur_k", c_int), ("noise_max", c_int), ("seed", ctypes.c_uint32)]
+
+
 class LayerInfo(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 16), ("kind", c_int), ("ksize", c_int), ("cin", c_int), ("cout", c_int),
                 ("off_w", c_int64), ("off_b", c_int64), ("off_mean", c_int64), ("off_var", c_int64)]
@@ -51,6 +56,7 @@ SIGNATURES = {
     "imk_unet_state_init": (c_int, [c_void_p, c_void_p, c_void_p]),
     "imk_unet_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "imk_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "imk_debug_materialize": (c_int, [c_int]),
     "imk_prof_enable": (c_int, [c_int]),
     "imk_prof_collect": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),

@@ -149,3 +149,23 @@ def test_parse_mask_rule(tmp_path):
     img, mask = F.parse_image_ISIC_2018(str(tmp_path / "images" / "a.png"))
     assert img.shape == (16, 16, 3) and np.array_equal(img[..., 1], ramp)
     assert mask.shape == (16, 16, 1) and mask.sum() == 1 and mask.reshape(-1)[255] == 1
+
+
+def _params(n, seed, **kw):
+    import random
+    from inconsistencymasks_amd import augment
+    return augment.draw_params(n, rng=random.Random(seed), np_rng=np.random.RandomState(seed), **kw)
+
+
+def test_augment_distribution_of_draws():
+    """the host draws follow the reference's distributions (functions.py:2795-2826, :1494)"""
+    prm = _params(4000, 5, free_rotation=True, max_blur=2, max_noise=10, brightness_range_alpha=(0.8, 1.2),
+                  brightness_range_beta=(-10, 10))
+    rot = np.bincount([q.rot for q in prm], minlength=4) / 4000
+    assert np.all(np.abs(rot - 0.25) < 0.04)
+    assert abs(np.mean([q.flip_h for q in prm]) - 0.5) < 0.04 and abs(np.mean([q.bright_on for q in prm]) - 0.5) < 0.04
+    ks = sorted(set(q.blur_k for q in prm))
+    assert ks == [0, 3, 5]
+    assert all(0.8 <= q.alpha <= 1.2 and -10 <= q.beta <= 10 and q.noise_max == 10 for q in prm)
+    prm = _params(200, 6, free_rotation=False)
+    assert all(q.rot == 0 and q.flip_v == 0 for q in prm)

@@ -1,0 +1,65 @@
+"""GPU parity of imk_augment against oracle/aug_oracle.py (bit-exact: integer / byte work)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(n, seed, **kw):
+    from inconsistencymasks_amd import augment
+    return augment.draw_params(n, rng=random.Random(seed), np_rng=np.random.RandomState(seed), **kw)
+
+
+@pytest.mark.parametrize("shape,cm,free", [((6, 64, 64, 3), 1, True), ((5, 48, 80, 3), 1, False), ((4, 32, 32, 1), 3, True),
+                                           ((3, 7, 7, 3), 1, True)])
+def test_augment_matches_oracle(shape, cm, free):
+    from inconsistencymasks_amd import augment
+    from oracle import aug_oracle as A
+    rng = np.random.default_rng(0)
+    B, H, W, C = shape
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    msk = rng.integers(0, 256, (B, H, W, cm), dtype=np.uint8)
+    for rep in range(4):                       # several draws so that every branch is visited
+        prm = _params(B, 100 + rep, free_rotation=free, max_blur=3, max_noise=25)
+        o, m = augment.augment_batch(torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda(), prm)
+        o, m = o.cpu().numpy(), m.cpu().numpy()
+        for b, q in enumerate(prm):
+            wi, wm = A.augment(img[b], msk[b], q.flip_v, q.flip_h, q.rot, q.bright_on, q.alpha, q.beta, q.blur_k,
+                               q.noise_max, q.seed)
+            assert np.array_equal(o[b], wi), (rep, b, [getattr(q, f[0]) for f in q._fields_])
+            assert np.array_equal(m[b], wm)
+
+
+def test_augment_each_stage_alone():
+    from inconsistencymasks_amd import _lib, augment
+    from oracle import aug_oracle as A
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (1, 40, 40, 3), dtype=np.uint8)
+    base = dict(flip_v=0, flip_h=0, rot=0, bright_on=0, alpha=1.0, beta=0.0, blur_k=0, noise_max=0, seed=7)
+    cases = [dict(flip_v=1), dict(flip_h=1), dict(rot=1), dict(rot=2), dict(rot=3), dict(bright_on=1, alpha=1.5, beta=-25.0),
+             dict(bright_on=1, alpha=0.5, beta=25.0), dict(blur_k=3), dict(blur_k=5), dict(blur_k=7), dict(noise_max=5),
+             dict(noise_max=25), dict()]
+    for c in cases:
+        kw = dict(base, **c)
+        prm = (_lib.AugParams * 1)()
+        for k, v in kw.items():
+            setattr(prm[0], k, v)
+        o, _ = augment.augment_batch(torch.from_numpy(img).cuda(), None, prm)
+        want, _ = A.augment(img[0], None, **kw)
+        assert np.array_equal(o[0].cpu().numpy(), want), c
+    # identity parameters return the input
+    prm = (_lib.AugParams * 1)()
+    prm[0].alpha = 1.0
+    o, _ = augment.augment_batch(torch.from_numpy(img).cuda(), None, prm)
+    assert np.array_equal(o.cpu().numpy(), img)
+
+
+def test_augment_rejects_quarter_turn_of_non_square():
+    from inconsistencymasks_amd import _lib, augment
+    prm = (_lib.AugParams * 1)()
+    prm[0].rot = 1
+    with pytest.raises(_lib.ImkError):
+        augment.augment_batch(torch.zeros((1, 8, 16, 3), dtype=torch.uint8, device="cuda"), None, prm)

@@ -188,3 +188,33 @@ def test_morphology_properties():
     one[4, 4] = 255
     assert O.dilate(one, 3).sum() == 9 * 255 and O.dilate(one, 5).sum() == 25 * 255
     assert np.array_equal(O.erode(O.dilate(one, 3), 3), one)
+
+
+# ---- augmentation oracle (unpinned against cv2; structural checks) ---------------------------------------------
+def test_aug_oracle_geometry_and_blur_properties():
+    from oracle import aug_oracle as A
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (12, 12, 3), dtype=np.uint8)
+    # flips / rotations compose like the cv2 calls they restate
+    assert np.array_equal(A.geometric(img, 1, 0, 0), np.flipud(img))
+    assert np.array_equal(A.geometric(img, 0, 1, 0), np.fliplr(img))
+    assert np.array_equal(A.geometric(img, 0, 0, 1)[0], img[::-1, 0])          # 90 CW: first row = first column, bottom-up
+    assert np.array_equal(A.geometric(A.geometric(img, 0, 0, 1), 0, 0, 3), img)
+    assert np.array_equal(A.geometric(img, 0, 0, 2), img[::-1, ::-1])
+    # blur: constant images are fixed points, kernels are normalised, result within the neighbourhood's range
+    for k in (3, 5, 7):
+        const = np.full((9, 9, 1), 77, np.uint8)
+        assert np.array_equal(A.gaussian_blur(const, k), const)
+        b = A.gaussian_blur(img, k)
+        assert b.min() >= img.min() and b.max() <= img.max()
+    # 3x3 known answer: centre impulse 255 -> [1 2 1]^T[1 2 1]/16 * 255, rounded half up
+    imp = np.zeros((5, 5, 1), np.uint8); imp[2, 2, 0] = 255
+    want = np.floor(np.outer([1, 2, 1], [1, 2, 1]) * 255 / 16 + 0.5).astype(np.uint8)
+    assert np.array_equal(A.gaussian_blur(imp, 3)[1:4, 1:4, 0], want)
+    # brightness: saturation and the absolute value
+    a = np.array([[[0], [100], [255]]], np.uint8)
+    assert A.convert_scale_abs(a, 1.5, -20).ravel().tolist() == [20, 130, 255]
+    # noise range [-m, m)
+    n = A.noise_field((64, 64, 3), 5, 1234)
+    assert n.min() == -5 and n.max() == 4
+    assert not np.array_equal(n, A.noise_field((64, 64, 3), 5, 1235))
