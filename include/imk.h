@@ -189,6 +189,23 @@ typedef struct imk_aug_params {   /* one per image, device array */
 int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w, int c, int cm,
                 const imk_aug_params *params, uint8_t *img_out, uint8_t *mask_out, int any_quarter_turn, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation reductions (benchmark_ISIC2018 / benchmark_multiclass)
+ * ---------------------------------------------------------------------------------------------- */
+/* Replaces the threshold + per-image numpy metric loop of benchmark_ISIC2018 (functions.py:1120-1140) with
+ * get_IoU_binary (:1767-1788) and dice_score_numpy_binary (:1837-1861):
+ *   probs [B,H,W] f32, gt [B,H,W] u8 -> pred_out [B,H,W] u8 in {0,255} (may be NULL), counts [B,5] int64 =
+ *   { #(gt!=0 & pred), #(gt!=0 | pred), #(gt>=128), #pred, #(gt>=128 & pred) };  pred = p > thr (cmp_ge: >=). */
+int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt, int batch, int h, int w,
+                    uint8_t *pred_out, int64_t *counts, void *stream);
+
+/* Replaces argmax + pixel_accuracy (functions.py:1820-1834) + get_IoU_multi_unique (:1791-1816) of
+ * benchmark_multiclass (:1308-1330):  probs [B,H,W,K] f32, gt [B,H,W] u8 class ids -> pred_out [B,H,W] u8 (may be
+ * NULL), counts [B,4,256] int64: [0][v] = #(gt==v), [1][v] = #(pred==v), [2][v] = #(gt==v & pred==v),
+ * [3][0] = #(pred==gt).  k <= 256. */
+int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
+                        int64_t *counts, void *stream);
+
 /* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
  * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on
  * every layer.  Global flag; training always stores them (the backward pass needs them). */

@@ -1,0 +1,120 @@
+// Evaluation reductions of the benchmark_* functions on the GPU.
+// The reference thresholds / argmaxes a batch of predictions and then loops over images in numpy
+// (functions.py:1078-1151 ISIC, :1265-1339 multiclass; metrics :1767-1861).  Here one streaming kernel per batch
+// produces the prediction masks and, per image, the INTEGER pixel counts every one of those metrics is a ratio of;
+// the host forms the ratios with the reference's own float expressions, so results are bit-identical.
+// HBM-bound: probabilities read once, mask written once, counts via LDS histograms + one atomic per bin per block.
+#include "imk_common.h"
+
+namespace {
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// counts[b][0..4] = #(gt!=0 & pred), #(gt!=0 | pred), #(gt>=128), #pred, #(gt>=128 & pred)
+__global__ __launch_bounds__(256) void eval_binary_kernel(const float *__restrict__ probs, float thr, int cmp_ge,
+                                                          const uint8_t *__restrict__ gt, int hw,
+                                                          uint8_t *__restrict__ pred_out, unsigned long long *__restrict__ counts) {
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * hw;
+    int c[5] = {0, 0, 0, 0, 0};
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < hw; p += gridDim.x * 1024) {
+        float v[4];
+        uint8_t g[4];
+        if (p + 3 < hw && ((base + p) & 3) == 0) {
+            const float4 f = *reinterpret_cast<const float4 *>(probs + base + p);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            const uint32_t gg = *reinterpret_cast<const uint32_t *>(gt + base + p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = (gg >> (8 * j)) & 0xff;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = (p + j < hw) ? probs[base + p + j] : -1.f; g[j] = (p + j < hw) ? gt[base + p + j] : 0; }
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = p + j < hw;
+            const bool pr = in && (cmp_ge ? v[j] >= thr : v[j] > thr);
+            const bool gn = g[j] != 0, gh = g[j] >= 128;
+            c[0] += gn && pr; c[1] += gn || pr; c[2] += gh; c[3] += pr; c[4] += gh && pr;
+            packed |= (pr ? 255u : 0u) << (8 * j);
+        }
+        if (pred_out) {
+            if (p + 3 < hw && ((base + p) & 3) == 0) *reinterpret_cast<uint32_t *>(pred_out + base + p) = packed;
+            else
+                for (int j = 0; j < 4 && p + j < hw; ++j) pred_out[base + p + j] = (packed >> (8 * j)) & 0xff;
+        }
+    }
+    __shared__ int s_red[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int s = wave_sum_i(c[k]);
+        if (lane == 0) s_red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int s = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        if (s) atomicAdd(counts + (size_t)b * 5 + threadIdx.x, (unsigned long long)s);
+    }
+}
+
+// counts[b][0][v] = #(gt==v), [1][v] = #(pred==v), [2][v] = #(gt==v & pred==v), v in 0..255; counts[b][3][0] = #(pred==gt)
+__global__ __launch_bounds__(256) void eval_multi_kernel(const float *__restrict__ probs, const uint8_t *__restrict__ gt,
+                                                         int hw, int K, uint8_t *__restrict__ pred_out,
+                                                         unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int hist[3 * 256 + 1];
+    for (int i = threadIdx.x; i < 3 * 256 + 1; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * hw;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+        const float *q = probs + (base + p) * K;
+        float best = q[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k) {        // first maximum wins (np.argmax); NaN handling as imk_im_multiclass: inputs finite
+            const float v = q[k];
+            if (v > best) { best = v; arg = k; }
+        }
+        const int g = gt[base + p];
+        if (pred_out) pred_out[base + p] = (uint8_t)arg;
+        atomicAdd(&hist[g], 1u);
+        atomicAdd(&hist[256 + arg], 1u);
+        if (g == arg) { atomicAdd(&hist[512 + g], 1u); atomicAdd(&hist[768], 1u); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 256 + 1; i += 256)
+        if (hist[i]) atomicAdd(counts + (size_t)b * 1024 + i, (unsigned long long)hist[i]);
+}
+
+}  // namespace
+
+extern "C" int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt, int batch, int h, int w,
+                               uint8_t *pred_out, int64_t *counts, void *stream_) {
+    IMK_CHECK_ARG(probs && gt && counts && batch > 0 && h > 0 && w > 0);
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_HIP(hipMemsetAsync(counts, 0, (size_t)batch * 5 * sizeof(int64_t), stream));
+    const int hw = h * w;
+    int bx = (int)imk_cdiv(hw, 1024);
+    if (bx > 64) bx = 64;
+    eval_binary_kernel<<<dim3(bx, batch), 256, 0, stream>>>(probs, thr, cmp_ge, gt, hw, pred_out, (unsigned long long *)counts);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+extern "C" int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
+                                   int64_t *counts, void *stream_) {
+    IMK_CHECK_ARG(probs && gt && counts && batch > 0 && h > 0 && w > 0 && k > 0 && k <= 256);
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_HIP(hipMemsetAsync(counts, 0, (size_t)batch * 1024 * sizeof(int64_t), stream));
+    const int hw = h * w;
+    int bx = (int)imk_cdiv(hw, 256 * 8);
+    if (bx > 64) bx = 64;
+    eval_multi_kernel<<<dim3(bx, batch), 256, 0, stream>>>(probs, gt, hw, k, pred_out, (unsigned long long *)counts);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 from PIL import Image
 
+from . import evaluate as _ev
 from . import im as _im
 from ._lib import check, lib
 from .unet import UNet, _stream
@@ -299,6 +300,83 @@ def create_pseudo_labels_im_multiclass(models, h, w, c, images_path, main_output
 
 
 # ---------------------------------------------------------------------------------------------------
+# Noisy-Student augmentation of a pseudo-label directory (IM+ drivers; functions.py:2567-2722)
+# ---------------------------------------------------------------------------------------------------
+from .augment import augment_batch, augment_image_and_mask, augment_image_and_masks, draw_params  # noqa: E402,F401
+
+
+def _augment_dirs(image_dir, mask_dirs, image_out, mask_outs, image_channels, num_images, copy_org, draw_kw):
+    """Shared body: every file of image_dir (+ same-named masks) -> num_images augmented copies `{stem}_aug_{n}.png`.
+    The file list is sharded over the ranks; batches are formed from consecutive files of equal size."""
+    import shutil
+    for d in [image_out] + list(mask_outs):
+        os.makedirs(d, exist_ok=True)
+    names = os.listdir(image_dir)
+    mine = shard_list(names)
+    if copy_org:
+        for name in mine:
+            shutil.copy(os.path.join(image_dir, name), os.path.join(image_out, name))
+            for src, dst in zip(mask_dirs, mask_outs):
+                shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    with _pool() as pool:
+        for i in range(0, len(mine), INFER_BATCH):
+            chunk = mine[i:i + INFER_BATCH]
+            imgs = list(pool.map(lambda n: read_png(os.path.join(image_dir, n), image_channels), chunk))
+            msks = list(pool.map(lambda n: np.concatenate([read_png(os.path.join(d, n), 1) for d in mask_dirs], 2), chunk))
+            by_shape = {}
+            for j, a in enumerate(imgs):
+                by_shape.setdefault(a.shape, []).append(j)
+            jobs = []
+            for idx in by_shape.values():
+                x = torch.from_numpy(np.stack([imgs[j] for j in idx], 0)).cuda()
+                m = torch.from_numpy(np.stack([msks[j] for j in idx], 0)).cuda()
+                for n in range(num_images):
+                    o, om = augment_batch(x, m, draw_params(len(idx), **draw_kw))
+                    o, om = o.cpu().numpy(), om.cpu().numpy()
+                    for row, j in enumerate(idx):
+                        stem = chunk[j][:-4]
+                        jobs.append((os.path.join(image_out, f"{stem}_aug_{n}.png"), o[row]))
+                        for k, dst in enumerate(mask_outs):
+                            jobs.append((os.path.join(dst, f"{stem}_aug_{n}.png"), om[row, :, :, k]))
+            list(pool.map(lambda a: write_png(*a), jobs))
+    if _dist():
+        _dist().barrier()
+
+
+def create_augment_images_and_masks_ISIC_2018(images_path, masks_path, main_output_path, num_images=9, copy_org=True,
+                                              brightness_range_alpha=(0.5, 1.5), brightness_range_beta=(-25, 25),
+                                              max_blur=3, max_noise=25, free_rotation=True):
+    """functions.py:2567-2609."""
+    _augment_dirs(images_path, [masks_path], os.path.join(main_output_path, "images"),
+                  [os.path.join(main_output_path, "masks")], 3, num_images, copy_org,
+                  dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                       max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation))
+
+
+def create_augment_images_and_masks_multiclass(images_path, masks_path, main_output_path, num_images=9, copy_org=True,
+                                               free_rotation=False, brightness_range_alpha=(0.5, 1.5),
+                                               brightness_range_beta=(-25, 25), max_blur=3, max_noise=25):
+    """functions.py:2678-2720 (note the position of free_rotation, as in the reference)."""
+    _augment_dirs(images_path, [masks_path], os.path.join(main_output_path, "images"),
+                  [os.path.join(main_output_path, "masks")], 3, num_images, copy_org,
+                  dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                       max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation))
+
+
+def create_augment_images_and_masks_hela(main_input_path, main_output_path, num_images=9, copy_org=True,
+                                         free_rotation=True, brightness_range_alpha=(0.7, 1.3),
+                                         brightness_range_beta=(-15, 15), max_blur=3, max_noise=25):
+    """functions.py:2613-2674.  The brightfield image is processed as 3 channels (cv2.imread's default), so that the
+    noise of the 3 channels is independent exactly as in the reference; the parser's grey conversion follows later."""
+    subs = ("alive", "dead", "mod_position")
+    _augment_dirs(os.path.join(main_input_path, "brightfield"), [os.path.join(main_input_path, s) for s in subs],
+                  os.path.join(main_output_path, "brightfield"), [os.path.join(main_output_path, s) for s in subs],
+                  3, num_images, copy_org,
+                  dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                       max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation))
+
+
+# ---------------------------------------------------------------------------------------------------
 # metrics (functions.py:162-184, 1767-1861)
 # ---------------------------------------------------------------------------------------------------
 def dice_loss(y_true, y_pred, smooth=1):
@@ -427,24 +505,25 @@ def load_model(path, custom_objects=None, device="cuda"):
 
 def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
     """Keras BinaryIoU(target_class_ids=[1], threshold=0.5) accumulated over the whole directory (the
-    val_binary_io_u monitor of functions.py:216-217)."""
+    val_binary_io_u monitor of functions.py:216-217); pixel counts from imk_eval_binary."""
     files = sorted(glob.glob(os.path.join(images_dir, "*.png")))
-    tp = fp = fn = 0
+    inter = union = 0
     with _pool() as pool:
         for i in range(0, len(files), batch):
             chunk = files[i:i + batch]
             items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), chunk))
             x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
-            y = torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda() > 0
-            p = model.predict_device(x) >= 0.5
-            tp += int((p & y).sum()); fp += int((p & ~y).sum()); fn += int((~p & y).sum())
-    return tp / max(tp + fp + fn, 1)
+            y = torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda()
+            _, cnt = _ev.eval_binary(model.predict_device(x), y, 0.5, True, want_pred=False)
+            inter += int(cnt[:, 0].sum()); union += int(cnt[:, 1].sum())
+    return inter / max(union, 1)
 
 
 def benchmark_ISIC2018(model, images_dir, masks_dir, pred_path, h, w, c, batch_size=64, create_images=True,
                        print_results=False):
     """functions.py:1078-1151: batch-64 predict, > 0.5, optional PNG dump, per-image IoU/Dice rounded to 4,
-    means rounded to 3."""
+    means rounded to 3.  Threshold + per-image pixel counts run in imk_eval_binary; the ratios are formed on the
+    host with the reference's float expressions (evaluate.iou_dice_from_counts)."""
     os.makedirs(pred_path, exist_ok=True)
     names = os.listdir(images_dir)
     ious, dices = [], []
@@ -454,12 +533,15 @@ def benchmark_ISIC2018(model, images_dir, masks_dir, pred_path, h, w, c, batch_s
             imgs = list(pool.map(lambda n: read_png(os.path.join(images_dir, n), c), chunk))
             gts = list(pool.map(lambda n: read_png(os.path.join(masks_dir, n), 1)[..., 0], chunk))
             probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda())
-            pred = ((probs > 0.5) * 255).to(torch.uint8).cpu().numpy()[..., 0]
+            pred_d, counts = _ev.eval_binary(probs, torch.from_numpy(np.stack(gts, 0)).cuda(), 0.5, False,
+                                             want_pred=create_images)
             if create_images:
+                pred = pred_d.cpu().numpy()
                 list(pool.map(lambda a: write_png(*a), [(os.path.join(pred_path, n), pred[j]) for j, n in enumerate(chunk)]))
             for j, n in enumerate(chunk):
-                d = round(float(dice_score_numpy_binary(gts[j], pred[j])), 4)
-                u = round(float(get_IoU_binary(gts[j], pred[j])), 4)
+                iou, dice = _ev.iou_dice_from_counts(counts[j])
+                d = round(float(dice), 4)
+                u = round(float(iou), 4)
                 dices.append(d); ious.append(u)
                 if print_results:
                     print(f"{n} IoU: {u}    DS: {d}")
@@ -553,7 +635,8 @@ class MeanIoU:
 
 def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_to_color_mapping, batch_size=64,
                          create_images=True, print_results=True):
-    """functions.py:1265-1339: batch-64 predict, argmax, PNG dumps, per-image PA / IoU rounded to 4, means to 3."""
+    """functions.py:1265-1339: batch-64 predict, argmax, PNG dumps, per-image PA / IoU rounded to 4, means to 3.
+    argmax + per-image class histograms run in imk_eval_multiclass (evaluate.pa_iou_from_counts forms the ratios)."""
     os.makedirs(pred_path, exist_ok=True)
     names = os.listdir(image_path)
     ious, pas = [], []
@@ -563,13 +646,15 @@ def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_t
             imgs = list(pool.map(lambda n: read_png(os.path.join(image_path, n), c), chunk))
             gts = list(pool.map(lambda n: read_png(os.path.join(gt_path, n), 1)[..., 0], chunk))
             probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda())
-            pred = probs.argmax(-1).to(torch.uint8).cpu().numpy()
+            pred_d, counts = _ev.eval_multiclass(probs, torch.from_numpy(np.stack(gts, 0)).cuda(), want_pred=create_images)
+            pred = pred_d.cpu().numpy() if create_images else None
             for j, n in enumerate(chunk):
                 if create_images:
                     write_png(os.path.join(pred_path, n), pred[j])
                     convert_class_to_color_mask(pred[j], os.path.join(pred_path, f"{n[:-4]}_color.png"), class_to_color_mapping)
-                pa = round(float(pixel_accuracy(pred[j], gts[j])), 4)
-                iou = round(float(get_IoU_multi_unique(pred[j], gts[j])), 4)
+                pa_f, iou_f = _ev.pa_iou_from_counts(counts[j], gts[j].size)
+                pa = round(float(pa_f), 4)
+                iou = round(float(iou_f), 4)
                 pas.append(pa); ious.append(iou)
                 if print_results:
                     print(f"{n} IoU: {iou}    PA: {pa}")

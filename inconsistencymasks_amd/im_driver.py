@@ -1,7 +1,12 @@
 """Generation loop of the per-dataset `*_IM.py` drivers of the reference (ISIC_2018/09_ISIC_2018_IM.py:47-153 and its
 siblings HeLa/09_HeLa_IM.py, SUIM/10_SUIM_IM.py, Cityscapes/09_Cityscapes_IM.py, which are copies of one template).
 Same loops, model / directory / CSV names and top-K hand-off; launch under torch.distributed.run for multi-GPU.
-Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES (comma-separated)."""
+Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES (comma-separated).
+
+approach="IM_plus" is the IM+ variant (ISIC_2018/11_ISIC_2018_IM+.py:40-135, SUIM/12_SUIM_IM+.py, HeLa/11_HeLa_IM+.py,
+Cityscapes/11_Cityscapes_IM+.py): the IM output goes to a `temp` directory, NUM_IMAGES_IM_PLUS augmented copies of each
+pseudo-labelled pair (no originals) form the training set, augmentation strength and the U-Net width alpha grow per
+generation (Noisy Student)."""
 import csv
 import os
 import shutil
@@ -31,6 +36,21 @@ DATASETS = {
 }
 
 
+_STRONG = dict(max_blurs=[0, 1, 1, 2, 3], max_noises=[5, 10, 15, 20, 25],
+               bra=[(0.9, 1.1), (0.8, 1.2), (0.7, 1.3), (0.6, 1.4), (0.5, 1.5)],
+               brb=[(-5, 5), (-10, 10), (-15, 15), (-20, 20), (-25, 25)])
+IM_PLUS = {   # per-generation schedules of the IM+ scripts (lines 46-50 / 47-51 / 48-52 of each)
+    "ISIC_2018": dict(alphas=[0.5, 0.75, 1, 1.25, 1.5], **_STRONG),
+    "SUIM": dict(alphas=[1, 1.25, 1.5, 1.75, 2], **_STRONG),
+    "HeLa": dict(alphas=[1, 1.25, 1.5, 1.75, 2], max_blurs=[0, 1, 1, 2, 3], max_noises=[5, 10, 15, 20, 25],
+                 bra=[(0.9, 1.1), (0.9, 1.1), (0.8, 1.2), (0.8, 1.2), (0.7, 1.3)],
+                 brb=[(-3, 3), (-6, 6), (-9, 9), (-12, 12), (-15, 15)]),
+    "Cityscapes": dict(alphas=[1, 1.25, 1.5, 1.75, 2], max_blurs=[0, 0, 0, 0, 1], max_noises=[3, 6, 9, 12, 15],
+                       bra=[(0.95, 1.05), (0.9, 1.1), (0.8, 1.2), (0.7, 1.3), (0.6, 1.4)],
+                       brb=[(-3, 3), (-6, 6), (-9, 9), (-12, 12), (-15, 15)]),
+}
+
+
 def default_color_mapping(n_classes):
     """colour -> class id, deterministic palette (the reference's per-dataset colour tables are cosmetic)."""
     return {((37 * k) % 256, (91 * k) % 256, (173 * k) % 256): k for k in range(n_classes)}
@@ -54,6 +74,12 @@ def run(dataset, approach="IM"):
     else:
         BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
     filt = S.get("FILTER_INCONSISTENT_CLASS_PRED", "false").lower() == "true"
+    plus = IM_PLUS[dataset] if approach == "IM_plus" else None
+    if plus:    # the IM+ scripts parse the blocking flags properly for every dataset (ISIC_2018/11_...IM+.py:38-39)
+        BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
+        filt = False
+        free_rot = S.get("FREE_ROTATION", "false").lower() == "true"
+        n_plus = int(S.get("NUM_IMAGES_IM_PLUS", 1))
     P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
     base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
     if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
@@ -68,7 +94,8 @@ def run(dataset, approach="IM"):
                 name_of = lambda g: f"{tag}_{approach}_{runid}_n{n}_gen{g}_e{EK}_d{DK}_bi_{BI}_bo_{BO}" + \
                     ("_filtered" if (filt and ds["kind"] == "multi") else "")
                 modelname = name_of(gen)
-                out = {k: os.path.join(base, f"{k}_predictions", approach, modelname) for k in ("val", "test", "train_unlabeled")}
+                out = {k: os.path.join(base, f"{k}_predictions", approach, *(["temp"] if plus else []), modelname)
+                       for k in ("val", "test", "train_unlabeled")}
                 if gen == 0:
                     files = [os.path.join(model_dir, f"{tag}_subset_{runid}_topK_{j}.h5") for j in range(1, n + 1)]
                 else:
@@ -87,6 +114,19 @@ def run(dataset, approach="IM"):
                         means.append(F.create_pseudo_labels_im_hela(best_models, H, W, C, os.path.join(P(f"{split}_DIR"), "brightfield"),
                                                                     out[key], EK, DK, BI, BO))
                 unl = out["train_unlabeled"]
+                if plus:     # augmented copies only (copy_org False) form the training set
+                    src, unl = unl, os.path.join(base, "train_unlabeled_predictions", approach, modelname)
+                    kw = dict(brightness_range_alpha=plus["bra"][gen], brightness_range_beta=plus["brb"][gen],
+                              max_blur=plus["max_blurs"][gen], max_noise=plus["max_noises"][gen])
+                    if ds["kind"] == "isic":
+                        F.create_augment_images_and_masks_ISIC_2018(os.path.join(src, "images"), os.path.join(src, "masks"),
+                                                                    unl, n_plus, False, free_rotation=free_rot, **kw)
+                    elif ds["kind"] == "multi":
+                        F.create_augment_images_and_masks_multiclass(os.path.join(src, "images"), os.path.join(src, "masks"),
+                                                                     unl, n_plus, False, free_rot, **kw)
+                    else:
+                        F.create_augment_images_and_masks_hela(src, unl, n_plus, False, free_rot, **kw)
+                    alpha = plus["alphas"][gen]
                 if rank == 0:    # labelled pairs join the pseudo-labelled directory
                     if ds["kind"] == "hela":
                         for sub in ("brightfield", "alive", "dead", "mod_position"):

@@ -169,3 +169,30 @@ def test_augment_distribution_of_draws():
     assert all(0.8 <= q.alpha <= 1.2 and -10 <= q.beta <= 10 and q.noise_max == 10 for q in prm)
     prm = _params(200, 6, free_rotation=False)
     assert all(q.rot == 0 and q.flip_v == 0 for q in prm)
+
+
+def _binary_counts(gt, pr):
+    gn, p, gh = gt != 0, pr != 0, gt >= 128
+    return [int((gn & p).sum()), int((gn | p).sum()), int(gh.sum()), int((pr >= 128).sum()), int((gh & (pr >= 128)).sum())]
+
+
+def _multi_counts(gt, pr):
+    c = np.zeros((4, 256), np.int64)
+    c[0] = np.bincount(gt.ravel(), minlength=256)
+    c[1] = np.bincount(pr.ravel(), minlength=256)
+    c[2] = np.bincount(gt.ravel()[gt.ravel() == pr.ravel()], minlength=256)
+    c[3, 0] = int((gt == pr).sum())
+    return c
+
+
+def test_metrics_from_integer_counts_match_reference_goldens_exactly(golden_dir):
+    """the evaluation kernels return integer counts; the host formulas must give the reference's floats bit for bit"""
+    from inconsistencymasks_amd import evaluate as E
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for k in g["cases"]:
+        iou, dice = E.iou_dice_from_counts(_binary_counts(g[k + "_gt"], g[k + "_pr"]))
+        assert iou == float(g[k + "_iou"][0]) and float(dice) == float(g[k + "_dice"][0])
+    for k in g["mc_cases"]:
+        gt, pr = g[k + "_gt"], g[k + "_pr"]
+        pa, iou = E.pa_iou_from_counts(_multi_counts(gt.astype(np.uint8), pr.astype(np.uint8)), gt.size)
+        assert pa == float(g[k + "_pa"][0]) and iou == float(g[k + "_iou"][0])

@@ -98,3 +98,39 @@ def test_isic_driver_toy_run(tmp_path):
     assert 16 <= n_img <= 40 and n_img == len(os.listdir(unl / "masks"))
     miou_val = float(rows[1].split(";")[1])
     assert 0.0 <= miou_val <= 1.0
+
+
+def test_isic_im_plus_toy_run(tmp_path):
+    """ISIC_2018/11_ISIC_2018_IM+.py:59-135: IM output under temp/, augmented copies (+ labelled pairs) as the training
+    set, alpha growing per generation (gen 0: 0.5, gen 1: 0.75 -> the gen-1 top-K models are wider)."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CONFIG.format(base=base) + "FREE_ROTATION = True\nNUM_IMAGES_IM_PLUS = 2\n")
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0,1", "IM_CANDIDATES": "0,1"}
+    subprocess.run([sys.executable, "-c", SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "11_ISIC_2018_IM+.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = "ISIC_2018_IM_plus_1_n2_gen{g}_e0_d0_bi_True_bo_True"
+    models = sorted(os.listdir(base / "models"))
+    for g in (0, 1):
+        for i in (1, 2):
+            assert stem.format(g=g) + f"_topK_{i}.h5" in models
+    temp = base / "train_unlabeled_predictions" / "IM_plus" / "temp" / stem.format(g=0)
+    plus = base / "train_unlabeled_predictions" / "IM_plus" / stem.format(g=0)
+    assert len(os.listdir(temp / "im")) == 24
+    kept = sorted(os.listdir(temp / "images"))
+    got = sorted(os.listdir(plus / "images"))
+    want = sorted([f"{k[:-4]}_aug_{n}.png" for k in kept for n in (0, 1)] + [f"ISIC_{i:05d}.png" for i in range(16)])
+    assert got == want and sorted(os.listdir(plus / "masks")) == want
+    # masks of the augmented pairs are a flip/rotation of the temp mask: same foreground pixel count
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    k = kept[0]
+    src = F.read_png(str(temp / "masks" / k), 1)
+    aug = F.read_png(str(plus / "masks" / f"{k[:-4]}_aug_0.png"), 1)
+    assert aug.shape == src.shape and int((aug > 0).sum()) == int((src > 0).sum())
+    # the width schedule: gen-0 models alpha 0.5, gen-1 models alpha 0.75
+    m0 = F.load_model(str(base / "models" / (stem.format(g=0) + "_topK_1.h5")))
+    m1 = F.load_model(str(base / "models" / (stem.format(g=1) + "_topK_1.h5")))
+    assert (m0.plan.alpha, m1.plan.alpha) == (0.5, 0.75)
