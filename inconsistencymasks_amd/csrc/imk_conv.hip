@@ -191,14 +191,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
         if (w_in_lds) {
             // One cooperative copy of this workgroup's weight fragments into LDS: the k-loop then never waits for L2
             // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
-            const int n16 = MT * nsp * 64;   // 16-byte chunks
+            // The copy is asynchronous (global_load_lds_dwordx4: global -> LDS without registers, one contiguous KB per
+            // wave and instruction), so all of it is in flight while the input tile is staged below.
+            const int n16 = MT * nsp * 64;   // 16-byte chunks; a multiple of 64, so the bound is wave-uniform
             for (int i = t; i < n16; i += 256) {
                 const int m = i / (nsp * 64);
-                const int ct = blockIdx.y * MT + m;
-                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ct < mt_total)
-                    v = *reinterpret_cast<const f16x8 *>(a.wpk + (((size_t)ct * ns_total + (size_t)pass * nsp) * 64 + (i - m * nsp * 64)) * 8);
-                *reinterpret_cast<f16x8 *>(s_w + (size_t)i * 8) = v;
+                int ct = blockIdx.y * MT + m;
+                if (ct >= mt_total) ct = mt_total - 1;   // padding rows of the last group: outputs are never stored
+                const f16 *src = a.wpk + (((size_t)ct * ns_total + (size_t)pass * nsp) * 64 + (i - m * nsp * 64)) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(s_w + (size_t)(i - lane) * 8), 16, 0, 0);
             }
         }
         // ---- stage this pass's channel slice of the input tile ------------------------------------------
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
             for (int u = 0; u < 4; ++u)
                 if (dst[u] >= 0) *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v[u];
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asynchronous weight copy has landed
         __syncthreads();
 
         // ---- MFMA loop over (tap, chunk) of this pass ----------------------------------------------------------
@@ -411,27 +414,34 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
     }
 }
 
-template <int LM, int NC8, bool CHAIN>
+// PAIR (layers with <= 8 output channels, i.e. level 0 at alpha = 0.5): a 16-row MFMA output would be half empty, so
+// the two halves of the K dimension carry two different tile rows instead: k-slot groups g = 0,1 hold (tap, chunk)
+// pairs of row A, g = 2,3 the same pairs of row B; weight rows 0-7 are non-zero only in the first half, rows 8-15 (the
+// same 8 output channels again) only in the second.  D rows 0-7 are then row A's channels, rows 8-15 row B's: every
+// lane owns 4 channels of one pixel and the epilogue runs with all 64 lanes instead of 32.
+template <int LM, int NC8, bool CHAIN, bool PAIR>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         float inv_tx, float inv_pi) {
-    constexpr int P = 4;                        // tile rows per wave (16 x 16 tile)
+    constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
-    constexpr int MAX_NS = (9 * NC8 + 3) / 4;
+    constexpr int MAX_NS = PAIR ? (9 * NC8 + 1) / 2 : (9 * NC8 + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
     const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
     const int n_items = HT * WT * NC8;
-    const int nq = (ks3 ? 9 : 1) * NC8, ns = (nq + 3) / 4;
+    const int nq = (ks3 ? 9 : 1) * NC8, ns = PAIR ? (nq + 1) / 2 : (nq + 3) / 4;
     uint8_t *s_tile = smem;
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);
     float *s_red = s_aff + 4 * 16;              // [4 waves][2][16]
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
+    const int set = PAIR ? (g >> 1) : 0;        // PAIR: which of the block's two tile rows this lane feeds and owns
     const int H = a.H, W = a.W;
     const int cs_in = a.x.cs_in;
     const int per_img = tiles_x * tiles_y;
+    auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
 
     stage_affine_table(a.x, s_aff);
 
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     // those lanes simply read offset 0 (no per-read select).
 #pragma unroll
     for (int s = 0; s < MAX_NS; ++s) {
-        const int q = 4 * s + g;
+        const int q = PAIR ? 2 * s + (g & 1) : 4 * s + g;
         const bool vq = (s < ns) && (q < nq);
         const int tap = q / NC8, c8 = q - tap * NC8;
         const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     }
     int base[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) base[p] = ((wave * P + p) * WT + n) * PS * 16;
+    for (int p = 0; p < P; ++p) base[p] = (tile_row(p) * WT + n) * PS * 16;
     // this thread's staging items (constant over tiles): LDS offset and position inside the halo tile
     int it_lds[MAX_ITEMS], it_py[MAX_ITEMS], it_px[MAX_ITEMS], it_c8[MAX_ITEMS];
 #pragma unroll
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         it_lds[k] = (i < n_items) ? (pix * PS + it_c8[k]) * 16 : -1;
     }
     float bias[4] = {0, 0, 0, 0}, bias2[4] = {0, 0, 0, 0};
-    const int co0 = 4 * g;
+    const int co0 = PAIR ? 4 * (g & 1) : 4 * g;
     if (a.epi == EP_RELU && a.bias)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         if (a.epi == EP_MASK) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + wave * P + p;
+                const int y = tc.ty0 + tile_row(p);
                 mk[p] = f16x4{0, 0, 0, 0};
                 if (y < H && x < W && co0 < a.cs_out)
                     mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         if (dystat) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + wave * P + p;
+                const int y = tc.ty0 + tile_row(p);
                 zq[p] = f16x4{0, 0, 0, 0};
                 if (y < H && x < W && co0 < a.cs_out)
                     zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             // the lane's 4 channels of pixel n are exactly k-slots (g, 0..3) of the next MFMA's B operand.
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + wave * P + p;
+                const int y = tc.ty0 + tile_row(p);
                 const bool inb = (y < H) && (x < W);
                 f16x4 hv;
 #pragma unroll
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         if (co0 < a.cs_out) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + wave * P + p;
+                const int y = tc.ty0 + tile_row(p);
                 if (y >= H || x >= W) continue;
                 const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0;
                 f16x4 v;
@@ -603,16 +613,19 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v1 = wave_sum<16>(s1[r]), v2 = wave_sum<16>(s2[r]);
-            if (n == 0) { s_red[(wave * 2 + 0) * 16 + 4 * g + r] = v1; s_red[(wave * 2 + 1) * 16 + 4 * g + r] = v2; }
+            if (n == 0) { s_red[(wave * 2 + 0) * 16 + 4 * g + r] = v1; s_red[(wave * 2 + 1) * 16 + 4 * g + r] = v2; }   // PAIR: [set][8]
         }
         __syncthreads();
         if (t < 32) {
             const int which = t >> 4, c = t & 15;
             const int cs_st = CHAIN ? a.cs_out2 : a.cs_out;
-            if (c < cs_st)
-                a.stats_partial[(size_t)blockIdx.x * 2 * cs_st + which * cs_st + c] =
-                    (s_red[(0 * 2 + which) * 16 + c] + s_red[(1 * 2 + which) * 16 + c]) +
-                    (s_red[(2 * 2 + which) * 16 + c] + s_red[(3 * 2 + which) * 16 + c]);
+            if (c < cs_st) {
+                float v = (s_red[(0 * 2 + which) * 16 + c] + s_red[(1 * 2 + which) * 16 + c]) +
+                          (s_red[(2 * 2 + which) * 16 + c] + s_red[(3 * 2 + which) * 16 + c]);
+                if (PAIR) v += (s_red[(0 * 2 + which) * 16 + c + 8] + s_red[(1 * 2 + which) * 16 + c + 8]) +
+                               (s_red[(2 * 2 + which) * 16 + c + 8] + s_red[(3 * 2 + which) * 16 + c + 8]);
+                a.stats_partial[(size_t)blockIdx.x * 2 * cs_st + which * cs_st + c] = v;
+            }
         }
     }
 }
@@ -919,15 +932,38 @@ __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs
         for (int i = blockIdx.x * 256 + threadIdx.x; i < 512; i += gridDim.x * 256) {
             const int j = i & 7, lane = (i >> 3) & 63;
             const int m = lane & 15, g = lane >> 4;
-            const int ci = 4 * g + j;
             float v = 0.f;
-            if (j < 4 && ci < jb.cin && m < jb.cout) v = jb.w[(size_t)ci * jb.cout + m];
+            if (!jb.pair) {
+                const int ci = 4 * g + j;
+                if (j < 4 && ci < jb.cin && m < jb.cout) v = jb.w[(size_t)ci * jb.cout + m];
+            } else {        // rows 0-7: row A's 8 outputs from k-slot groups 0,1; rows 8-15: row B's from groups 2,3
+                const int ci = 4 * (g & 1) + j, co = m & 7;
+                if (j < 4 && (m >> 3) == (g >> 1) && ci < jb.cin && co < jb.cout) v = jb.w[(size_t)ci * jb.cout + co];
+            }
             jb.dst[i] = (f16)v;
         }
         return;
     }
     const int T = jb.ksize == 3 ? 9 : 1;
     const int m_dim = jb.transposed ? jb.cin : jb.cout, k_dim = jb.transposed ? jb.cout : jb.cin;
+    if (jb.pair) {              // one 16-row block, k-step s: group g carries (tap, chunk) pair q = 2s + (g & 1) of row g >> 1
+        const int nc8 = ((k_dim + 7) & ~7) / 8;
+        const int nq = T * nc8, ns = (nq + 1) / 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * 512; i += gridDim.x * 256) {
+            const int j = i & 7, lane = (i >> 3) & 63, st = i >> 9;
+            const int m = lane & 15, g = lane >> 4;
+            const int q = 2 * st + (g & 1);
+            const int tap = q / nc8, c8 = q - tap * nc8;
+            const int mi = m & 7, ki = c8 * 8 + j;
+            float v = 0.f;
+            if (q < nq && (m >> 3) == (g >> 1) && mi < m_dim && ki < k_dim) {
+                if (!jb.transposed) v = jb.w[((size_t)tap * jb.cin + ki) * jb.cout + mi];
+                else v = jb.w[((size_t)(T - 1 - tap) * jb.cin + mi) * jb.cout + ki];
+            }
+            jb.dst[i] = (f16)v;
+        }
+        return;
+    }
     const int nc8 = ((k_dim + 7) & ~7) / 8;
     const int nc8p = imk_pass_chunks(nc8), nsp = (T * nc8p + 3) / 4;
     const int ns = imk_cdiv_d(nc8, nc8p) * nsp;
@@ -1111,13 +1147,13 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8, bool CHAIN>
-static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
+template <int LM, int NC8, bool CHAIN, bool PAIR>
+static int launch_conv_pipe_p(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float);
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8, CHAIN>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8, CHAIN, PAIR>, 256, lds) != hipSuccess || nb < 1) nb = 4;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
@@ -1132,7 +1168,7 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    conv_pipe_kernel<LM, NC8, CHAIN><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
+    conv_pipe_kernel<LM, NC8, CHAIN, PAIR><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
                                                           1.0f / (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -1141,6 +1177,11 @@ static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
         g_prof.push_back(pr);
     }
     return IMK_OK;
+}
+
+template <int LM, int NC8, bool CHAIN>
+static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
+    return a.pair ? launch_conv_pipe_p<LM, NC8, CHAIN, true>(a, stream) : launch_conv_pipe_p<LM, NC8, CHAIN, false>(a, stream);
 }
 
 template <int NC8, bool CHAIN>
@@ -1155,16 +1196,30 @@ static int launch_conv_pipe_lm(const ImkConvArgs &a, hipStream_t stream) {
     }
 }
 
+static bool pipe_enabled() {
+    static const bool on = []() { const char *e = getenv("IMK_CONV_PIPE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static bool pair_enabled() {
+    static const bool on = []() { const char *e = getenv("IMK_CONV_PAIR"); return !(e && e[0] == '0'); }();
+    return on && pipe_enabled();
+}
+
+bool imk_conv_pair_layout(int k_in, int m_out, bool u8_input) {
+    return pair_enabled() && imk_pad8(k_in) <= 16 && m_out <= 8 && (!u8_input || k_in <= 4);
+}
+
 bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     static const bool off = []() { const char *e = getenv("IMK_CONV_CHAIN"); return e && e[0] == '0'; }();
-    const char *e = getenv("IMK_CONV_PIPE");
-    if (off || (e && e[0] == '0')) return false;
+    if (off || !pipe_enabled()) return false;
+    if (pair_enabled() && a.cout <= 8 && cout2 > 8) return false;   // the two stages must use the same fragment layout
     return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
 
 static bool g_use_pipe = true;   // IMK_CONV_PIPE=0 in the environment falls back to the per-tile kernel (A/B runs)
 
-int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream) {
+int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
+    ImkConvArgs a = a_in;
     IMK_CHECK_ARG(a.x.in && a.wpk && (a.out || a.wpk2) && a.B > 0 && a.H > 0 && a.W > 0);
     IMK_CHECK_ARG(a.ksize == 1 || a.ksize == 3);
     IMK_CHECK_ARG(a.x.cs_in % 8 == 0 && a.cs_out % 8 == 0 && a.x.cs_in >= a.x.cin && a.cs_out >= a.cout);
@@ -1173,6 +1228,8 @@ int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream) {
     static const bool env_checked = []() { const char *e = getenv("IMK_CONV_PIPE"); if (e && e[0] == '0') g_use_pipe = false; return true; }();
     (void)env_checked;
     const bool pipe_ok = g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
+    a.pair = pipe_ok && pair_enabled() && a.cout <= 8;   // must mirror imk_conv_pair_layout
+    if (a.wpk2 && a.pair && a.cout2 > 8) return IMK_EUNSUPPORTED;
     if (a.wpk2) {   // fused second stage: only the pipelined kernel implements it (callers check imk_conv_can_chain)
         if (!pipe_ok || a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cout2 > 16 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
         if (a.x.cs_in == 8) return launch_conv_pipe_lm<1, true>(a, stream);
@@ -1249,11 +1306,12 @@ int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int 
     return IMK_OK;
 }
 
-size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed) {
+size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool pair) {
     if (transposed == 2) return 512;
     const int T = ksize == 3 ? 9 : 1;
     const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
     const int nc8 = imk_pad8(k_dim) / 8;
+    if (pair) return (size_t)((T * nc8 + 1) / 2) * 512;
     const int nc8p = imk_pass_chunks(nc8);
     const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
     return (size_t)((m_dim + 15) / 16) * ns * 512;
@@ -1265,7 +1323,7 @@ int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int trans
     const int nc8 = imk_pad8(k_dim) / 8;
     const int nc8p = imk_pass_chunks(nc8);
     const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
-    const int total = (int)imk_packed_conv_halfs(ksize, cin, cout, transposed);
+    const int total = (int)imk_packed_conv_halfs(ksize, cin, cout, transposed, false);
     pack_conv_kernel<<<imk_cdiv(total, 256), 256, 0, stream>>>(w, T, cin, cout, transposed, m_dim, k_dim, nc8, ns, total, dst);
     IMK_LAUNCH_CHECK();
     return IMK_OK;

@@ -48,6 +48,7 @@ struct ImkConvArgs {
     float *stats_partial;  // optional: [rows][2*cs] (EP_RELU: sum, sumsq of the fp16-rounded outputs)
     int *stats_rows;       // host, optional: receives the number of partial rows this launch writes
     int epi;
+    int pair;              // set by imk_launch_conv: weights are in the pair layout (imk_conv_pair_layout)
 };
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize);  // rows of stats_partial
 int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream);
@@ -72,12 +73,16 @@ int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int 
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
 bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
-size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed);
+// "Pair" fragment layout (see conv_pipe_kernel): used by every conv operand with <= 8 output channels that the
+// pipelined kernel runs (<= 16 input channels, u8 input with <= 4 channels).  k_in / m_out are the operand's own input /
+// output channel counts (forward: cin / cout, dgrad: cout / cin; chain: both must be <= 8).
+bool imk_conv_pair_layout(int k_in, int m_out, bool u8_input);
+size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool pair);
 int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream);
 
 // batched variant: up to IMK_PACK_MAX_JOBS (layer, direction) jobs per launch, table passed by value
 #define IMK_PACK_MAX_JOBS 32
-struct ImkPackJob { const float *w; f16 *dst; int ksize, cin, cout, transposed; };
+struct ImkPackJob { const float *w; f16 *dst; int ksize, cin, cout, transposed, pair; };
 struct ImkPackJobs { ImkPackJob j[IMK_PACK_MAX_JOBS]; int n; };
 int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream);
 

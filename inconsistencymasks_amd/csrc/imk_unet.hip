@@ -70,8 +70,9 @@ void build_layers(imk_unet_plan *p) {
     size_t pk = 0;
     for (auto &l : p->layers) {
         if (l.kind == 0) {
-            l.pk_bytes_fwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 0) * 2;
-            l.pk_bytes_bwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 1) * 2;
+            const bool u8 = (&l == &p->layers[0]);   // the stem reads the uint8 image
+            l.pk_bytes_fwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 0, imk_conv_pair_layout(l.cin, l.cout, u8)) * 2;
+            l.pk_bytes_bwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 1, imk_conv_pair_layout(l.cout, l.cin, false)) * 2;
             l.pk_fwd = (int64_t)pk; pk = up(pk + l.pk_bytes_fwd);
             l.pk_bwd = (int64_t)pk; pk = up(pk + l.pk_bytes_bwd);
             l.pk_chain = -1;
@@ -404,7 +405,9 @@ extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *par
                 if (tr == 0 && (int)i == out_idx) continue;   // the head runs in fp32 from `params` directly
                 if (tr == 2 && (l.pk_chain < 0 || (int)i == out_idx)) continue;
                 f16 *dst = (f16 *)(pk + (tr == 2 ? l.pk_chain : (tr ? l.pk_bwd : l.pk_fwd)));
-                pj.j[pj.n++] = ImkPackJob{params + l.off_w, dst, l.ksize, l.cin, l.cout, tr};
+                const int pair = tr == 2 ? (imk_conv_pair_layout(l.cin, l.cout, false) && l.cin <= 8)
+                                         : (tr ? imk_conv_pair_layout(l.cout, l.cin, false) : imk_conv_pair_layout(l.cin, l.cout, i == 0));
+                pj.j[pj.n++] = ImkPackJob{params + l.off_w, dst, l.ksize, l.cin, l.cout, tr, pair};
                 if (pj.n == IMK_PACK_MAX_JOBS) { int rc = flush_pack(); if (rc) return rc; }
             }
         } else {
