@@ -419,7 +419,19 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 // pairs of row A, g = 2,3 the same pairs of row B; weight rows 0-7 are non-zero only in the first half, rows 8-15 (the
 // same 8 output channels again) only in the second.  D rows 0-7 are then row A's channels, rows 8-15 row B's: every
 // lane owns 4 channels of one pixel and the epilogue runs with all 64 lanes instead of 32.
-template <int LM, int NC8, bool CHAIN, bool PAIR>
+//
+// Memory pipeline.  gfx950 returns vector-memory results in issue order and counts loads and stores in one counter
+// (vmcnt), and the compiler can only wait for "all but the N youngest" when N is the same on every path.  So inside the
+// loop every global access is unconditional and their number per iteration is a compile-time constant:
+//   * out-of-image halo pixels and idle staging slots load a clamped in-image address and are zeroed at staging time;
+//   * the prefetch of the last iteration re-reads the current tile;
+//   * the epilogue kind (EPI, DYSTAT), the chain's intermediate store (CHAIN = 2: none) and full tiles (FULL: H and W
+//     multiples of 16 and every lane owning real output channels, so no guard around any store) are template
+//     parameters, and the epilogue's own loads (ReLU mask, BN output z) are issued BEFORE the prefetch.
+// With that the waits become vmcnt(#prefetch loads) before the epilogue and vmcnt(#stores) before staging, i.e. the
+// prefetch stays in flight across the MFMAs and the epilogue and the stores across the next staging.
+// CHAIN: 0 none, 1 chained 1x1 with the intermediate stored (training), 2 chained, intermediate not stored (inference).
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         float inv_tx, float inv_pi) {
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
@@ -462,20 +474,22 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     int base[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) base[p] = (tile_row(p) * WT + n) * PS * 16;
-    // this thread's staging items (constant over tiles): LDS offset and position inside the halo tile
+    // this thread's staging items (constant over tiles): LDS offset and position inside the halo tile.  Idle slots
+    // (beyond the tile's item count) repeat slot 0's pixel, so that their (unconditional) load is a cache hit.
     int it_lds[MAX_ITEMS], it_py[MAX_ITEMS], it_px[MAX_ITEMS], it_c8[MAX_ITEMS];
 #pragma unroll
     for (int k = 0; k < MAX_ITEMS; ++k) {
         const int i = t + 256 * k;
-        const int pix = i / NC8;
-        it_c8[k] = i - pix * NC8;
+        const bool live = i < n_items;
+        const int pix = (live ? i : t % n_items) / NC8;
+        it_c8[k] = (live ? i : t % n_items) - pix * NC8;
         it_py[k] = pix / WT;
         it_px[k] = pix - it_py[k] * WT;
-        it_lds[k] = (i < n_items) ? (pix * PS + it_c8[k]) * 16 : -1;
+        it_lds[k] = live ? (pix * PS + it_c8[k]) * 16 : -1;
     }
     float bias[4] = {0, 0, 0, 0}, bias2[4] = {0, 0, 0, 0};
     const int co0 = PAIR ? 4 * (g & 1) : 4 * g;
-    if (a.epi == EP_RELU && a.bias)
+    if (EPI == EP_RELU && a.bias)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
     f16x8 af2 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -484,8 +498,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias2[r] = (co0 + r < a.cout2) ? a.bias2[co0 + r] : 0.f;
     }
-    const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
-    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
+    const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);
+    // FULL also promises that every lane owns real channels (PAIR, or 16-channel outputs): no guard around any store
+    const bool lane_out = FULL || co0 < (CHAIN ? a.cs_out2 : a.cs_out);   // this lane's 4 channels exist in the output tensor
+    const bool lane_mid = FULL || co0 < a.cs_out;                          // ... in the chain's intermediate
 
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // BN statistics, accumulated over all tiles of this workgroup
     RawChunk<LM> raw[MAX_ITEMS];
@@ -496,51 +512,49 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
             const int y = tc.ty0 + it_py[k] - halo, x = tc.tx0 + it_px[k] - halo;
-            if (it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
-                raw_load<LM>(a.x, tc.b, y, x, H, W, it_c8[k], raw[k]);
-                valid |= 1u << k;
-            }
+            const bool ok = it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+            raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
+            valid |= (ok ? 1u : 0u) << k;
         }
     };
 
     int tile = blockIdx.x;
-    if (tile < n_tiles) issue(tile);
-    __syncthreads();  // affine table visible
+    issue(tile < n_tiles ? tile : n_tiles - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in; nothing older is pending in the loop
+    __syncthreads();                      // affine table visible
     while (tile < n_tiles) {
         // registers -> LDS (BN / pool / up+add / u8 conversion applied here)
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
             if (it_lds[k] >= 0) {
-                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (valid & (1u << k)) v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
+                f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
+                if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
             }
         }
         const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
         const int x = tc.tx0 + n;
         __syncthreads();
+        // output pixel of each column block; partial tiles clamp the coordinates used for LOADS (stores are guarded)
+        size_t pix[P];
+        bool inb[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int y = tc.ty0 + tile_row(p);
+            inb[p] = FULL || (y < H && x < W);
+            pix[p] = (size_t)(tc.b * H + (FULL ? y : min(y, H - 1))) * W + (FULL ? x : min(x, W - 1));
+        }
+        f16x4 mk[P], zq[P];
+        if (EPI == EP_MASK) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+        }
+        if (DYSTAT) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+        }
         const int next = tile + gridDim.x;
-        if (next < n_tiles) issue(next);          // in flight during the MFMAs and stores below
-        f16x4 mk[P];
-        if (a.epi == EP_MASK) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + tile_row(p);
-                mk[p] = f16x4{0, 0, 0, 0};
-                if (y < H && x < W && co0 < a.cs_out)
-                    mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
-            }
-        }
-        f16x4 zq[P];
-        if (dystat) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + tile_row(p);
-                zq[p] = f16x4{0, 0, 0, 0};
-                if (y < H && x < W && co0 < a.cs_out)
-                    zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0);
-            }
-        }
+        issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
         f32x4 acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = f32x4{0, 0, 0, 0};
@@ -555,54 +569,49 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             }
         }
         if (CHAIN) {
-            // stage 1: h = relu(acc + b) in fp16 (stored only if the caller wants it); stage 2 on the register tile:
+            // stage 1: h = relu(acc + b) in fp16 (stored only in training); stage 2 on the register tile:
             // the lane's 4 channels of pixel n are exactly k-slots (g, 0..3) of the next MFMA's B operand.
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + tile_row(p);
-                const bool inb = (y < H) && (x < W);
                 f16x4 hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hv[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
-                const size_t pix = (size_t)(tc.b * H + y) * W + x;
-                if (a.out && inb && co0 < a.cs_out) *reinterpret_cast<f16x4 *>(a.out + pix * a.cs_out + co0) = hv;
+                if (CHAIN == 1 && (FULL || inb[p]) && lane_mid) *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + co0) = hv;
                 const f16x8 bf2 = {hv[0], hv[1], hv[2], hv[3], 0, 0, 0, 0};
                 const f32x4 a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2, bf2, f32x4{0, 0, 0, 0}, 0, 0, 0);
-                if (inb && co0 < a.cs_out2) {
-                    f16x4 v;
+                f16x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(a2[r] + bias2[r], 0.f);
-                    *reinterpret_cast<f16x4 *>(a.out2 + pix * a.cs_out2 + co0) = v;
+                for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(a2[r] + bias2[r], 0.f);
+                if ((FULL || inb[p]) && lane_out) {
+                    *reinterpret_cast<f16x4 *>(a.out2 + pix[p] * a.cs_out2 + co0) = v;
                     if (want_stats)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
                 }
             }
-        } else
-        if (co0 < a.cs_out) {
+        } else {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int y = tc.ty0 + tile_row(p);
-                if (y >= H || x >= W) continue;
-                const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0;
                 f16x4 v;
-                if (a.epi == EP_RELU) {
+                if (EPI == EP_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
-                } else if (a.epi == EP_MASK) {
+                } else if (EPI == EP_MASK) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = ((float)mk[p][r] > 0.f) ? (f16)acc[p][r] : (f16)0.f;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (f16)acc[p][r];
                 }
-                *reinterpret_cast<f16x4 *>(a.out + o) = v;
-                if (dystat) {
+                if ((FULL || inb[p]) && lane_out) {
+                    *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + co0) = v;
+                    if (DYSTAT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * (float)zq[p][r]; }
-                } else if (want_stats) {
+                        for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * (float)zq[p][r]; }
+                    } else if (want_stats) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                        for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                    }
                 }
             }
         }
@@ -1147,13 +1156,14 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8, bool CHAIN, bool PAIR>
-static int launch_conv_pipe_p(const ImkConvArgs &a, hipStream_t stream) {
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
+static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float);
+    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL>;
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pipe_kernel<LM, NC8, CHAIN, PAIR>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 4;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
@@ -1168,8 +1178,7 @@ static int launch_conv_pipe_p(const ImkConvArgs &a, hipStream_t stream) {
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    conv_pipe_kernel<LM, NC8, CHAIN, PAIR><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x,
-                                                          1.0f / (tiles_x * tiles_y));
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x, 1.0f / (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     if (prof) {
@@ -1179,21 +1188,50 @@ static int launch_conv_pipe_p(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8, bool CHAIN>
-static int launch_conv_pipe(const ImkConvArgs &a, hipStream_t stream) {
-    return a.pair ? launch_conv_pipe_p<LM, NC8, CHAIN, true>(a, stream) : launch_conv_pipe_p<LM, NC8, CHAIN, false>(a, stream);
+// Forward convs (EP_RELU): every load mode but BNBWD, optionally chained.  Gradient convs (EP_PLAIN / EP_MASK, with or
+// without the BN-gradient statistics): input is a raw gradient or a BN backward on load; never chained.
+template <int NC8, bool PAIR, bool FULL>
+static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
+    if (a.epi == EP_RELU) {
+        const int chain = a.wpk2 ? (a.out ? 1 : 2) : 0;
+#define IMK_PIPE_FWD(LM)                                                                              \
+        (chain == 0 ? launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_RELU, false, FULL>(a, stream)           \
+         : chain == 1 ? launch_conv_pipe_k<LM, NC8, 1, PAIR, EP_RELU, false, FULL>(a, stream)         \
+                      : launch_conv_pipe_k<LM, NC8, 2, PAIR, EP_RELU, false, FULL>(a, stream))
+        switch (a.x.lmode) {
+            case LM_RAW: return IMK_PIPE_FWD(LM_RAW);
+            case LM_AFFINE: return IMK_PIPE_FWD(LM_AFFINE);
+            case LM_POOL: return IMK_PIPE_FWD(LM_POOL);
+            case LM_UPADD: return IMK_PIPE_FWD(LM_UPADD);
+            case LM_U8: return IMK_PIPE_FWD(LM_U8);
+            default: return IMK_EUNSUPPORTED;
+        }
+#undef IMK_PIPE_FWD
+    }
+    if (a.wpk2) return IMK_EUNSUPPORTED;
+    const bool dystat = a.dystat_z && a.stats_partial;
+#define IMK_PIPE_BWD(LM)                                                                                         \
+    (a.epi == EP_MASK ? (dystat ? launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_MASK, true, FULL>(a, stream)           \
+                                : launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_MASK, false, FULL>(a, stream))         \
+                      : (dystat ? launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_PLAIN, true, FULL>(a, stream)          \
+                                : launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_PLAIN, false, FULL>(a, stream)))
+    switch (a.x.lmode) {
+        case LM_RAW: return IMK_PIPE_BWD(LM_RAW);
+        case LM_BNBWD: return IMK_PIPE_BWD(LM_BNBWD);
+        default: return IMK_EUNSUPPORTED;
+    }
+#undef IMK_PIPE_BWD
 }
 
-template <int NC8, bool CHAIN>
-static int launch_conv_pipe_lm(const ImkConvArgs &a, hipStream_t stream) {
-    switch (a.x.lmode) {
-        case LM_RAW: return launch_conv_pipe<LM_RAW, NC8, CHAIN>(a, stream);
-        case LM_AFFINE: return launch_conv_pipe<LM_AFFINE, NC8, CHAIN>(a, stream);
-        case LM_POOL: return launch_conv_pipe<LM_POOL, NC8, CHAIN>(a, stream);
-        case LM_UPADD: return launch_conv_pipe<LM_UPADD, NC8, CHAIN>(a, stream);
-        case LM_BNBWD: return launch_conv_pipe<LM_BNBWD, NC8, CHAIN>(a, stream);
-        default: return launch_conv_pipe<LM_U8, NC8, CHAIN>(a, stream);
-    }
+static int launch_conv_pipe_any(const ImkConvArgs &a, hipStream_t stream) {
+    const bool all_ch = a.pair || (a.cs_out == 16 && (!a.wpk2 || a.cs_out2 == 16));
+    const bool full = (a.H % 16 == 0) && (a.W % TW == 0) && all_ch;
+    const bool nc1 = a.x.cs_in == 8;
+#define IMK_PIPE_SEL(NC8)                                                                                   \
+    (a.pair ? (full ? launch_conv_pipe_v<NC8, true, true>(a, stream) : launch_conv_pipe_v<NC8, true, false>(a, stream)) \
+            : (full ? launch_conv_pipe_v<NC8, false, true>(a, stream) : launch_conv_pipe_v<NC8, false, false>(a, stream)))
+    return nc1 ? IMK_PIPE_SEL(1) : IMK_PIPE_SEL(2);
+#undef IMK_PIPE_SEL
 }
 
 static bool pipe_enabled() {
@@ -1232,13 +1270,9 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     if (a.wpk2 && a.pair && a.cout2 > 8) return IMK_EUNSUPPORTED;
     if (a.wpk2) {   // fused second stage: only the pipelined kernel implements it (callers check imk_conv_can_chain)
         if (!pipe_ok || a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cout2 > 16 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
-        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1, true>(a, stream);
-        return launch_conv_pipe_lm<2, true>(a, stream);
+        return launch_conv_pipe_any(a, stream);
     }
-    if (pipe_ok) {
-        if (a.x.cs_in == 8) return launch_conv_pipe_lm<1, false>(a, stream);
-        return launch_conv_pipe_lm<2, false>(a, stream);
-    }
+    if (pipe_ok) return launch_conv_pipe_any(a, stream);
     if (conv_tile_h(a.x.cs_in, a.ksize) == 16) return launch_conv_th<16>(a, stream);
     return launch_conv_th<8>(a, stream);
 }
