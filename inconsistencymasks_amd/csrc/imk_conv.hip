@@ -152,9 +152,13 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
 // Channel passes: layers with more than 256 input channels (alpha > 1 bottleneck, IM+ at alpha = 2) do not fit one LDS
 // tile; their K dimension is walked in n_pass passes of nc8p chunks (<= 32 chunks = 256 channels), each pass staging its
 // channel slice of the tile and of the packed weights.  k order = (pass, tap, chunk in pass) -- see pack_conv_kernel.
+struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds; };
+
+// bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
 template <int TH, int MT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int mt_total,
-                                                        int nc8, int nc8p, int n_pass, int ps, int nsp, int w_in_lds) {
+__device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkConvGeom &gm, int bx, int by) {
+    const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, mt_total = gm.mt_total, nc8 = gm.nc8, nc8p = gm.nc8p;
+    const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp, w_in_lds = gm.w_in_lds;
     constexpr int P = TH / 4;  // pixel groups (tile rows) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     float *s_aff = reinterpret_cast<float *>(smem + (size_t)HT * WT * ps * 16);
     f16 *s_w = reinterpret_cast<f16 *>(s_aff + 4 * a.x.cs_in);   // [MT][nsp][512] packed weight fragments of one pass
     const int t = threadIdx.x;
-    const TileCoord tc = tile_coord(blockIdx.x, tiles_x, tiles_y, TH);
+    const TileCoord tc = tile_coord(bx, tiles_x, tiles_y, TH);
     const int H = a.H, W = a.W;
     const int ns_total = n_pass * nsp;
 
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
     if (a.x.lmode != LM_RAW && a.x.lmode != LM_U8) __syncthreads();
 
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
-    const int ct0 = blockIdx.y * MT;
+    const int ct0 = by * MT;
     int base[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) base[p] = ((wave * P + p) * WT + n) * ps * 16;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
             const int n16 = MT * nsp * 64;   // 16-byte chunks; a multiple of 64, so the bound is wave-uniform
             for (int i = t; i < n16; i += 256) {
                 const int m = i / (nsp * 64);
-                int ct = blockIdx.y * MT + m;
+                int ct = by * MT + m;
                 if (ct >= mt_total) ct = mt_total - 1;   // padding rows of the last group: outputs are never stored
                 const f16 *src = a.wpk + (((size_t)ct * ns_total + (size_t)pass * nsp) * 64 + (i - m * nsp * 64)) * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -329,10 +333,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, int tiles
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) v += s_red[(w * 2 + which) * 16 * MT + c];
-                a.stats_partial[(size_t)blockIdx.x * 2 * a.cs_out + which * a.cs_out + co] = v;
+                a.stats_partial[(size_t)bx * 2 * a.cs_out + which * a.cs_out + co] = v;
             }
         }
     }
+}
+
+template <int TH, int MT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGeom gm) {
+    conv_mfma_body<TH, MT>(a, gm, blockIdx.x, blockIdx.y);
 }
 
 // =====================================================================================================
@@ -506,8 +515,21 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // BN statistics, accumulated over all tiles of this workgroup
     RawChunk<LM> raw[MAX_ITEMS];
     unsigned valid = 0;
+    // uint8 image, full 16 x 16 tiles of a 1x1 conv (the stem): a tile row is 16 * cin contiguous bytes = cin aligned
+    // 16-byte segments, so 16 * cin threads fetch the whole tile with one wide load each (instead of cin byte loads
+    // per pixel and thread); the bytes go through LDS to the pixel that owns them.
+    constexpr bool U8ROWS = (LM == LM_U8) && FULL;
+    uint8_t *s_u8 = reinterpret_cast<uint8_t *>(s_red + 4 * 2 * 16);   // [16 rows][cin * 16 bytes], cin <= 4
+    uint4 rowseg = {0, 0, 0, 0};
+    const int u8_cin = a.x.cin, u8_nseg = 16 * u8_cin;
+    const int u8_t = t < u8_nseg ? t : 0;                 // idle threads repeat segment 0 (loads are unconditional)
+    const int u8_row = u8_t / u8_cin, u8_seg = u8_t - u8_row * u8_cin;
     auto issue = [&](int tile) {
         const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
+        if constexpr (U8ROWS) {
+            rowseg = *reinterpret_cast<const uint4 *>((const uint8_t *)a.x.in + ((size_t)(tc.b * H + tc.ty0 + u8_row) * W + tc.tx0) * u8_cin + u8_seg * 16);
+            return;
+        }
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
@@ -524,12 +546,22 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     __syncthreads();                      // affine table visible
     while (tile < n_tiles) {
         // registers -> LDS (BN / pool / up+add / u8 conversion applied here)
+        if constexpr (U8ROWS) {
+            if (t < u8_nseg) *reinterpret_cast<uint4 *>(s_u8 + t * 16) = rowseg;
+            __syncthreads();
+            const uint8_t *pb = s_u8 + (t >> 4) * u8_nseg + (t & 15) * u8_cin;   // pixel t of the tile
+            f16x8 v;
 #pragma unroll
-        for (int k = 0; k < MAX_ITEMS; ++k) {
-            if (it_lds[k] >= 0) {
-                f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
-                if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
+            for (int j = 0; j < 8; ++j) v[j] = (f16)((j < 4 && j < u8_cin) ? (float)pb[j] / 255.0f : 0.0f);
+            *reinterpret_cast<f16x8 *>(s_tile + it_lds[0]) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAX_ITEMS; ++k) {
+                if (it_lds[k] >= 0) {
+                    f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
+                    if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
+                }
             }
         }
         const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
@@ -646,9 +678,14 @@ constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 
 
 // LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
 // tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
+struct ImkWgradGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco; };
+
+// bx = split (walks tiles bx, bx + nbx, ...), by = (input-channel tile, output-channel tile) pair of nby
 template <int LM>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int tiles_x, int tiles_y, int n_tiles,
-                                                         int cit_n, int cot_n, int nc8_in, int nc8_out) {
+__device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const ImkWgradGeom &gm, int bx, int by, int nbx, int nby) {
+    const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, n_tiles = gm.n_tiles, cit_n = gm.cit_n, cot_n = gm.cot_n;
+    const int nc8_in = gm.nci, nc8_out = gm.nco;
+    (void)tiles_y; (void)cit_n;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
@@ -658,7 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
     f16 *s_d = s_x + 18 * 18 * WG_STRIDE_H;
     float *s_aff = reinterpret_cast<float *>(s_d + 256 * WG_STRIDE_H);
     const int t = threadIdx.x;
-    const int pair = blockIdx.y;
+    const int pair = by;
     const int cit = pair / cot_n, cot = pair - cit * cot_n;
     const int H = a.H, W = a.W;
     const int lane = t & 63, wave = t >> 6, g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
@@ -725,7 +762,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
         }
     };
 
-    int tile = blockIdx.x;
+    int tile = bx;
     if (tile < n_tiles) issue(tile);
     __syncthreads();   // affine table visible
     while (tile < n_tiles) {
@@ -754,7 +791,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
             *reinterpret_cast<f16x8 *>(s_d + d_lds[k]) = v;
         }
         __syncthreads();
-        const int next = tile + gridDim.x;
+        const int next = tile + nbx;
         if (next < n_tiles) issue(next);     // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -794,12 +831,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, int til
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_acc[(wave * 10 + i) * 256 + r * 64 + lane] = acc[i][r];
     __syncthreads();
-    float *dst = a.partial + ((size_t)blockIdx.x * gridDim.y + pair) * (T + 1) * 256;
+    float *dst = a.partial + ((size_t)bx * nby + pair) * (T + 1) * 256;
     for (int i = 0; i <= T; ++i) {
         const int src = (i == T) ? 9 : i;
         dst[i * 256 + t] = s_acc[(0 * 10 + src) * 256 + t] + s_acc[(1 * 10 + src) * 256 + t] +
                            s_acc[(2 * 10 + src) * 256 + t] + s_acc[(3 * 10 + src) * 256 + t];
     }
+}
+
+template <int LM>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgradGeom gm) {
+    wgrad_mfma_body<LM>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // stage 1 of the deterministic split reduction: [n_split][n_tiles][256] -> [n_chunks][n_tiles][256],
@@ -1097,8 +1139,11 @@ extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
     return IMK_OK;
 }
 
-template <int TH>
-static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
+// Launch geometry of the per-tile kernel for one conv.
+struct ConvLaunch { ImkConvGeom gm; int th, mt; int gx, gy; size_t lds; };
+
+static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
+    const int TH = conv_tile_h(a.x.cs_in, a.ksize);
     const int halo = a.ksize == 3 ? 1 : 0;
     const int nc8 = a.x.cs_in / 8;
     const int nc8p = imk_pass_chunks(nc8), n_pass = imk_cdiv_d(nc8, nc8p);
@@ -1121,33 +1166,47 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
     int w_in_lds = 0;
     while (true) {
         const size_t wbytes = (size_t)mt * nsp * 1024;
-        if (wbytes <= 64 * 1024 && lds_base + wbytes <= 150 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
+        if (wbytes <= 80 * 1024 && lds_base + wbytes <= 150 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
         if (mt > 1) { mt >>= 1; continue; }
         break;
     }
     if (nsp * n_pass <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
-    dim3 grid(n_sp, imk_cdiv(mt_total, mt));
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
+    L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds};
+    L.th = TH; L.mt = mt; L.gx = n_sp; L.gy = imk_cdiv(mt_total, mt); L.lds = lds;
+    return IMK_OK;
+}
+
+template <typename K>
+static int set_lds_limit(K kern, size_t lds) {
+    if (lds > 64 * 1024)  // above the default dynamic-LDS limit: opt in (idempotent, no sync)
+        IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return IMK_OK;
+}
+
+static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
+    ConvLaunch L{};
+    int rc = plan_conv_mfma(a, L);
+    if (rc) return rc;
+    const dim3 grid(L.gx, L.gy);
     auto launch = [&](auto kern) -> int {
-        if (lds > 64 * 1024)  // above the default dynamic-LDS limit: opt in (idempotent, no sync)
-            IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds);
+        int r = set_lds_limit(kern, L.lds);
+        if (r) return r;
+        kern<<<grid, 256, L.lds, stream>>>(a, L.gm);
         return IMK_OK;
     };
     ProfRec pr{};
     const bool prof = prof_sample();
     if (prof) {
         pr.e0 = prof_event(); pr.e1 = prof_event();
-        pr.variant = (TH == 8 ? 3 : 0) + (mt == 4 ? 2 : (mt == 2 ? 1 : 0));
+        pr.variant = (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0));
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    int rc;
-    if (mt == 4) rc = launch(conv_mfma_kernel<TH, 4>);
-    else if (mt == 2) rc = launch(conv_mfma_kernel<TH, 2>);
-    else rc = launch(conv_mfma_kernel<TH, 1>);
+    if (L.th == 16) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4>) : (L.mt == 2 ? launch(conv_mfma_kernel<16, 2>) : launch(conv_mfma_kernel<16, 1>));
+    else rc = L.mt == 4 ? launch(conv_mfma_kernel<8, 4>) : (L.mt == 2 ? launch(conv_mfma_kernel<8, 2>) : launch(conv_mfma_kernel<8, 1>));
     if (rc) return rc;
-    if (a.stats_rows) *a.stats_rows = n_sp;
+    if (a.stats_rows) *a.stats_rows = L.gx;
     if (prof) {
         IMK_HIP(hipEventRecord(pr.e1, stream));
         g_prof.push_back(pr);
@@ -1159,7 +1218,7 @@ static int launch_conv_th(const ImkConvArgs &a, hipStream_t stream) {
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float);
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float) + 1024;   // tile, affine table, statistics, u8 rows
     auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL>;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -1225,7 +1284,8 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
 
 static int launch_conv_pipe_any(const ImkConvArgs &a, hipStream_t stream) {
     const bool all_ch = a.pair || (a.cs_out == 16 && (!a.wpk2 || a.cs_out2 == 16));
-    const bool full = (a.H % 16 == 0) && (a.W % TW == 0) && all_ch;
+    const bool u8_ok = a.x.lmode != LM_U8 || (a.ksize == 1 && ((uintptr_t)a.x.in & 15) == 0);   // FULL + u8: row-segment loads
+    const bool full = (a.H % 16 == 0) && (a.W % TW == 0) && all_ch && u8_ok;
     const bool nc1 = a.x.cs_in == 8;
 #define IMK_PIPE_SEL(NC8)                                                                                   \
     (a.pair ? (full ? launch_conv_pipe_v<NC8, true, true>(a, stream) : launch_conv_pipe_v<NC8, true, false>(a, stream)) \
@@ -1273,8 +1333,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
         return launch_conv_pipe_any(a, stream);
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
-    if (conv_tile_h(a.x.cs_in, a.ksize) == 16) return launch_conv_th<16>(a, stream);
-    return launch_conv_th<8>(a, stream);
+    return launch_conv_mfma(a, stream);
 }
 
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout) {
@@ -1293,28 +1352,35 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
     return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch
 }
 
-int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
+struct WgradLaunch { ImkWgradGeom gm; int gx, gy; size_t lds; };
+
+static int plan_wgrad(const ImkWgradArgs &a, WgradLaunch &L) {
     IMK_CHECK_ARG(a.x.in && a.dA && a.partial && a.B > 0 && a.H > 0 && a.W > 0 && a.n_split > 0);
     IMK_CHECK_ARG(a.ksize == 1 || a.ksize == 3);
     IMK_CHECK_ARG(a.x.cs_in % 8 == 0 && a.cs_out % 8 == 0);
-    const int halo = a.ksize == 3 ? 1 : 0;
+    if (a.x.lmode == LM_BNBWD) return IMK_EUNSUPPORTED;   // the x side of a wgrad is always a forward tensor
+    if (a.x.lmode == LM_U8 && a.x.cin > 4) return IMK_EUNSUPPORTED;
     const int cit_n = (a.x.cs_in + 15) / 16, cot_n = (a.cs_out + 15) / 16;
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
-    const int n_tiles = a.B * tiles_x * tiles_y;
-    (void)halo;
     size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + (4 * (size_t)a.x.cs_in + 3 * (size_t)a.cs_out) * sizeof(float);
     const size_t red = 4 * 10 * 256 * sizeof(float);
     if (lds < red) lds = red;
-    dim3 grid(a.n_split, cit_n * cot_n);
-    if (a.x.lmode == LM_U8 && a.x.cin > 4) return IMK_EUNSUPPORTED;
-    const int nci = a.x.cs_in / 8, nco = a.cs_out / 8;
+    L.gm = ImkWgradGeom{tiles_x, tiles_y, a.B * tiles_x * tiles_y, cit_n, cot_n, a.x.cs_in / 8, a.cs_out / 8};
+    L.gx = a.n_split; L.gy = cit_n * cot_n; L.lds = lds;
+    return IMK_OK;
+}
+
+int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
+    WgradLaunch L{};
+    int rc = plan_wgrad(a, L);
+    if (rc) return rc;
+    const dim3 grid(L.gx, L.gy);
     switch (a.x.lmode) {
-        case LM_RAW: wgrad_mfma_kernel<LM_RAW><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
-        case LM_AFFINE: wgrad_mfma_kernel<LM_AFFINE><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
-        case LM_POOL: wgrad_mfma_kernel<LM_POOL><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
-        case LM_UPADD: wgrad_mfma_kernel<LM_UPADD><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
-        case LM_BNBWD: return IMK_EUNSUPPORTED;   // the x side of a wgrad is always a forward tensor
-        default: wgrad_mfma_kernel<LM_U8><<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco); break;
+        case LM_RAW: wgrad_mfma_kernel<LM_RAW><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
+        case LM_AFFINE: wgrad_mfma_kernel<LM_AFFINE><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
+        case LM_POOL: wgrad_mfma_kernel<LM_POOL><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
+        case LM_UPADD: wgrad_mfma_kernel<LM_UPADD><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
+        default: wgrad_mfma_kernel<LM_U8><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
     }
     IMK_LAUNCH_CHECK();
     return IMK_OK;

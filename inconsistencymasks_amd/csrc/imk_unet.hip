@@ -522,10 +522,9 @@ struct Bwd {
     // dgrad of `conv` -> dst, optionally masked by the ReLU of the tensor `mask`.  If dst is the output gradient of
     // a BatchNorm whose only gradient source this is (stat_bn >= 0), the kernel also emits that BN's backward
     // statistics (sum dy, sum dy*z), which saves the separate reduction pass.
-    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+    void dgrad_args(int conv, f16 *dst, const f16 *mask, int stat_bn, int *rows, ImkConvArgs &a) const {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
-        ImkConvArgs a{};
         grad_input(conv, a.x);
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
         a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
@@ -533,19 +532,46 @@ struct Bwd {
         a.out = dst;
         a.mask = mask;
         a.epi = mask ? EP_MASK : EP_PLAIN;
-        int rows = 0;
         if (stat_bn >= 0) {
             a.dystat_z = c.act(bn_producer(c.t, stat_bn));
             a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[stat_bn].bwd_partial);
-            a.stats_rows = &rows;
+            a.stats_rows = rows;
         }
-        int rc = imk_launch_conv(a, c.stream);
-        if (rc) return rc;
+    }
+    int dgrad_done(int stat_bn, int rows) {
         if (stat_bn >= 0) {
             if (rows <= 0 || rows > c.ws.L[stat_bn].n_bwd_rows) return IMK_EWORKSPACE;
             dy_rows[stat_bn] = rows;
         }
         return IMK_OK;
+    }
+    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        ImkConvArgs a{};
+        int rows = 0;
+        dgrad_args(conv, dst, mask, stat_bn, &rows, a);
+        int rc = imk_launch_conv(a, c.stream);
+        if (rc) return rc;
+        return dgrad_done(stat_bn, rows);
+    }
+    void wgrad_args(int conv, const f16 *dA_override, ImkWgradArgs &a) const {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        a.x = conv_input(c, conv, x);
+        if (dA_override) {
+            a.dA = dA_override;
+        } else {
+            ImkInput gi{};
+            grad_input(conv, gi);
+            a.dA = reinterpret_cast<const f16 *>(gi.in);
+            if (gi.lmode == LM_BNBWD) { a.dA_z = reinterpret_cast<const f16 *>(gi.in2); a.dA_coef = gi.sc; }
+        }
+        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+        a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
+        a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
+    }
+    int wgrad_job(int conv, const ImkWgradArgs &a) {
+        const ImkLayer &l = c.p->layers[conv];
+        return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
     }
     // Weight/bias gradient of `conv`: depends only on dA[conv] (just produced on the main stream) and on forward
     // tensors, and nothing downstream in the backward pass depends on it -> fork it onto the side stream.
@@ -563,21 +589,18 @@ struct Bwd {
             used_side = true;
         }
         ImkWgradArgs a{};
-        a.x = conv_input(c, conv, x);
-        if (dA_override) {
-            a.dA = dA_override;
-        } else {
-            ImkInput gi{};
-            grad_input(conv, gi);
-            a.dA = reinterpret_cast<const f16 *>(gi.in);
-            if (gi.lmode == LM_BNBWD) { a.dA_z = reinterpret_cast<const f16 *>(gi.in2); a.dA_coef = gi.sc; }
-        }
-        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
-        a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
-        a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
+        wgrad_args(conv, dA_override, a);
         int rc = imk_launch_wgrad(a, ws);
         if (rc) return rc;
-        return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+        return wgrad_job(conv, a);
+    }
+    // wgrad + dgrad of `conv` (both read its pre-activation gradient).  Running the two as one launch (dgrad blocks and
+    // wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per step), the
+    // common LDS footprint of the fused kernel leaves one workgroup per CU, so the two halves still run back to back.
+    int wgrad_dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        int rc = wgrad(conv);
+        if (rc) return rc;
+        return dgrad(conv, dst, mask, stat_bn);
     }
     // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
     int finish_wgrads() {
@@ -684,29 +707,22 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         f16 *dU = reinterpret_cast<f16 *>(c.base + c.ws.dU[j]);
         if (j == 3) OK(b.bn_bwd(t.d_bnb[j], 0, nullptr, nullptr));
         else OK(b.bn_bwd(t.d_bnb[j], 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[j + 1])));
-        OK(b.wgrad(t.d_c1[j]));
-        OK(b.dgrad(t.d_c1[j], c.dA(t.d_c3[j]), c.act(t.d_c3[j])));
-        OK(b.wgrad(t.d_c3[j]));
-        OK(b.dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr, t.d_bna[j]));
+        OK(b.wgrad_dgrad(t.d_c1[j], c.dA(t.d_c3[j]), c.act(t.d_c3[j])));
+        OK(b.wgrad_dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr, t.d_bna[j]));
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
-        OK(b.wgrad(t.d_ca[j]));
-        OK(b.dgrad(t.d_ca[j], dU, nullptr));
+        OK(b.wgrad_dgrad(t.d_ca[j], dU, nullptr));
     }
     // bottleneck: dy = 2x2 sum of dU[decoder 6]
     OK(b.bn_bwd(t.b_bn, 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[0])));
-    OK(b.wgrad(t.b_c1));
-    OK(b.dgrad(t.b_c1, c.dA(t.b_c3), c.act(t.b_c3)));
-    OK(b.wgrad(t.b_c3));
-    OK(b.dgrad(t.b_c3, reinterpret_cast<f16 *>(c.base + c.ws.dP[3]), nullptr));
+    OK(b.wgrad_dgrad(t.b_c1, c.dA(t.b_c3), c.act(t.b_c3)));
+    OK(b.wgrad_dgrad(t.b_c3, reinterpret_cast<f16 *>(c.base + c.ws.dP[3]), nullptr));
     // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
     for (int i = 3; i >= 0; --i) {
         OK(b.bn_bwd(t.e_bn[i], 1, reinterpret_cast<f16 *>(c.base + c.ws.dU[3 - i]),
                     reinterpret_cast<f16 *>(c.base + c.ws.dP[i])));
-        OK(b.wgrad(t.e_c1[i]));
-        OK(b.dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
-        OK(b.wgrad(t.e_c3[i]));
+        OK(b.wgrad_dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
         f16 *dst = i > 0 ? reinterpret_cast<f16 *>(c.base + c.ws.dP[i - 1]) : c.dy(t.in_bn);
-        OK(b.dgrad(t.e_c3[i], dst, nullptr, i > 0 ? -1 : t.in_bn));
+        OK(b.wgrad_dgrad(t.e_c3[i], dst, nullptr, i > 0 ? -1 : t.in_bn));
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));
