@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // =====================================================================================================
 // wgrad
 // =====================================================================================================
-constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 channels + 8 pad = 48 B)
+constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 channels + 8 pad = 48 B; a 32-byte pitch measured the same)
 
 // LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
 // tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
@@ -713,29 +713,37 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (f16)(i16 == 0 ? 1.0f : 0.0f);
 
-    // staging items of this thread (constant over tiles): 3 chunks of the x slice, 2 of the dA slice
+    // staging items of this thread (constant over tiles): up to 3 chunks of the x slice, 2 of the dA slice.  A slice
+    // is 16 channels = 2 chunks per pixel; when the tensor has only one chunk there (8-channel layers: level 0 at
+    // alpha = 0.5, where most of the pixels are), items are pixels, so every thread carries live items and the
+    // always-zero second chunk of the LDS slices is written once, before the loop.
     constexpr int NX = 3, ND = 2;
-    const int n_x = HT * WT * 2;
+    const int cx = min(2, nc8_in - 2 * cit), cd = min(2, nc8_out - 2 * cot);   // live chunks per pixel: 1 or 2
+    const int n_x = HT * WT * cx, n_d = 256 * cd;
     int x_lds[NX], x_py[NX], x_px[NX], x_c8[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int i = t + 256 * k;
-        const int pix = i >> 1;
-        x_c8[k] = 2 * cit + (i & 1);
+        const int pix = cx == 2 ? i >> 1 : i, ch = cx == 2 ? (i & 1) : 0;
+        x_c8[k] = 2 * cit + ch;
         x_py[k] = pix / WT;
         x_px[k] = pix - x_py[k] * WT;
-        x_lds[k] = (i < n_x) ? pix * WG_STRIDE_H + (i & 1) * 8 : -1;
+        x_lds[k] = (i < n_x) ? pix * WG_STRIDE_H + ch * 8 : -1;
     }
     int d_lds[ND], d_py[ND], d_px[ND], d_c8[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
         const int i = t + 256 * k;
-        const int pix = i >> 1;
-        d_c8[k] = 2 * cot + (i & 1);
+        const int pix = cd == 2 ? i >> 1 : i, ch = cd == 2 ? (i & 1) : 0;
+        d_c8[k] = 2 * cot + ch;
         d_py[k] = pix >> 4;
         d_px[k] = pix & 15;
-        d_lds[k] = pix * WG_STRIDE_H + (i & 1) * 8;
+        d_lds[k] = (i < n_d) ? pix * WG_STRIDE_H + ch * 8 : -1;
     }
+    // the dead second chunks read as zeros for every tile (nothing else ever writes them)
+    if (cx < 2)
+        for (int i = t; i < 18 * 18; i += 256) *reinterpret_cast<f16x8 *>(s_x + i * WG_STRIDE_H + 8) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (cd < 2) *reinterpret_cast<f16x8 *>(s_d + t * WG_STRIDE_H + 8) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     RawChunk<LM> xr[NX];
     f16x8 dr[ND], dz[ND];
     unsigned vx = 0, vd = 0;
@@ -745,7 +753,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int y = tc.ty0 + x_py[k] - halo, x = tc.tx0 + x_px[k] - halo;
-            if (x_lds[k] >= 0 && x_c8[k] < nc8_in && y >= 0 && y < H && x >= 0 && x < W) {
+            if (x_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
                 raw_load<LM>(a.x, tc.b, y, x, H, W, x_c8[k], xr[k]);
                 vx |= 1u << k;
             }
@@ -753,7 +761,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             const int y = tc.ty0 + d_py[k], x = tc.tx0 + d_px[k];
-            if (d_c8[k] < nc8_out && y < H && x < W) {
+            if (d_lds[k] >= 0 && y < H && x < W) {
                 const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + d_c8[k] * 8;
                 dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + o);
                 if (bnbwd) dz[k] = *reinterpret_cast<const f16x8 *>(a.dA_z + o);
@@ -776,6 +784,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
+            if (d_lds[k] < 0) continue;
             f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (vd & (1u << k)) {
                 v = dr[k];
@@ -1339,7 +1348,8 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout) {
     const int n_tiles = B * imk_cdiv(H, 16) * imk_cdiv(W, TW);
     const int n_pairs = ((imk_pad8(cin) + 15) / 16) * ((imk_pad8(cout) + 15) / 16);
-    int s = 768 / n_pairs;   // ~3 resident workgroups per CU; each walks its tiles with prefetch
+    static const int target = []() { const char *e = getenv("IMK_WGRAD_WGS"); return e ? atoi(e) : 768; }();
+    int s = target / n_pairs;   // ~3 resident workgroups per CU; each walks its tiles with prefetch
     if (s < 1) s = 1;
     if (s > n_tiles) s = n_tiles;
     return s;
