@@ -146,6 +146,76 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
         for (int i = threadIdx.x; i < 3 * cs; i += 256) s_aff[i] = in.sc[i];
 }
 
+// ---- two-phase input staging: raw global loads into registers, transform later ------------------------------------
+template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 2 : 1)]; };
+template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
+
+template <int LM>
+__device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x, int H, int W, int c8, RawChunk<LM> &r) {
+    const int cs = in.cs_in;
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE) {
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
+    } else if constexpr (LM == LM_POOL) {
+        const int W2 = 2 * W;
+        const f16 *p = (const f16 *)in.in + ((size_t)(b * 2 * H + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
+        r.v[0] = *(const f16x8 *)p;
+        r.v[1] = *(const f16x8 *)(p + cs);
+        r.v[2] = *(const f16x8 *)(p + (size_t)W2 * cs);
+        r.v[3] = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
+    } else if constexpr (LM == LM_UPADD) {
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * cs + c8 * 8);
+        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
+    } else if constexpr (LM == LM_BNBWD) {
+        const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
+        r.v[0] = *(const f16x8 *)((const f16 *)in.in + o);
+        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + o);
+    } else {
+        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < in.cin) ? p[j] : 0;
+    }
+}
+
+template <int LM>
+__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin) {
+    if constexpr (LM == LM_RAW) {
+        return r.v[0];
+    } else if constexpr (LM == LM_AFFINE) {
+        return affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
+    } else if constexpr (LM == LM_POOL) {
+        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)r.v[0][j] * sc[j] + sh[j], bq = (float)r.v[1][j] * sc[j] + sh[j];
+            const float c = (float)r.v[2][j] * sc[j] + sh[j], d = (float)r.v[3][j] * sc[j] + sh[j];
+            o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
+        }
+        return o;
+    } else if constexpr (LM == LM_UPADD) {
+        const f16x8 lo = affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
+        const f16x8 sk = affine8(r.v[1], s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
+        return o;
+    } else if constexpr (LM == LM_BNBWD) {
+        const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zf = (float)r.v[1][j];
+            o[j] = zf > 0.f ? (f16)(A[j] * (float)r.v[0][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
+        }
+        return o;
+    } else {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / 255.0f : 0.0f);
+        return o;
+    }
+}
+
 // =====================================================================================================
 // forward / dgrad
 // =====================================================================================================
@@ -155,7 +225,10 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
 struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds; };
 
 // bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
-template <int TH, int MT>
+// DEEPB: long staging batches (all of a thread's items in flight at once) for launches that do not fill the chip --
+// there the kernel's duration is the latency chain of one workgroup; with several rounds of workgroups per CU the
+// shorter batches (fewer registers) are faster.
+template <int TH, int MT, int LM, bool DEEPB>
 __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkConvGeom &gm, int bx, int by) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, mt_total = gm.mt_total, nc8 = gm.nc8, nc8p = gm.nc8p;
     const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp, w_in_lds = gm.w_in_lds;
@@ -173,8 +246,8 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     const int H = a.H, W = a.W;
     const int ns_total = n_pass * nsp;
 
-    stage_affine_table(a.x, s_aff);
-    if (a.x.lmode != LM_RAW && a.x.lmode != LM_U8) __syncthreads();
+    stage_affine_table(a.x, s_aff);   // visible after the barrier inside the first staging batch
+    bool aff_pending = (LM != LM_RAW && LM != LM_U8);
 
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int ct0 = by * MT;
@@ -209,28 +282,49 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
         }
         // ---- stage this pass's channel slice of the input tile ------------------------------------------
         const int n_items = HT * WT * nc8_cur;
-        // batches of 4 items per thread: the 4 (or more) global loads of a batch are issued back to back, so a
-        // thread pays one memory latency per batch instead of one per item
-        for (int i0 = t; i0 < n_items; i0 += 4 * 256) {
-            f16x8 v[4];
-            int dst[4];
+        // Batches of items per thread: all global loads of a batch are issued back to back (unconditionally, with
+        // clamped coordinates: no branch between them), the transforms (BN / pool / up+add / BN backward) follow, so a
+        // thread pays one memory latency per batch.  Deep layers have 10-20 items per thread: 1-2 batches.
+        if constexpr (LM == LM_U8) {     // uint8 input with 5-8 channels (never the shipped configs): simple path
+            for (int i = t; i < n_items; i += 256) {
+                const int pix = i / nc8_cur, c8 = i - pix * nc8_cur;
+                const int py = pix / WT, px = pix - py * WT;
+                const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (y >= 0 && y < H && x >= 0 && x < W) v = load_chunk(a.x, tc.b, y, x, H, W, c8_lo + c8, s_aff);
+                *reinterpret_cast<f16x8 *>(s_tile + (pix * ps + c8) * 16) = v;
+            }
+        } else {
+            constexpr int BATCH = !DEEPB ? 4 : ((LM == LM_POOL) ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 6 : 12));
+            const int n_batches = (n_items + BATCH * 256 - 1) / (BATCH * 256);   // uniform trip count (barrier inside)
+            for (int bt = 0; bt < n_batches; ++bt) {
+                const int i0 = t + bt * BATCH * 256;
+                RawChunk<LM> r[BATCH];
+                int dst[BATCH], c8s[BATCH];
+                unsigned ok = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
-                dst[u] = -1;
-                v[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (i < n_items) {
-                    const int pix = i / nc8_cur;
-                    const int c8 = i - pix * nc8_cur;
+                for (int u = 0; u < BATCH; ++u) {
+                    const int i = i0 + u * 256;
+                    const int ii = i < n_items ? i : t;          // idle slots repeat this thread's first item
+                    const int pix = ii / nc8_cur;
+                    const int c8 = ii - pix * nc8_cur;
                     const int py = pix / WT, px = pix - py * WT;
                     const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
-                    dst[u] = (pix * ps + c8) * 16;
-                    if (y >= 0 && y < H && x >= 0 && x < W) v[u] = load_chunk(a.x, tc.b, y, x, H, W, c8_lo + c8, s_aff);
+                    dst[u] = i < n_items ? (pix * ps + c8) * 16 : -1;
+                    c8s[u] = c8_lo + c8;
+                    if (y >= 0 && y < H && x >= 0 && x < W) ok |= 1u << u;
+                    raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, c8s[u], r[u]);
+                }
+                if (aff_pending) { __syncthreads(); aff_pending = false; }   // affine table (uniform branch)
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    if (dst[u] >= 0) {
+                        f16x8 v = raw_transform<LM>(r[u], s_aff, a.x.cs_in, c8s[u], a.x.cin);
+                        if (!(ok & (1u << u))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v;
+                    }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v[u];
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asynchronous weight copy has landed
         __syncthreads();
@@ -339,9 +433,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     }
 }
 
-template <int TH, int MT>
+template <int TH, int MT, int LM, bool DEEPB>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGeom gm) {
-    conv_mfma_body<TH, MT>(a, gm, blockIdx.x, blockIdx.y);
+    conv_mfma_body<TH, MT, LM, DEEPB>(a, gm, blockIdx.x, blockIdx.y);
 }
 
 // =====================================================================================================
@@ -354,75 +448,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 //     resident workgroup always has a tile of loads in flight;
 //   * the packed weights (<= 5 k-steps) and the per-lane LDS offsets are loaded once per workgroup.
 // =====================================================================================================
-template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 2 : 1)]; };
-template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
-
-template <int LM>
-__device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x, int H, int W, int c8, RawChunk<LM> &r) {
-    const int cs = in.cs_in;
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE) {
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
-    } else if constexpr (LM == LM_POOL) {
-        const int W2 = 2 * W;
-        const f16 *p = (const f16 *)in.in + ((size_t)(b * 2 * H + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
-        r.v[0] = *(const f16x8 *)p;
-        r.v[1] = *(const f16x8 *)(p + cs);
-        r.v[2] = *(const f16x8 *)(p + (size_t)W2 * cs);
-        r.v[3] = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
-    } else if constexpr (LM == LM_UPADD) {
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * cs + c8 * 8);
-        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
-    } else if constexpr (LM == LM_BNBWD) {
-        const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + o);
-        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + o);
-    } else {
-        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < in.cin) ? p[j] : 0;
-    }
-}
-
-template <int LM>
-__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin) {
-    if constexpr (LM == LM_RAW) {
-        return r.v[0];
-    } else if constexpr (LM == LM_AFFINE) {
-        return affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
-    } else if constexpr (LM == LM_POOL) {
-        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = (float)r.v[0][j] * sc[j] + sh[j], bq = (float)r.v[1][j] * sc[j] + sh[j];
-            const float c = (float)r.v[2][j] * sc[j] + sh[j], d = (float)r.v[3][j] * sc[j] + sh[j];
-            o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-        }
-        return o;
-    } else if constexpr (LM == LM_UPADD) {
-        const f16x8 lo = affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
-        const f16x8 sk = affine8(r.v[1], s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
-        return o;
-    } else if constexpr (LM == LM_BNBWD) {
-        const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float zf = (float)r.v[1][j];
-            o[j] = zf > 0.f ? (f16)(A[j] * (float)r.v[0][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
-        }
-        return o;
-    } else {
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / 255.0f : 0.0f);
-        return o;
-    }
-}
-
 // PAIR (layers with <= 8 output channels, i.e. level 0 at alpha = 0.5): a 16-row MFMA output would be half empty, so
 // the two halves of the K dimension carry two different tile rows instead: k-slot groups g = 0,1 hold (tap, chunk)
 // pairs of row A, g = 2,3 the same pairs of row B; weight rows 0-7 are non-zero only in the first half, rows 8-15 (the
@@ -1212,8 +1237,21 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    if (L.th == 16) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4>) : (L.mt == 2 ? launch(conv_mfma_kernel<16, 2>) : launch(conv_mfma_kernel<16, 1>));
-    else rc = L.mt == 4 ? launch(conv_mfma_kernel<8, 4>) : (L.mt == 2 ? launch(conv_mfma_kernel<8, 2>) : launch(conv_mfma_kernel<8, 1>));
+    const bool deepb = (long long)L.gx * L.gy <= 1024;   // at most ~2 rounds of workgroups: latency-bound launch
+#define IMK_MFMA_MT(TH, LM, DB) \
+    (L.mt == 4 ? launch(conv_mfma_kernel<TH, 4, LM, DB>) : (L.mt == 2 ? launch(conv_mfma_kernel<TH, 2, LM, DB>) : launch(conv_mfma_kernel<TH, 1, LM, DB>)))
+#define IMK_MFMA_TH(LM) (L.th == 16 ? (deepb ? IMK_MFMA_MT(16, LM, true) : IMK_MFMA_MT(16, LM, false)) \
+                                    : (deepb ? IMK_MFMA_MT(8, LM, true) : IMK_MFMA_MT(8, LM, false)))
+    switch (a.x.lmode) {
+        case LM_RAW: rc = IMK_MFMA_TH(LM_RAW); break;
+        case LM_AFFINE: rc = IMK_MFMA_TH(LM_AFFINE); break;
+        case LM_POOL: rc = IMK_MFMA_TH(LM_POOL); break;
+        case LM_UPADD: rc = IMK_MFMA_TH(LM_UPADD); break;
+        case LM_BNBWD: rc = IMK_MFMA_TH(LM_BNBWD); break;
+        default: rc = IMK_MFMA_TH(LM_U8); break;
+    }
+#undef IMK_MFMA_TH
+#undef IMK_MFMA_MT
     if (rc) return rc;
     if (a.stats_rows) *a.stats_rows = L.gx;
     if (prof) {
