@@ -90,6 +90,28 @@ struct BnPrepArgs {
     int B, H, W, cs;
 };
 
+// block reduction over the pixel slots (fixed tree => deterministic), one partial row per block
+__device__ __forceinline__ void prep_block_reduce(const float (&s1)[8], const float (&s2)[8], int slot, int slots, int sh,
+                                                  int c8, int nc8, int cs, float *partial) {
+    __shared__ float s_r[256][17];   // [slot][chunk lane][16]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_r[threadIdx.x][j] = s1[j]; s_r[threadIdx.x][8 + j] = s2[j]; }
+    __syncthreads();
+    for (int o = slots >> 1; o > 0; o >>= 1) {
+        if (slot < o)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s_r[threadIdx.x][j] += s_r[threadIdx.x + (o << sh)][j];
+        __syncthreads();
+    }
+    if (slot == 0 && c8 < nc8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            partial[(size_t)blockIdx.x * 2 * cs + c8 * 8 + j] = s_r[threadIdx.x][j];
+            partial[(size_t)blockIdx.x * 2 * cs + cs + c8 * 8 + j] = s_r[threadIdx.x][8 + j];
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
     // thread -> (pixel slot, chunk): 256 threads = (256 / nc8p) pixel slots x nc8p chunk lanes, nc8p = nc8 rounded up
@@ -191,24 +213,64 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
             }
         }
     }
-    // block reduction over the pixel slots (fixed tree => deterministic): s_r[slot][chunk lane][16]
-    __shared__ float s_r[256][17];
+    prep_block_reduce(s1, s2, slot, slots, sh, c8, nc8, a.cs, a.partial);
+}
+
+// MODE 1 (encoder outputs: skip gradient + max-pool scatter), one 2x2 pooling window per thread and iteration: the four
+// z and four skip-gradient chunks of the window and its pooled gradient are 9 loads for 4 pixels (the per-pixel
+// form above needs 6 per pixel: itself, the pooled gradient, the skip gradient and the three other window elements),
+// the first-maximum decision is taken once per window, and the index arithmetic runs per window instead of per pixel.
+__global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
+    const int nc8 = a.cs / 8;
+    int sh = 0;
+    while ((1 << sh) < nc8) ++sh;
+    const int nc8p = 1 << sh;
+    const int c8 = threadIdx.x & (nc8p - 1);
+    const int slot = threadIdx.x >> sh;
+    const int slots = 256 >> sh;
+    const unsigned Hh = a.H / 2, Wh = a.W / 2;
+    const unsigned n_win = (unsigned)a.B * Hh * Wh;
+    const unsigned stride = (unsigned)gridDim.x * slots;
+    float s1[8], s2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s_r[threadIdx.x][j] = s1[j]; s_r[threadIdx.x][8 + j] = s2[j]; }
-    __syncthreads();
-    for (int o = slots >> 1; o > 0; o >>= 1) {
-        if (slot < o)
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (c8 < nc8) {
+        float sc[8], shf[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s_r[threadIdx.x][j] += s_r[threadIdx.x + (o << sh)][j];
-        __syncthreads();
-    }
-    if (slot == 0 && c8 < nc8) {
+        for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c8 * 8 + j]; shf[j] = a.sh[c8 * 8 + j]; }
+        const size_t o1 = (size_t)a.cs, o2 = (size_t)a.W * a.cs;
+        for (unsigned w = blockIdx.x * slots + slot; w < n_win; w += stride) {
+            const unsigned xh = w % Wh, r = w / Wh, yh = r % Hh, b = r / Hh;
+            const size_t w00 = (((size_t)(b * a.H + 2 * yh) * a.W + 2 * xh) * nc8 + c8) * 8;
+            const size_t off[4] = {w00, w00 + o1, w00 + o2, w00 + o2 + o1};   // row-major window order
+            f16x8 z[4], g[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a.partial[(size_t)blockIdx.x * 2 * a.cs + c8 * 8 + j] = s_r[threadIdx.x][j];
-            a.partial[(size_t)blockIdx.x * 2 * a.cs + a.cs + c8 * 8 + j] = s_r[threadIdx.x][8 + j];
+            for (int e = 0; e < 4; ++e) z[e] = *reinterpret_cast<const f16x8 *>(a.z + off[e]);
+            const f16x8 dp = *reinterpret_cast<const f16x8 *>(a.g_other + ((size_t)w * nc8 + c8) * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = a.g_direct ? *reinterpret_cast<const f16x8 *>(a.g_direct + off[e]) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            f16x8 dy[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // the pooled gradient goes to the FIRST maximum of the window in row-major order
+                f16 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (f16)((float)z[e][j] * sc[j] + shf[j]);
+                int win = 0;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) if (v[e] > v[win]) win = e;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dy[e][j] = (f16)((float)g[e][j] + (e == win ? (float)dp[j] : 0.f));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<f16x8 *>(a.dy_out + off[e]) = dy[e];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = (float)dy[e][j]; s1[j] += d; s2[j] += d * (float)z[e][j]; }
+            }
         }
     }
+    prep_block_reduce(s1, s2, slot, slots, sh, c8, nc8, a.cs, a.partial);
 }
 
 // pass 2: per-channel coefficients  dz = A*dy + Bc*z + Cc  and the gamma/beta gradients
@@ -493,6 +555,7 @@ int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, co
     BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs};
     const int nb = imk_bn_prep_blocks(B, H, W, cs);
     if (mode == 0) bn_bwd_prep_kernel<0><<<nb, 256, 0, stream>>>(a);
+    else if (mode == 1 && H % 2 == 0 && W % 2 == 0) bn_bwd_prep_pool_kernel<<<nb, 256, 0, stream>>>(a);
     else if (mode == 1) bn_bwd_prep_kernel<1><<<nb, 256, 0, stream>>>(a);
     else bn_bwd_prep_kernel<2><<<nb, 256, 0, stream>>>(a);
     IMK_LAUNCH_CHECK();
