@@ -878,74 +878,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgra
     wgrad_mfma_body<LM>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
-// stage 1 of the deterministic split reduction: [n_split][n_tiles][256] -> [n_chunks][n_tiles][256],
-// 16 splits per chunk; coalesced (thread = element of a 16x16 tile).
-constexpr int WG_RED_CHUNK = 16;
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_split, int n_tiles,
-                                                           float *__restrict__ red) {
-    const int tile = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
-    const int s0 = chunk * WG_RED_CHUNK, s1 = min(n_split, s0 + WG_RED_CHUNK);
-    const size_t stride = (size_t)n_tiles * 256;
-    const float *p = partial + (size_t)tile * 256 + t;
-    float v[WG_RED_CHUNK];
-#pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = (s0 + i < s1) ? p[(size_t)(s0 + i) * stride] : 0.f;
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += v[i];
-    red[((size_t)chunk * n_tiles + tile) * 256 + t] = acc;
-}
-
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ partial, int n_split, int T,
-                                                             int cin, int cout, int cit_n, int cot_n,
-                                                             const float *__restrict__ inv_scale_ptr,
-                                                             float *__restrict__ dw, float *__restrict__ db,
-                                                             float *__restrict__ found_inf) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n_w = T * cin * cout;
-    if (i >= n_w + cout) return;
-    int tap, ci, co;
-    if (i < n_w) {
-        co = i % cout;
-        const int r = i / cout;
-        ci = r % cin;
-        tap = r / cin;
-    } else {
-        co = i - n_w; ci = 0; tap = T;
-    }
-    const int cit = ci >> 4, cot = co >> 4, m = ci & 15, nn = co & 15;
-    const int e = (m & 3) * 64 + (m >> 2) * 16 + nn;
-    const int n_pairs = cit_n * cot_n;
-    const size_t stride = (size_t)n_pairs * (T + 1) * 256;
-    const float *p = partial + ((size_t)(cit * cot_n + cot) * (T + 1) + tap) * 256 + e;
-    float s = 0.f;
-    for (int k = 0; k < n_split; ++k) s += p[(size_t)k * stride];
-    s *= *inv_scale_ptr;
-    if (!isfinite(s)) *found_inf = 1.0f;
-    if (i < n_w) dw[i] = s; else db[co] = s;
-}
-
-// fp32 HWIO -> fp16 MFMA-A fragment order.  element index = ((ct*ns + s)*64 + lane)*8 + j
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ w, int T, int cin, int cout,
-                                                        int transposed, int m_dim, int k_dim, int nc8, int ns,
-                                                        int total, f16 *__restrict__ dst) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int j = i & 7, lane = (i >> 3) & 63;
-    const int cs = i >> 9;
-    const int s = cs % ns, ct = cs / ns;
-    const int m = lane & 15, g = lane >> 4;
-    const int nc8p = imk_pass_chunks(nc8), nsp = (T * nc8p + 3) / 4;   // ns = n_pass * nsp
-    const int pass = s / nsp, q = 4 * (s - pass * nsp) + g;
-    const int tap = q / nc8p, c8 = pass * nc8p + (q - tap * nc8p);
-    const int mi = ct * 16 + m, ki = (c8 < nc8 && (q - tap * nc8p) < nc8p) ? c8 * 8 + j : k_dim;
-    float v = 0.f;
-    if (tap < T && mi < m_dim && ki < k_dim) {
-        if (!transposed) v = w[((size_t)tap * cin + ki) * cout + mi];                 // m = co, k = ci
-        else v = w[((size_t)(T - 1 - tap) * cin + mi) * cout + ki];                    // m = ci, k = co, flipped taps
-    }
-    dst[i] = (f16)v;
-}
+constexpr int WG_RED_CHUNK = 16;   // splits summed per stage-1 chunk of the weight-gradient reduction
 
 // ---- batched, deterministic reduction of all layers' weight-gradient partials -----------------------------
 __device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx, bool stage1) {
@@ -1434,26 +1367,6 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int cin, int cout,
-                              const float *inv_scale_ptr, float *dw, float *db, float *found_inf, hipStream_t stream) {
-    const int T = ksize == 3 ? 9 : 1;
-    const int cit_n = (imk_pad8(cin) + 15) / 16, cot_n = (imk_pad8(cout) + 15) / 16;
-    const int total = T * cin * cout + cout;
-    if (n_split > WG_RED_CHUNK) {  // two-stage: the second stage then walks at most 64 values per element
-        const int n_tiles = cit_n * cot_n * (T + 1);
-        const int n_chunks = imk_cdiv(n_split, WG_RED_CHUNK);
-        float *red = const_cast<float *>(partial) + (size_t)n_split * n_tiles * 256;  // scratch behind the partials
-        wgrad_reduce_kernel<<<dim3(n_tiles, n_chunks), 256, 0, stream>>>(partial, n_split, n_tiles, red);
-        IMK_LAUNCH_CHECK();
-        partial = red;
-        n_split = n_chunks;
-    }
-    wgrad_finalize_kernel<<<imk_cdiv(total, 256), 256, 0, stream>>>(partial, n_split, T, cin, cout, cit_n, cot_n,
-                                                                   inv_scale_ptr, dw, db, found_inf);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
-}
-
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool pair) {
     if (transposed == 2) return 512;
     const int T = ksize == 3 ? 9 : 1;
@@ -1465,14 +1378,3 @@ size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool 
     return (size_t)((m_dim + 15) / 16) * ns * 512;
 }
 
-int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream) {
-    const int T = ksize == 3 ? 9 : 1;
-    const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
-    const int nc8 = imk_pad8(k_dim) / 8;
-    const int nc8p = imk_pass_chunks(nc8);
-    const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
-    const int total = (int)imk_packed_conv_halfs(ksize, cin, cout, transposed, false);
-    pack_conv_kernel<<<imk_cdiv(total, 256), 256, 0, stream>>>(w, T, cin, cout, transposed, m_dim, k_dim, nc8, ns, total, dst);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
-}

@@ -15,21 +15,19 @@ struct ImkCtl {
 int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *beta, float *mov_mean, float *mov_var, float *scale, float *shift,
                            float *save_mean, float *save_invstd, hipStream_t stream);
-int imk_launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, int c, int cs,
-                       float *scale, float *shift, hipStream_t stream);
 int imk_bn_prep_blocks(int B, int H, int W, int cs);
 int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
                            const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream);
 int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *save_mean, const float *save_invstd, const float *inv_scale_ptr, float *coef,
                            float *dgamma, float *dbeta, float *found_inf, hipStream_t stream);
-int imk_launch_bn_bwd_apply(const f16 *dy, const f16 *z, const float *coef, int cs, long long n_pix, f16 *dA,
-                            hipStream_t stream);
 int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                     int K, int softmax, long long n_pix, float *probs, hipStream_t stream);
 int imk_loss_blocks(long long n_pix);
-int imk_launch_loss_grad(const float *probs, const uint8_t *y, int K, int cs, int kind, long long n_pix,
-                         const ImkCtl *ctl, f16 *dlogit, float *loss_partial, float *stats, hipStream_t stream);
+// training: head (BN on load, fp32 1x1 conv, sigmoid / softmax) + loss + d(loss * scale)/d(logits), no probability tensor
+int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, f16 *dlogit,
+                         float *loss_partial, hipStream_t stream);
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
                              hipStream_t stream);
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);

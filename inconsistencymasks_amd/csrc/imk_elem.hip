@@ -54,18 +54,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
     }
 }
 
-// inference: fold the moving statistics
-__global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
-                               const float *__restrict__ mean, const float *__restrict__ var, int c, int cs,
-                               float *__restrict__ scale, float *__restrict__ shift) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= cs) return;
-    if (ch >= c) { scale[ch] = 0.f; shift[ch] = 0.f; return; }
-    const float sc = gamma[ch] / sqrtf(var[ch] + BN_EPS);
-    scale[ch] = sc;
-    shift[ch] = beta[ch] - mean[ch] * sc;
-}
-
+// inference: fold the moving statistics of all BatchNorm layers (one job each) into scale | shift
 __global__ void bn_fold_batched_kernel(ImkFoldJobs jobs) {
     const ImkFoldJob &jb = jobs.j[blockIdx.y];
     for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < jb.cs; ch += gridDim.x * blockDim.x) {
@@ -314,44 +303,6 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float *__restric
     }
 }
 
-// pass 3: dA = (A*dy + Bc*z + Cc) * [z > 0]   (BN backward + ReLU backward of the conv that produced z)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f16 *__restrict__ dy, const f16 *__restrict__ z,
-                                                           const float *__restrict__ coef, int cs, long long n_items,
-                                                           f16 *__restrict__ dA) {
-    extern __shared__ float s_c[];
-    for (int i = threadIdx.x; i < 3 * cs; i += 256) s_c[i] = coef[i];
-    __syncthreads();
-    const int nc8 = cs / 8;
-    const long long G = (long long)gridDim.x * 256;
-    constexpr int UB = 4;
-    for (long long it0 = (long long)blockIdx.x * 256 + threadIdx.x; it0 < n_items; it0 += UB * G) {
-        f16x8 d[UB], zz[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const long long it = it0 + u * G;
-            if (it < n_items) {
-                d[u] = *reinterpret_cast<const f16x8 *>(dy + it * 8);
-                zz[u] = *reinterpret_cast<const f16x8 *>(z + it * 8);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const long long it = it0 + u * G;
-            if (it >= n_items) continue;
-            const int c8 = (int)((unsigned)it % (unsigned)nc8);
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ch = c8 * 8 + j;
-                const float zf = (float)zz[u][j];
-                const float v = s_c[ch] * (float)d[u][j] + s_c[cs + ch] * zf + s_c[2 * cs + ch];
-                o[j] = (zf > 0.f) ? (f16)v : (f16)0.f;
-            }
-            *reinterpret_cast<f16x8 *>(dA + it * 8) = o;
-        }
-    }
-}
-
 // ---- output head: BN on load -> 1x1 conv in fp32 -> sigmoid / softmax --------------------------------
 // one thread per pixel; weights broadcast from LDS.  K <= 64.
 template <int CS>
@@ -401,44 +352,80 @@ __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, co
     }
 }
 
-// ---- loss + gradient w.r.t. the logits ------------------------------------------------------------
-// mse:  L = mean_{all elements}(p - t)^2, dlogit = S * 2 (p - t) / Ntot * p (1 - p)      (sigmoid head)
-// cce:  L = mean_{pixels} -log(p_t), dlogit_k = S * (p_k - [k == t]) / Npix   (softmax head; Keras takes the
-//       softmax ACTIVATION's cached logits, so there is no probability clipping in loss or gradient; p_t is only
-//       floored at FLT_MIN so that an fp32 underflow reports 87.3 instead of inf)
-__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ probs, const uint8_t *__restrict__ y,
-                                                        int K, int cs, int kind, long long n_pix,
-                                                        const float *__restrict__ loss_scale_ptr,
+// ---- training: head + loss + gradient w.r.t. the logits in one pass ---------------------------------------------
+// Same arithmetic as head_kernel followed by loss_grad_kernel (same expressions in the same order, so the values are
+// bit-identical), without the [n_pix, K] fp32 probability tensor in between: the logits are recomputed per pass
+// (K * CS FMAs) instead of being parked in HBM.
+template <int CS>
+__global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ z, const float *__restrict__ sc,
+                                                        const float *__restrict__ sh, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, int cin, int K, int softmax,
+                                                        long long n_pix, const uint8_t *__restrict__ y,
+                                                        const float *__restrict__ loss_scale_ptr, int cs_out,
                                                         f16 *__restrict__ dlogit, float *__restrict__ loss_partial) {
+    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
+    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
+    for (int i = threadIdx.x; i < K * CS; i += 256) {
+        const int k = i / CS, c = i - k * CS;
+        s_w[i] = (c < cin) ? w[(size_t)c * K + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < K; i += 256) s_b[i] = bias[i];
+    for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
+    __syncthreads();
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     const float S = *loss_scale_ptr;
     float l = 0.f;
     if (p < n_pix) {
-        const float *pr = probs + p * K;
-        f16 *d = dlogit + p * cs;
-        if (kind == 0) {
+        float xin[CS];
+#pragma unroll
+        for (int q = 0; q < CS / 8; ++q) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+        }
+        auto logit = [&](int k) {
+            float acc = s_b[k];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
+            return acc;
+        };
+        f16 *d = dlogit + p * cs_out;
+        if (!softmax) {
             const float inv_n = 1.0f / ((float)n_pix * (float)K);
-            for (int k = 0; k < cs; ++k) {
-                float g = 0.f;
-                if (k < K) {
-                    const float pk = pr[k], t = (float)y[p * K + k];
-                    const float e = pk - t;
-                    l += e * e;
-                    g = S * 2.0f * e * inv_n * pk * (1.0f - pk);
+            for (int k0 = 0; k0 < cs_out; k0 += 8) {
+                f16x8 g8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j;
+                    if (k < K) {
+                        const float pk = 1.0f / (1.0f + expf(-logit(k))), t = (float)y[p * K + k];
+                        const float e = pk - t;
+                        l += e * e;
+                        g8[j] = (f16)(S * 2.0f * e * inv_n * pk * (1.0f - pk));
+                    }
                 }
-                d[k] = (f16)g;
+                *reinterpret_cast<f16x8 *>(d + k0) = g8;
             }
         } else {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, logit(k));
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) sum += expf(logit(k) - mx);
+            const float inv = 1.0f / sum;
             const int t = y[p];
             const float inv_n = 1.0f / (float)n_pix;
-            for (int k = 0; k < cs; ++k) {
-                float g = 0.f;
-                if (k < K) {
-                    const float pk = pr[k];
-                    if (k == t) l = -logf(fmaxf(pk, 1.17549435e-38f));
-                    g = S * (pk - (k == t ? 1.0f : 0.0f)) * inv_n;
+            for (int k0 = 0; k0 < cs_out; k0 += 8) {
+                f16x8 g8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j;
+                    if (k < K) {
+                        const float pk = expf(logit(k) - mx) * inv;
+                        if (k == t) l = -logf(fmaxf(pk, 1.17549435e-38f));
+                        g8[j] = (f16)(S * (pk - (k == t ? 1.0f : 0.0f)) * inv_n);
+                    }
                 }
-                d[k] = (f16)g;
+                *reinterpret_cast<f16x8 *>(d + k0) = g8;
             }
         }
     }
@@ -449,11 +436,22 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict_
     if (threadIdx.x == 0) loss_partial[blockIdx.x] = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
 }
 
+// ---- loss (head_loss_kernel above) ------------------------------------------------------------------------------
+// mse:  L = mean_{all elements}(p - t)^2, dlogit = S * 2 (p - t) / Ntot * p (1 - p)      (sigmoid head)
+// cce:  L = mean_{pixels} -log(p_t), dlogit_k = S * (p_k - [k == t]) / Npix   (softmax head; Keras takes the
+//       softmax ACTIVATION's cached logits, so there is no probability clipping in loss or gradient; p_t is only
+//       floored at FLT_MIN so that an fp32 underflow reports 87.3 instead of inf)
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int n, double denom,
                                                             const ImkCtl *__restrict__ ctl, float *__restrict__ stats) {
     __shared__ double r[256];
     double s = 0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {     // 8 independent loads in flight per thread; same summation order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (i0 + u * 256 < n) ? partial[i0 + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
     r[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -522,13 +520,6 @@ int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, doub
     return IMK_OK;
 }
 
-int imk_launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, int c, int cs,
-                       float *scale, float *shift, hipStream_t stream) {
-    bn_fold_kernel<<<imk_cdiv(cs, 64), 64, 0, stream>>>(gamma, beta, mean, var, c, cs, scale, shift);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
-}
-
 int imk_launch_bn_fold_jobs(const ImkFoldJobs &jobs, hipStream_t stream) {
     if (jobs.n <= 0) return IMK_OK;
     bn_fold_batched_kernel<<<dim3(2, jobs.n), 256, 0, stream>>>(jobs);
@@ -571,16 +562,6 @@ int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, doub
     return IMK_OK;
 }
 
-int imk_launch_bn_bwd_apply(const f16 *dy, const f16 *z, const float *coef, int cs, long long n_pix, f16 *dA,
-                            hipStream_t stream) {
-    const long long items = n_pix * (cs / 8);
-    long long nb = (items + 256 * 4 - 1) / (256 * 4);   // one batch of 4 per thread up to 4096 blocks
-    if (nb > 4096) nb = 4096;
-    if (nb < 1) nb = 1;
-    bn_bwd_apply_kernel<<<(int)nb, 256, 3 * cs * sizeof(float), stream>>>(dy, z, coef, cs, items, dA);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
-}
 
 int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                     int K, int softmax, long long n_pix, float *probs, hipStream_t stream) {
@@ -600,14 +581,26 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
 
 int imk_loss_blocks(long long n_pix) { return (int)((n_pix + 255) / 256); }
 
-int imk_launch_loss_grad(const float *probs, const uint8_t *y, int K, int cs, int kind, long long n_pix,
-                         const ImkCtl *ctl, f16 *dlogit, float *loss_partial, float *stats, hipStream_t stream) {
+int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, f16 *dlogit,
+                         float *loss_partial, hipStream_t stream) {
+    if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = imk_loss_blocks(n_pix);
-    loss_grad_kernel<<<nb, 256, 0, stream>>>(probs, y, K, cs, kind, n_pix, &ctl->loss_scale, dlogit, loss_partial);
+    const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
+    const int cs_out = imk_pad8(K);
+#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, &ctl->loss_scale, cs_out, dlogit, loss_partial)
+    switch (cs) {
+        case 8: IMK_HL(8); break;
+        case 16: IMK_HL(16); break;
+        case 24: IMK_HL(24); break;
+        case 32: IMK_HL(32); break;
+        default: return IMK_EUNSUPPORTED;
+    }
+#undef IMK_HL
     IMK_LAUNCH_CHECK();
-    (void)stats;
     return IMK_OK;
 }
+
 
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
                              hipStream_t stream) {

@@ -39,7 +39,7 @@ struct ImkConvArgs {
     // optional fused second stage (EP_RELU only): out2 = relu(W2 . relu(W . x + bias) + bias2), a 1x1 conv chained on
     // the accumulator tile inside the same kernel (unet.py:12-13 / 37-38: Conv3x3+ReLU -> Conv1x1+ReLU).  `out` (the
     // intermediate) is then written only if non-null; statistics are taken on out2.
-    const f16 *wpk2;       // chain-packed 1x1 weights (imk_launch_pack_conv mode 2)
+    const f16 *wpk2;       // chain-packed 1x1 weights (pack mode 2)
     const float *bias2;
     f16 *out2;             // [B,H,W,cs_out2]
     int cout2, cs_out2;
@@ -65,10 +65,6 @@ struct ImkWgradArgs {
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout);
 size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout);
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
-// sums the partials in a fixed order, multiplies by inv_scale, writes dW (HWIO) and db into the flat
-// gradient vector, ORs non-finite detection into *found_inf.
-int imk_launch_wgrad_finalize(const float *partial, int n_split, int ksize, int cin, int cout,
-                              const float *inv_scale_ptr, float *dw, float *db, float *found_inf, hipStream_t stream);
 
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
@@ -78,7 +74,6 @@ bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
 // output channel counts (forward: cin / cout, dgrad: cout / cin; chain: both must be <= 8).
 bool imk_conv_pair_layout(int k_in, int m_out, bool u8_input);
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool pair);
-int imk_launch_pack_conv(const float *w, int ksize, int cin, int cout, int transposed, f16 *dst, hipStream_t stream);
 
 // batched variant: up to IMK_PACK_MAX_JOBS (layer, direction) jobs per launch, table passed by value
 #define IMK_PACK_MAX_JOBS 32

@@ -326,6 +326,7 @@ int run_forward(Ctx &c, const uint8_t *x, float *probs, float *params_rw) {
     for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN_PAIR(t.d_c3[j], t.d_c1[j]); }
 #undef RUN_PAIR
 #undef RUN
+    if (!probs) return IMK_OK;   // training: the caller runs the fused head + loss kernel
     const ImkLayer &o = c.p->layers[t.out];
     const int bn = t.d_bnb[3];
     return imk_launch_head(c.act(t.d_c1[3]), c.bn_scale(bn), c.bn_shift(bn), c.params + o.off_w, c.params + o.off_b,
@@ -666,14 +667,17 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     int rc;
 #define OK(e) do { rc = (e); if (rc) return rc; } while (0)
     OK(imk_launch_ctl_begin(sv.ctl, stream));
-    float *probs = reinterpret_cast<float *>(c.base + c.ws.probs);
-    OK(run_forward(c, x, probs, params));
+    OK(run_forward(c, x, nullptr, params));
 
-    // loss and d(loss*scale)/d(logits)
+    // head + loss + d(loss*scale)/d(logits) in one pass over the last activation
     f16 *dlogit = reinterpret_cast<f16 *>(c.base + c.ws.dlogit);
     float *loss_partial = reinterpret_cast<float *>(c.base + c.ws.loss_partial);
-    OK(imk_launch_loss_grad(probs, y, cf.n_out, imk_pad8(cf.n_out), loss_kind, n_pix, sv.ctl, dlogit, loss_partial, stats,
-                            stream));
+    {
+        const ImkLayer &o = plan->layers[t.out];
+        const int bn = t.d_bnb[3];
+        OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(bn), c.bn_shift(bn), params + o.off_w, params + o.off_b, o.cin,
+                                imk_pad8(o.cin), o.cout, cf.act_out, n_pix, y, sv.ctl, dlogit, loss_partial, stream));
+    }
 
     std::call_once(plan->side_once, [plan]() {
         bool ok = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) == hipSuccess;
