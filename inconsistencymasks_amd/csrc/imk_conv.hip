@@ -20,6 +20,7 @@
 // unet.py:4-43 and their gradients inside model.fit (functions.py:218).
 #include <cstdlib>
 #include "imk_kernels.h"
+#include "imk_elem.h"
 
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T *)(p))
@@ -945,6 +946,7 @@ __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, c
 
 // all conv layers of a model in one launch: blockIdx.y = job
 __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs) {
+    if (jobs.ctl && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) imk_ctl_end_step(jobs.ctl, jobs.stats);
     const ImkPackJob &jb = jobs.j[blockIdx.y];
     if (jb.transposed == 2) {   // chain operand of a 1x1 conv: one k-step, lane (m, g), j < 4 <-> W[ci = 4g + j][co = m]
         for (int i = blockIdx.x * 256 + threadIdx.x; i < 512; i += gridDim.x * 256) {

@@ -26,14 +26,26 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
 int imk_loss_blocks(long long n_pix);
 // training: head (BN on load, fp32 1x1 conv, sigmoid / softmax) + loss + d(loss * scale)/d(logits), no probability tensor
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
-                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, f16 *dlogit,
+                         int K, int softmax, long long n_pix, const uint8_t *y, ImkCtl *ctl, f16 *dlogit,
                          float *loss_partial, hipStream_t stream);
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
                              hipStream_t stream);
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
-int imk_launch_ctl_begin(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream);
+
+// End of an optimizer step (Keras dynamic loss scale: halve on overflow, double after 2000 consecutive finite steps;
+// step counter).  Called by one thread of the weight re-packing kernel, which runs right after adamw_kernel.
+__device__ __forceinline__ void imk_ctl_end_step(ImkCtl *ctl, const float *stats) {
+    if (stats[1] != 0.f) {
+        ctl->loss_scale = fmaxf(ctl->loss_scale * 0.5f, 1.0f);
+        ctl->good_steps = 0;
+    } else {
+        ctl->step += 1;
+        if (++ctl->good_steps >= 2000) { ctl->loss_scale *= 2.0f; ctl->good_steps = 0; }
+    }
+    ctl->inv_loss_scale = 1.0f / ctl->loss_scale;
+}
 
 // all BatchNorm layers of a model folded (moving statistics -> scale | shift) in one launch
 #define IMK_FOLD_MAX_JOBS 32

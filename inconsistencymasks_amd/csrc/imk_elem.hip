@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                                                         const float *__restrict__ sh, const float *__restrict__ w,
                                                         const float *__restrict__ bias, int cin, int K, int softmax,
                                                         long long n_pix, const uint8_t *__restrict__ y,
-                                                        const float *__restrict__ loss_scale_ptr, int cs_out,
+                                                        ImkCtl *__restrict__ ctl, int cs_out,
                                                         f16 *__restrict__ dlogit, float *__restrict__ loss_partial) {
     extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
     float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
     for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
     __syncthreads();
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    const float S = *loss_scale_ptr;
+    const float S = ctl->loss_scale;
+    // start of the step's gradient part: clear the overflow flag (every kernel that can set it runs after this one,
+    // the optimizer step that consumed the previous value ran before it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->found_inf = 0.f;
     float l = 0.f;
     if (p < n_pix) {
         float xin[CS];
@@ -475,8 +478,6 @@ __global__ void ctl_init_kernel(ImkCtl *ctl) {
     ctl->found_inf = 0.f;
 }
 
-__global__ void ctl_begin_step_kernel(ImkCtl *ctl) { ctl->found_inf = 0.f; }
-
 // tfa AdamW: var -= wd*var; m,v update; var -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
 __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
                                                     const float *__restrict__ g, long long n, const ImkCtl *__restrict__ ctl,
@@ -494,18 +495,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     pi -= lr_t * mi / (sqrtf(vi) + eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
-}
-
-// Keras dynamic loss scale: halve on overflow, double after 2000 consecutive finite steps
-__global__ void ctl_end_step_kernel(ImkCtl *ctl, const float *__restrict__ stats) {
-    if (stats[1] != 0.f) {
-        ctl->loss_scale = fmaxf(ctl->loss_scale * 0.5f, 1.0f);
-        ctl->good_steps = 0;
-    } else {
-        ctl->step += 1;
-        if (++ctl->good_steps >= 2000) { ctl->loss_scale *= 2.0f; ctl->good_steps = 0; }
-    }
-    ctl->inv_loss_scale = 1.0f / ctl->loss_scale;
 }
 
 }  // namespace
@@ -582,13 +571,13 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
 int imk_loss_blocks(long long n_pix) { return (int)((n_pix + 255) / 256); }
 
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
-                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, f16 *dlogit,
+                         int K, int softmax, long long n_pix, const uint8_t *y, ImkCtl *ctl, f16 *dlogit,
                          float *loss_partial, hipStream_t stream) {
     if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = imk_loss_blocks(n_pix);
     const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
     const int cs_out = imk_pad8(K);
-#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, &ctl->loss_scale, cs_out, dlogit, loss_partial)
+#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, cs_out, dlogit, loss_partial)
     switch (cs) {
         case 8: IMK_HL(8); break;
         case 16: IMK_HL(16); break;
@@ -616,17 +605,9 @@ int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream) {
     return IMK_OK;
 }
 
-int imk_launch_ctl_begin(ImkCtl *ctl, hipStream_t stream) {
-    ctl_begin_step_kernel<<<1, 1, 0, stream>>>(ctl);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
-}
-
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream) {
     adamw_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(p, m, v, g, n, ctl, stats, grad_scale, lr, wd, b1, b2, eps);
     IMK_LAUNCH_CHECK();
-    ctl_end_step_kernel<<<1, 1, 0, stream>>>(ctl, stats);
-    IMK_LAUNCH_CHECK();
-    return IMK_OK;
+    return IMK_OK;   // the step counter / loss scale update rides on the re-packing launch that follows (imk_ctl_end_step)
 }

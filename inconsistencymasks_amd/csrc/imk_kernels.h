@@ -76,9 +76,15 @@ bool imk_conv_pair_layout(int k_in, int m_out, bool u8_input);
 size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool pair);
 
 // batched variant: up to IMK_PACK_MAX_JOBS (layer, direction) jobs per launch, table passed by value
-#define IMK_PACK_MAX_JOBS 32
+#define IMK_PACK_MAX_JOBS 80
 struct ImkPackJob { const float *w; f16 *dst; int ksize, cin, cout, transposed, pair; };
-struct ImkPackJobs { ImkPackJob j[IMK_PACK_MAX_JOBS]; int n; };
+struct ImkCtl;
+struct ImkPackJobs {
+    ImkPackJob j[IMK_PACK_MAX_JOBS];
+    int n;
+    ImkCtl *ctl;            // optional: end-of-optimizer-step bookkeeping done by one thread of this launch
+    const float *stats;
+};
 int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream);
 
 // All weight-gradient reductions of a training step in two launches (stage 1: 16 splits -> 1 chunk, coalesced;

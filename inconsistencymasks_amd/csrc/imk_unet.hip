@@ -391,14 +391,17 @@ extern "C" int imk_debug_materialize(int on) { g_materialize = on != 0; return I
 
 extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return plan ? plan->packed_bytes : IMK_EINVAL; }
 
-extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// ctl / stats: non-null after an optimizer step -- the first packing launch then also closes the step (loss-scale and
+// step-counter update), which saves a launch of its own.
+static int pack_weights(const imk_unet_plan *plan, const float *params, void *packed, hipStream_t stream, ImkCtl *ctl,
+                        const float *stats) {
     IMK_CHECK_ARG(plan && params && packed);
     uint8_t *pk = (uint8_t *)packed;
     const int out_idx = plan->find("out");
     ImkPackJobs pj{};
     ImkFoldJobs fj{};
-    auto flush_pack = [&]() -> int { int rc = imk_launch_pack_jobs(pj, stream); pj.n = 0; return rc; };
+    pj.ctl = ctl; pj.stats = stats;
+    auto flush_pack = [&]() -> int { int rc = imk_launch_pack_jobs(pj, stream); pj.n = 0; pj.ctl = nullptr; return rc; };
     for (size_t i = 0; i < plan->layers.size(); ++i) {
         const ImkLayer &l = plan->layers[i];
         if (l.kind == 0) {
@@ -419,7 +422,12 @@ extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *par
     }
     int rc = flush_pack();
     if (rc) return rc;
+    if (pj.ctl) return IMK_EINVAL;   // the step must have been closed by a packing launch
     return imk_launch_bn_fold_jobs(fj, stream);
+}
+
+extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream_) {
+    return pack_weights(plan, params, packed, (hipStream_t)stream_, nullptr, nullptr);
 }
 
 extern "C" int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode) {
@@ -666,7 +674,6 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     const long long n_pix = (long long)batch * cf.h * cf.w;
     int rc;
 #define OK(e) do { rc = (e); if (rc) return rc; } while (0)
-    OK(imk_launch_ctl_begin(sv.ctl, stream));
     OK(run_forward(c, x, nullptr, params));
 
     // head + loss + d(loss*scale)/d(logits) in one pass over the last activation
@@ -744,5 +751,5 @@ extern "C" int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, voi
     int rc = imk_launch_adamw(params, sv.m, sv.v, grads, plan->n_trainable, sv.ctl, stats, grad_scale, lr, wd, beta1, beta2,
                               eps, (hipStream_t)stream_);
     if (rc) return rc;
-    return imk_unet_pack_weights(plan, params, packed, stream_);
+    return pack_weights(plan, params, packed, (hipStream_t)stream_, sv.ctl, stats);
 }

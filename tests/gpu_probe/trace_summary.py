@@ -8,7 +8,9 @@ for r in csv.DictReader(open(f)):
     name = re.sub(r"^void ", "", name).split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
 rows.sort()
-begins = [i for i, r in enumerate(rows) if r[2].startswith("ctl_begin_step")]
+stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4")]          # uint8 stem: start of a forward
+folds = [i for i, r in enumerate(rows) if r[2].startswith("bn_fold_batched_kernel")]     # end of an optimizer step
+heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2]]                          # end of an inference call
 def show(seg, title):
     t0 = seg[0][0]
     span = (seg[-1][1] - t0) / 1e3
@@ -23,11 +25,13 @@ def show(seg, title):
         try: g = int(gx) // max(int(wx), 1)
         except ValueError: g = gx
         print(f"  {(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f} {n:42s} {g}")
-if len(begins) >= 2:
-    show(rows[begins[-2]:begins[-1]], "training step (second to last)")
-last_train_end = begins[-1]
-# inference calls follow the last training step: split at the u8 stem kernel
-tail = rows[last_train_end:]
-stems = [i for i, r in enumerate(tail) if "conv_pipe_kernel<4" in r[2]]
-if len(stems) >= 3:
-    show(tail[stems[-2]:stems[-1]], "inference call B=128 (second to last)")
+train = [(st, min(f for f in folds if f > st)) for st in stems if any(f > st for f in folds)
+         and not any(h > st and h < min(f for f in folds if f > st) for h in heads)]
+if len(train) >= 2:
+    st, en = train[-2]
+    show(rows[st:en + 1], "training step (second to last)")
+infer = [(st, min(h for h in heads if h > st)) for st in stems if any(h > st for h in heads)
+         and not any(f > st and f < min(h for h in heads if h > st) for f in folds)]
+if len(infer) >= 2:
+    st, en = infer[-2]
+    show(rows[st:en + 1], "inference call B=128 (second to last)")
