@@ -134,3 +134,198 @@ def test_isic_im_plus_toy_run(tmp_path):
     m0 = F.load_model(str(base / "models" / (stem.format(g=0) + "_topK_1.h5")))
     m1 = F.load_model(str(base / "models" / (stem.format(g=1) + "_topK_1.h5")))
     assert (m0.plan.alpha, m1.plan.alpha) == (0.5, 0.75)
+
+
+MULTI_CONFIG = """[DEFAULT]
+SEED = 42
+NUM_EPOCHS = 2
+BATCH_SIZE = 8
+LR = 0.003
+WD = 1e-4
+THRESHOLD = 0.5
+TOP_Ks = 2
+
+[SUIM]
+IMAGE_HEIGHT = 64
+IMAGE_WIDTH = 64
+IMAGE_CHANNELS = 3
+NUM_CLASSES = 3
+BASE_DIR = {base}/
+ALPHA = 0.5
+ACTIFU = relu
+ACTIFU_OUTPUT = softmax
+ERODE_KERNEL = 0
+DILATE_KERNEL = 0
+BLOCK_INPUT = True
+BLOCK_OUTPUT = True
+FILTER_INCONSISTENT_CLASS_PRED = False
+FREE_ROTATION = False
+NUM_IMAGES_IM_PLUS = 1
+"""
+
+MULTI_SETUP = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd import functions as F, paths
+from inconsistencymasks_amd.unet import get_unet
+rng = np.random.default_rng(0)
+def sample(n, d_img, d_mask):
+    os.makedirs(d_img, exist_ok=True); os.makedirs(d_mask, exist_ok=True)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in range(n):
+        cy, cx, r = rng.integers(20, 44), rng.integers(20, 44), rng.integers(8, 16)
+        cls = np.zeros((64, 64), np.uint8)
+        cls[yy > 40] = 1                                        # "sea floor"
+        cls[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = 2        # "object"
+        img = np.stack([60 + 70 * (cls == 1) + 150 * (cls == 2), 90 + 60 * (cls == 2), 200 - 80 * (cls == 1)], -1)
+        img = (img + rng.integers(-10, 10, (64, 64, 3))).clip(0, 255).astype(np.uint8)
+        F.write_png(os.path.join(d_img, f"s_{{i:04d}}.png"), img)
+        F.write_png(os.path.join(d_mask, f"s_{{i:04d}}.png"), cls)
+sample(16, paths.SUIM_TRAIN_LABELED_IMAGES_DIR, paths.SUIM_TRAIN_LABELED_MASKS_DIR)
+sample(24, paths.SUIM_TRAIN_UNLABELED_IMAGES_DIR, paths.SUIM_TRAIN_UNLABELED_MASKS_DIR)
+sample(8, paths.SUIM_VAL_IMAGES_DIR, paths.SUIM_VAL_MASKS_DIR)
+sample(8, paths.SUIM_TEST_IMAGES_DIR, paths.SUIM_TEST_MASKS_DIR)
+os.makedirs(paths.SUIM_MODEL_DIR, exist_ok=True)
+import torch
+names = sorted(os.listdir(paths.SUIM_TRAIN_LABELED_IMAGES_DIR))
+x = torch.from_numpy(np.stack([F.read_png(os.path.join(paths.SUIM_TRAIN_LABELED_IMAGES_DIR, n), 3) for n in names])).cuda()
+y = torch.from_numpy(np.stack([F.read_png(os.path.join(paths.SUIM_TRAIN_LABELED_MASKS_DIR, n), 1)[..., 0] for n in names])).cuda()
+for j in (1, 2):
+    m = get_unet(64, 64, 3, 3, 0.5, "relu", "softmax", seed=j)
+    for it in range(700):
+        m.train_step(x, y, 1, 3e-3 if it < 200 else 0.0, 1e-4 if it < 200 else 0.0)
+    m.repack()
+    F.save_model(m, os.path.join(paths.SUIM_MODEL_DIR, f"SUIM_subset_1_topK_{{j}}.h5"))
+"""
+
+
+@pytest.mark.parametrize("script,approach", [("10_SUIM_IM.py", "IM"), ("12_SUIM_IM+.py", "IM_plus")])
+def test_suim_driver_toy_run(tmp_path, script, approach):
+    """SUIM/10_SUIM_IM.py and SUIM/12_SUIM_IM+.py on a 3-class toy set: argmax IM, CCE training, multiclass benchmark."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(MULTI_CONFIG.format(base=base))
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1"}
+    subprocess.run([sys.executable, "-c", MULTI_SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "SUIM", script)], env=env, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = f"SUIM_{approach}_1_n2_gen0_e0_d0_bi_True_bo_True"
+    models = sorted(os.listdir(base / "models"))
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    rows = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert rows[0] == "modelname;mPA_val;mPA_test;mPA_train_unlabeled;mIoU_val;mIoU_test;mIoU_train_unlabeled"
+    vals = [float(v) for v in rows[1].split(";")[1:]]
+    assert len(rows) == 3 and all(0.0 <= v <= 1.0 for v in vals)
+    # (candidates train for 2 short epochs: their BN moving statistics are far from converged, so no accuracy bar here;
+    #  the 700-step gen-0 ensemble must agree on most pixels, though)
+    im_rows = (base / "csv" / f"mean_im_size_{stem}.csv").read_text().strip().splitlines()
+    assert all(float(v) < 0.5 * 64 * 64 for v in im_rows[1].split(";"))
+    sub = ("temp",) if approach == "IM_plus" else ()
+    unl = base.joinpath("train_unlabeled_predictions", approach, *sub, stem)
+    assert len(os.listdir(unl / "im")) == 24 and len(os.listdir(unl / "masks")) == len(os.listdir(unl / "images"))
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    m = F.read_png(str(unl / "masks" / sorted(os.listdir(unl / "masks"))[0]), 1)
+    assert set(np.unique(m)) <= {0, 1, 2}                  # class ids, not x255
+    pred_dir = base / "val_predictions" / approach / (stem + "_0")
+    assert any(n.endswith("_color.png") for n in os.listdir(pred_dir))
+
+
+HELA_CONFIG = """[DEFAULT]
+SEED = 42
+NUM_EPOCHS = 2
+BATCH_SIZE = 8
+LR = 0.003
+WD = 1e-4
+THRESHOLD = 0.5
+TOP_Ks = 2
+
+[HELA]
+IMAGE_HEIGHT = 64
+IMAGE_WIDTH = 64
+IMAGE_CHANNELS = 1
+NUM_CLASSES = 3
+BASE_DIR = {base}/
+ALPHA = 0.5
+ACTIFU = relu
+ACTIFU_OUTPUT = sigmoid
+ERODE_KERNEL = 0
+DILATE_KERNEL = 0
+BLOCK_INPUT = True
+BLOCK_OUTPUT = True
+FREE_ROTATION = True
+NUM_IMAGES_IM_PLUS = 1
+"""
+
+HELA_SETUP = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd import functions as F, paths
+from inconsistencymasks_amd.unet import get_unet
+rng = np.random.default_rng(0)
+yy, xx = np.mgrid[0:64, 0:64]
+def sample(n, d, tag):
+    for k in ("brightfield", "alive", "dead", "mod_position"):
+        os.makedirs(os.path.join(d, k), exist_ok=True)
+    for i in range(n):
+        bf = np.full((64, 64), 120, np.int64) + rng.integers(-8, 8, (64, 64))
+        alive = np.zeros((64, 64), np.uint8); dead = np.zeros((64, 64), np.uint8); pos = np.zeros((64, 64), np.uint8)
+        for cy, cx, is_dead in ((16, 16, 0), (16, 46, 1), (46, 30, int(rng.integers(0, 2)))):
+            cy += int(rng.integers(-4, 5)); cx += int(rng.integers(-4, 5))
+            cell = (yy - cy) ** 2 + (xx - cx) ** 2 < 64
+            bf[cell] += 70 if is_dead else -60
+            (dead if is_dead else alive)[cell] = 255
+            pos[(yy - cy) ** 2 + (xx - cx) ** 2 < 9] = 255
+        name = f"{{tag}}_{{i:04d}}.png"
+        F.write_png(os.path.join(d, "brightfield", name), bf.clip(0, 255).astype(np.uint8))
+        F.write_png(os.path.join(d, "alive", name), alive); F.write_png(os.path.join(d, "dead", name), dead)
+        F.write_png(os.path.join(d, "mod_position", name), pos)
+sample(16, paths.HELA_TRAIN_LABELED_DIR, "lab"); sample(24, paths.HELA_TRAIN_UNLABELED_DIR, "unl")
+sample(8, paths.HELA_VAL_DIR, "val"); sample(8, paths.HELA_TEST_DIR, "tst")
+os.makedirs(paths.HELA_MODEL_DIR, exist_ok=True)
+import torch
+bfd = os.path.join(paths.HELA_TRAIN_LABELED_DIR, "brightfield")
+items = [F.parse_image_hela(os.path.join(bfd, n), 1) for n in sorted(os.listdir(bfd))]
+x = torch.from_numpy(np.stack([it[0] for it in items])).cuda()
+y = torch.from_numpy(np.stack([it[1] for it in items])).cuda()
+for j in (1, 2):
+    m = get_unet(64, 64, 1, 3, 0.5, "relu", "sigmoid", seed=j)
+    for it in range(700):
+        m.train_step(x, y, 0, 3e-3 if it < 200 else 0.0, 1e-4 if it < 200 else 0.0)
+    m.repack()
+    F.save_model(m, os.path.join(paths.HELA_MODEL_DIR, f"HeLa_subset_1_topK_{{j}}.h5"))
+"""
+
+
+def test_hela_driver_toy_run(tmp_path):
+    """HeLa/09_HeLa_IM.py on a toy set: three binary IMs (>=) per image, position discs, 5 output directories, the
+    9-value result tuple, ranking by tuple index 4."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(HELA_CONFIG.format(base=base))
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1"}
+    subprocess.run([sys.executable, "-c", HELA_SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "HeLa", "09_HeLa_IM.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = "HeLa_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    models = sorted(os.listdir(base / "models"))
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    rows = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert rows[0].split(";") == ["modelname", "mIoU_val", "mIoU_ad_val", "mean_cell_count_error_val", "mIoU_test",
+                                  "mIoU_ad_test", "mean_cell_count_error_test", "mIoU_unlabeled", "mIoU_ad_unlabeled",
+                                  "mean_cell_count_error_unlabeled"]
+    assert len(rows) == 3 and len(rows[1].split(";")) == 10
+    unl = base / "train_unlabeled_predictions" / "IM" / stem
+    for k in ("brightfield", "alive", "dead", "mod_position"):
+        assert len(os.listdir(unl / k)) == 24 + 16                 # every unlabeled image + the labelled pairs
+    assert len(os.listdir(unl / "im")) == 24
+    # blocking: where the combined IM is set, brightfield and masks are zero
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    n = sorted(os.listdir(unl / "im"))[0]
+    im = F.read_png(str(unl / "im" / n), 1)[..., 0] > 0
+    for k in ("brightfield", "alive", "dead"):
+        assert not F.read_png(str(unl / k / n), 1)[..., 0][im].any()
