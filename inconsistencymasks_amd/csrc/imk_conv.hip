@@ -226,14 +226,14 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds; };
 
 // bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
-// DEEPB: long staging batches (all of a thread's items in flight at once) for launches that do not fill the chip --
-// there the kernel's duration is the latency chain of one workgroup; with several rounds of workgroups per CU the
-// shorter batches (fewer registers) are faster.
-template <int TH, int MT, int LM, bool DEEPB>
+// (Measured and dropped for the launches that do not fill the chip -- deep layers at batch 32: staging batches of 6-12
+// items per thread, 1.386 vs 1.369 ms per step; 1024-thread workgroups with one wave per tile row, 1.450 ms.)
+template <int TH, int MT, int LM>
 __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkConvGeom &gm, int bx, int by) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, mt_total = gm.mt_total, nc8 = gm.nc8, nc8p = gm.nc8p;
     const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp, w_in_lds = gm.w_in_lds;
-    constexpr int P = TH / 4;  // pixel groups (tile rows) per wave
+    constexpr int NW = 4, NT = 64 * NW;   // waves / threads per workgroup
+    constexpr int P = TH / NW;            // pixel groups (tile rows) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             // The copy is asynchronous (global_load_lds_dwordx4: global -> LDS without registers, one contiguous KB per
             // wave and instruction), so all of it is in flight while the input tile is staged below.
             const int n16 = MT * nsp * 64;   // 16-byte chunks; a multiple of 64, so the bound is wave-uniform
-            for (int i = t; i < n16; i += 256) {
+            for (int i = t; i < n16; i += NT) {
                 const int m = i / (nsp * 64);
                 int ct = by * MT + m;
                 if (ct >= mt_total) ct = mt_total - 1;   // padding rows of the last group: outputs are never stored
@@ -287,7 +287,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
         // clamped coordinates: no branch between them), the transforms (BN / pool / up+add / BN backward) follow, so a
         // thread pays one memory latency per batch.  Deep layers have 10-20 items per thread: 1-2 batches.
         if constexpr (LM == LM_U8) {     // uint8 input with 5-8 channels (never the shipped configs): simple path
-            for (int i = t; i < n_items; i += 256) {
+            for (int i = t; i < n_items; i += NT) {
                 const int pix = i / nc8_cur, c8 = i - pix * nc8_cur;
                 const int py = pix / WT, px = pix - py * WT;
                 const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
@@ -296,16 +296,16 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
                 *reinterpret_cast<f16x8 *>(s_tile + (pix * ps + c8) * 16) = v;
             }
         } else {
-            constexpr int BATCH = !DEEPB ? 4 : ((LM == LM_POOL) ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 6 : 12));
-            const int n_batches = (n_items + BATCH * 256 - 1) / (BATCH * 256);   // uniform trip count (barrier inside)
+            constexpr int BATCH = 4;
+            const int n_batches = (n_items + BATCH * NT - 1) / (BATCH * NT);   // uniform trip count (barrier inside)
             for (int bt = 0; bt < n_batches; ++bt) {
-                const int i0 = t + bt * BATCH * 256;
+                const int i0 = t + bt * BATCH * NT;
                 RawChunk<LM> r[BATCH];
                 int dst[BATCH], c8s[BATCH];
                 unsigned ok = 0;
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
-                    const int i = i0 + u * 256;
+                    const int i = i0 + u * NT;
                     const int ii = i < n_items ? i : t;          // idle slots repeat this thread's first item
                     const int pix = ii / nc8_cur;
                     const int c8 = ii - pix * nc8_cur;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     }
     if (want_stats) {  // workgroup-uniform branch
         __syncthreads();  // everyone is done reading the tile; reuse its LDS
-        float *s_red = reinterpret_cast<float *>(smem);  // [4 waves][2][16*MT]
+        float *s_red = reinterpret_cast<float *>(smem);  // [NW waves][2][16*MT]
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -427,16 +427,16 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             if (co < a.cs_out) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += s_red[(w * 2 + which) * 16 * MT + c];
+                for (int w = 0; w < NW; ++w) v += s_red[(w * 2 + which) * 16 * MT + c];
                 a.stats_partial[(size_t)bx * 2 * a.cs_out + which * a.cs_out + co] = v;
             }
         }
     }
 }
 
-template <int TH, int MT, int LM, bool DEEPB>
+template <int TH, int MT, int LM>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGeom gm) {
-    conv_mfma_body<TH, MT, LM, DEEPB>(a, gm, blockIdx.x, blockIdx.y);
+    conv_mfma_body<TH, MT, LM>(a, gm, blockIdx.x, blockIdx.y);
 }
 
 // =====================================================================================================
@@ -1122,7 +1122,7 @@ static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
     const int mt_total = (a.cout + 15) / 16;
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, TH);
     const size_t tile_bytes = (size_t)(TH + 2 * halo) * (TW + 2 * halo) * ps * 16;
-    const size_t stats_bytes = 4 * 2 * 16 * 4 * sizeof(float);
+    const size_t stats_bytes = 4 * 2 * 16 * 4 * sizeof(float);   // [4 waves][2][16 * MT <= 64]
     size_t lds = tile_bytes + 4 * (size_t)a.x.cs_in * sizeof(float);
     if (lds < stats_bytes) lds = stats_bytes;
     const size_t lds_base = lds;
@@ -1172,11 +1172,9 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         pr.bytes = conv_algorithmic_bytes(a);
         IMK_HIP(hipEventRecord(pr.e0, stream));
     }
-    const bool deepb = (long long)L.gx * L.gy <= 1024;   // at most ~2 rounds of workgroups: latency-bound launch
-#define IMK_MFMA_MT(TH, LM, DB) \
-    (L.mt == 4 ? launch(conv_mfma_kernel<TH, 4, LM, DB>) : (L.mt == 2 ? launch(conv_mfma_kernel<TH, 2, LM, DB>) : launch(conv_mfma_kernel<TH, 1, LM, DB>)))
-#define IMK_MFMA_TH(LM) (L.th == 16 ? (deepb ? IMK_MFMA_MT(16, LM, true) : IMK_MFMA_MT(16, LM, false)) \
-                                    : (deepb ? IMK_MFMA_MT(8, LM, true) : IMK_MFMA_MT(8, LM, false)))
+#define IMK_MFMA_MT(TH, LM) \
+    (L.mt == 4 ? launch(conv_mfma_kernel<TH, 4, LM>) : (L.mt == 2 ? launch(conv_mfma_kernel<TH, 2, LM>) : launch(conv_mfma_kernel<TH, 1, LM>)))
+#define IMK_MFMA_TH(LM) (L.th == 16 ? IMK_MFMA_MT(16, LM) : IMK_MFMA_MT(8, LM))
     switch (a.x.lmode) {
         case LM_RAW: rc = IMK_MFMA_TH(LM_RAW); break;
         case LM_AFFINE: rc = IMK_MFMA_TH(LM_AFFINE); break;
