@@ -140,7 +140,10 @@ int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int lay
  * agreement -> IM -> blocking without writing the probability stack.  One call = functions.py:2844-2887
  * minus file I/O, for a batch.  `params`/`packed` are arrays (host) of n_models device pointers.
  * binary heads (act_out = 0): outputs as imk_im_binary;  softmax heads: as imk_im_multiclass
- * (masks_out = final_out [B,H,W], pred_size unused, presence optional).                                */
+ * (masks_out = final_out [B,H,W], pred_size unused, presence optional).
+ * workspace: n_models * align256(B*H*W*n_out*4) for the probability stack + k * imk_unet_workspace_bytes(plan, B, 0),
+ * 1 <= k <= min(n_models, 3): with k > 1 the models run on k streams side by side (forked from and joined to
+ * `stream` with events; the call stays asynchronous), with k = 1 back to back.                          */
 int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
                         const float *const *params, const void *const *packed,
                         const uint8_t *x, int batch, float thr, int cmp_ge,

@@ -25,11 +25,12 @@ struct imk_unet_plan {
     int64_t n_total, n_trainable;
     int64_t packed_bytes;
     // Side stream for the weight-gradient kernels (off the dependency chain of the backward pass), forked
-    // from / joined to the caller's stream with events.  Created on the first training call.
+    // from / joined to the caller's stream with events (one fork per conv layer: 24).  Created on the first training call.
     mutable std::once_flag side_once;
-    mutable hipStream_t side = nullptr;
+    static constexpr int MAX_SIDE = 2;
+    mutable hipStream_t side[MAX_SIDE] = {};
     mutable hipEvent_t ev_fork[40] = {};
-    mutable hipEvent_t ev_join = nullptr;
+    mutable hipEvent_t ev_join[MAX_SIDE] = {};
     mutable bool side_ok = false;
     int find(const char *name) const {
         for (size_t i = 0; i < layers.size(); ++i) if (layers[i].name == name) return (int)i;

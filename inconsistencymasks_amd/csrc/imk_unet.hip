@@ -359,12 +359,13 @@ extern "C" int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out
 
 extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) {
     if (!plan) return;
-    if (plan->side) {
-        (void)hipStreamSynchronize(plan->side);
-        (void)hipStreamDestroy(plan->side);
-        for (auto &e : plan->ev_fork) if (e) (void)hipEventDestroy(e);
-        if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+    for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
+        if (!plan->side[i]) continue;
+        (void)hipStreamSynchronize(plan->side[i]);
+        (void)hipStreamDestroy(plan->side[i]);
+        if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
     }
+    for (auto &e : plan->ev_fork) if (e) (void)hipEventDestroy(e);
     delete plan;
 }
 
@@ -465,6 +466,21 @@ extern "C" int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mo
 }
 
 // Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
+// Side streams + fork/join events of a plan, created on first use (training: weight gradients; ensemble inference: one
+// model per stream).
+static bool ensure_side_streams(const imk_unet_plan *plan) {
+    std::call_once(plan->side_once, [plan]() {
+        bool ok = true;
+        for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
+            ok = ok && hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        plan->side_ok = ok;
+    });
+    return plan->side_ok;
+}
+
 extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, const float *const *params,
                                    const void *const *packed, const uint8_t *x, int batch, float thr, int cmp_ge,
                                    const uint8_t *img, int block_in, int block_out, uint8_t *img_out, uint8_t *masks_out,
@@ -478,11 +494,30 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
     // the probability stack must be contiguous [N,B,H,W,K]: only the last slab may be padded
     const size_t probs_exact = (size_t)batch * cf.h * cf.w * cf.n_out * sizeof(float);
     uint8_t *base = (uint8_t *)workspace;
+    // The models are independent until the IM kernel: with room for one activation workspace per stream (the caller
+    // passes probs + k * imk_unet_workspace_bytes, k <= 1 + MAX_SIDE) they run on k streams side by side -- the deep
+    // layers of one model fill the gaps of the other's.  With room for one only, they run back to back.
+    const int max_streams = 1 + imk_unet_plan::MAX_SIDE;
+    int n_slabs = (int)(((size_t)workspace_bytes - probs_one * n_models) / ws.total);
+    if (n_slabs > n_models) n_slabs = n_models;
+    if (n_slabs > max_streams) n_slabs = max_streams;
+    static const bool conc_off = []() { const char *e = getenv("IMK_ENSEMBLE_STREAMS"); return e && e[0] == '0'; }();
+    if (n_slabs > 1 && (conc_off || !ensure_side_streams(plan))) n_slabs = 1;
+    hipStream_t main_stream = (hipStream_t)stream_;
+    if (n_slabs > 1) {
+        IMK_HIP(hipEventRecord(plan->ev_fork[0], main_stream));
+        for (int s = 1; s < n_slabs; ++s) IMK_HIP(hipStreamWaitEvent(plan->side[s - 1], plan->ev_fork[0], 0));
+    }
     for (int m = 0; m < n_models; ++m) {
-        Ctx c{plan, make_topo(plan), ws, base + probs_one * n_models, params[m], (const uint8_t *)packed[m], batch, false,
-              (hipStream_t)stream_};
+        const int sl = m % n_slabs;
+        Ctx c{plan, make_topo(plan), ws, base + probs_one * n_models + ws.total * sl, params[m], (const uint8_t *)packed[m],
+              batch, false, sl == 0 ? main_stream : plan->side[sl - 1]};
         int rc = run_forward(c, x, (float *)(base + probs_exact * m), nullptr);
         if (rc) return rc;
+    }
+    for (int s = 1; s < n_slabs; ++s) {
+        IMK_HIP(hipEventRecord(plan->ev_join[s - 1], plan->side[s - 1]));
+        IMK_HIP(hipStreamWaitEvent(main_stream, plan->ev_join[s - 1], 0));
     }
     if (cf.act_out == 0)
         return imk_im_binary((const float *)base, n_models, batch, cf.h, cf.w, cf.n_out, thr, cmp_ge, img, cf.c_in, block_in,
@@ -507,11 +542,11 @@ struct Bwd {
     const uint8_t *x;
     float *grads;
     ImkCtl *ctl;
-    hipStream_t side;       // weight-gradient work runs here (== c.stream if no side stream is available)
-    long long side_max_pixels;   // layers with at most this many pixels run their wgrad on the side stream
+    int n_side;             // side streams in use (0: everything on c.stream); weight-gradient work is dealt round-robin
+    long long side_max_pixels;   // layers with at most this many pixels run their wgrad on a side stream
     ImkWgFinalJobs jobs{};
     int n_fork = 0;
-    bool used_side = false;
+    bool used_side[imk_unet_plan::MAX_SIDE] = {};
 
     int dy_rows[64] = {};   // per BN: statistics rows written by the kernel that produced dy (0 = none, run the prep pass)
 
@@ -587,15 +622,15 @@ struct Bwd {
     int wgrad(int conv, const f16 *dA_override = nullptr) {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
-        // Deep (small-map) layers launch too few workgroups to fill the chip: only those are forked onto the side
-        // stream, where they overlap with the main chain; the wide layers stay in line (they would only contend).
         const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
-        hipStream_t ws = (side != c.stream && small) ? side : c.stream;
-        if (ws != c.stream) {
+        hipStream_t ws = c.stream;
+        if (n_side > 0 && small) {
+            const int si = n_fork % n_side;
+            ws = c.p->side[si];
             hipEvent_t ev = c.p->ev_fork[n_fork++];
             IMK_HIP(hipEventRecord(ev, c.stream));
-            IMK_HIP(hipStreamWaitEvent(side, ev, 0));
-            used_side = true;
+            IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
+            used_side[si] = true;
         }
         ImkWgradArgs a{};
         wgrad_args(conv, dA_override, a);
@@ -603,9 +638,9 @@ struct Bwd {
         if (rc) return rc;
         return wgrad_job(conv, a);
     }
-    // wgrad + dgrad of `conv` (both read its pre-activation gradient).  Running the two as one launch (dgrad blocks and
-    // wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per step), the
-    // common LDS footprint of the fused kernel leaves one workgroup per CU, so the two halves still run back to back.
+    // wgrad (side stream) + dgrad of `conv`; both read its pre-activation gradient.  Running the two as ONE launch
+    // (dgrad and wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per
+    // step) -- the common LDS footprint of the fused kernel leaves one workgroup per CU.
     int wgrad_dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
         int rc = wgrad(conv);
         if (rc) return rc;
@@ -613,9 +648,10 @@ struct Bwd {
     }
     // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
     int finish_wgrads() {
-        if (used_side) {   // join: the reductions below read the side stream's partials
-            IMK_HIP(hipEventRecord(c.p->ev_join, side));
-            IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join, 0));
+        for (int si = 0; si < n_side; ++si) {   // join: the reductions below read the side streams' partials
+            if (!used_side[si]) continue;
+            IMK_HIP(hipEventRecord(c.p->ev_join[si], c.p->side[si]));
+            IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join[si], 0));
         }
         return imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, c.stream);
     }
@@ -686,17 +722,15 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
                                 imk_pad8(o.cin), o.cout, cf.act_out, n_pix, y, sv.ctl, dlogit, loss_partial, stream));
     }
 
-    std::call_once(plan->side_once, [plan]() {
-        bool ok = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) == hipSuccess;
-        for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) == hipSuccess;
-        plan->side_ok = ok;
-    });
-    // Optional side stream for the deep, small-map layers (IMK_SIDE_PIXELS = largest B*H*W that is forked; default 0 =
-    // never: measured 1.54 ms per step with and without, so the simpler single-stream order is kept).
-    // Forking the wide layers too was measured slower (1.91 vs 1.76 ms per step): they fill the chip by themselves.
-    static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : 0LL; }();
-    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0) ? plan->side : stream, side_px};
+    ensure_side_streams(plan);
+    // The weight-gradient kernels run on a side stream, forked after the kernel that produced their gradient operand and
+    // joined before the final reduction: nothing on the backward chain depends on them, and they fill the gaps that the
+    // latency-bound kernels of the chain leave (1.280 vs 1.365 ms per step with all 24 on the side stream; forking only
+    // the deep layers' was neutral).  IMK_SIDE_PIXELS = largest B*H*W that is forked (0: single stream).
+    static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : (1LL << 62); }();
+    static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
+                                         return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
+    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0) ? n_side_env : 0, side_px};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
     {

@@ -188,7 +188,8 @@ class EnsembleIM:
         dev = x_u8.device
         if self._ws is None or self._ws_batch < b:
             per = ((b * p.h * p.w * p.n_out * 4 + 255) // 256) * 256
-            self._ws = torch.empty(per * n + p.workspace_bytes(b, 0), dtype=torch.uint8, device=dev)
+            # one activation workspace per concurrently running model (imk_unet_forward_im puts up to 3 on streams)
+            self._ws = torch.empty(per * n + min(n, 3) * p.workspace_bytes(b, 0), dtype=torch.uint8, device=dev)
             self._ws_batch = b
         binary = p.act_out == "sigmoid"
         kb = p.n_out if binary else 1
