@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--infer-batch", type=int, default=128)
+    ap.add_argument("--infer-batch", type=int, default=256)
     ap.add_argument("--images", type=int, default=U_UNLABELED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch event timing (roofline fields empty)")
@@ -277,7 +277,23 @@ def main():
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
                 "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
                 "share_of_step_time": round(pms[v] * args.prof_period / (1000 * elapsed), 3), "sampling": f"every {args.prof_period}th conv launch of the timed region",
-                "all_conv_variants": conv_all}
+                "all_conv_variants": conv_all,
+                "note": "timed region: the weight-gradient kernels (side stream) and the ensemble's second model run beside "
+                        "this kernel, its event-bracketed durations include that sharing; 'exclusive' = the same workload "
+                        "with every kernel alone on one stream (imk_debug_single_stream)"}
+    # the same generation once more with every kernel alone on the stream: the kernel's own rate
+    imk_lib.imk_debug_single_stream(1)
+    imk_lib.imk_prof_enable(args.prof_period if not args.no_prof else 0)
+    prof_collect()
+    generation()
+    barrier()
+    xc, xms, xby = prof_collect()
+    imk_lib.imk_prof_enable(0)
+    imk_lib.imk_debug_single_stream(0)
+    if xms[v]:
+        x_ach = xby[v] / xms[v] / 1e6
+        roofline["exclusive"] = {"achieved": round(x_ach, 1), "frac": round(x_ach / HBM_PEAK_GBS, 4),
+                                 "launches": int(xc[v]), "avg_us_per_launch": round(1000 * xms[v] / max(xc[v], 1), 2)}
 
     # ---- the fused IM kernel on the same shapes (HBM-bound; SURVEY 8d: 1 MiB / image) ------------------------
     probs = torch.stack([m.predict_device(x_unl[:args.infer_batch]) for m in models], 0)

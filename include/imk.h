@@ -214,6 +214,10 @@ int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h,
  * every layer.  Global flag; training always stores them (the backward pass needs them). */
 int imk_debug_materialize(int on);
 
+/* Measurement: with on = 1 every kernel runs on the caller's stream (no side stream for the weight gradients, the
+ * ensemble's models back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
+int imk_debug_single_stream(int on);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the convolution kernel, on the stream the
  * kernel is launched on.  imk_prof_enable(k) makes every k-th conv launch record an event pair (0 = off);

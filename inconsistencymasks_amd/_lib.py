@@ -60,6 +60,7 @@ SIGNATURES = {
     "imk_eval_binary": (c_int, [c_void_p, c_float, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_eval_multiclass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_debug_materialize": (c_int, [c_int]),
+    "imk_debug_single_stream": (c_int, [c_int]),
     "imk_prof_enable": (c_int, [c_int]),
     "imk_prof_collect": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -390,6 +390,9 @@ extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer
 
 extern "C" int imk_debug_materialize(int on) { g_materialize = on != 0; return IMK_OK; }
 
+static bool g_single_stream = false;   // imk_debug_single_stream(1): no side streams (kernels run alone: exclusive timings)
+extern "C" int imk_debug_single_stream(int on) { g_single_stream = on != 0; return IMK_OK; }
+
 extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return plan ? plan->packed_bytes : IMK_EINVAL; }
 
 // ctl / stats: non-null after an optimizer step -- the first packing launch then also closes the step (loss-scale and
@@ -502,7 +505,7 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
     if (n_slabs > n_models) n_slabs = n_models;
     if (n_slabs > max_streams) n_slabs = max_streams;
     static const bool conc_off = []() { const char *e = getenv("IMK_ENSEMBLE_STREAMS"); return e && e[0] == '0'; }();
-    if (n_slabs > 1 && (conc_off || !ensure_side_streams(plan))) n_slabs = 1;
+    if (n_slabs > 1 && (conc_off || g_single_stream || !ensure_side_streams(plan))) n_slabs = 1;
     hipStream_t main_stream = (hipStream_t)stream_;
     if (n_slabs > 1) {
         IMK_HIP(hipEventRecord(plan->ev_fork[0], main_stream));
@@ -730,7 +733,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : (1LL << 62); }();
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0) ? n_side_env : 0, side_px};
+    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0 && !g_single_stream) ? n_side_env : 0, side_px};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
     {

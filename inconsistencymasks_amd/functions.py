@@ -37,7 +37,7 @@ THRESHOLD = float(_D.get("THRESHOLD", 0.5))
 NUM_EPOCHS = int(_D.get("NUM_EPOCHS", 50))
 NUM_EPOCHS_CS = int(_D.get("NUM_EPOCHS_CS", 100))
 
-INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 128))
+INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 256))
 _IO_THREADS = int(os.environ.get("IMK_IO_THREADS", 8))
 
 
