@@ -621,25 +621,49 @@ struct Bwd {
         return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
     }
     // Weight/bias gradient of `conv`: depends only on dA[conv] (just produced on the main stream) and on forward
-    // tensors, and nothing downstream in the backward pass depends on it -> fork it onto the side stream.
-    int wgrad(int conv, const f16 *dA_override = nullptr) {
-        const ImkLayer &l = c.p->layers[conv];
-        const Dim d = res_dim(c.p->cfg, l.res);
-        const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
-        hipStream_t ws = c.stream;
-        if (n_side > 0 && small) {
-            const int si = n_fork % n_side;
-            ws = c.p->side[si];
-            hipEvent_t ev = c.p->ev_fork[n_fork++];
-            IMK_HIP(hipEventRecord(ev, c.stream));
-            IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
-            used_side[si] = true;
-        }
+    // tensors, and nothing downstream in the backward pass depends on it -> it goes to the side stream.  Forking costs
+    // an event record on the main stream (a barrier packet: ~6 us before the next kernel starts), so the weight
+    // gradients of a whole resolution block are queued and forked together (flush_wgrads: 11 forks per step, not 24).
+    struct Pending { int conv; const f16 *dA_override; };
+    Pending pending[8];
+    int n_pending = 0;
+    int launch_wgrad(int conv, const f16 *dA_override, hipStream_t ws) {
         ImkWgradArgs a{};
         wgrad_args(conv, dA_override, a);
         int rc = imk_launch_wgrad(a, ws);
         if (rc) return rc;
         return wgrad_job(conv, a);
+    }
+    int wgrad(int conv, const f16 *dA_override = nullptr) {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
+        if (n_side > 0 && small) {
+            if (n_pending == 8) { int rc = flush_wgrads(); if (rc) return rc; }
+            pending[n_pending++] = Pending{conv, dA_override};
+            // full-resolution layers: fork at once -- their kernels are long (the bubble is small against them) and the
+            // last block's weight gradients would otherwise all start after the main chain has ended
+            return l.res == 0 ? flush_wgrads() : IMK_OK;
+        }
+        return launch_wgrad(conv, dA_override, c.stream);
+    }
+    int flush_wgrads() {
+        if (n_pending == 0) return IMK_OK;
+        const int si = n_fork % n_side;
+        hipStream_t ws = c.p->side[si];
+        hipEvent_t ev = c.p->ev_fork[n_fork++];
+        IMK_HIP(hipEventRecord(ev, c.stream));
+        IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
+        used_side[si] = true;
+        for (int i = 0; i < n_pending; ++i) {
+            int rc = launch_wgrad(pending[i].conv, pending[i].dA_override, ws);
+            if (rc) return rc;
+        }
+        n_pending = 0;
+        // ... and their split reductions right behind them, so that only the last layers' are left for the end of the step
+        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, ws);
+        jobs = ImkWgFinalJobs{};
+        return rc;
     }
     // wgrad (side stream) + dgrad of `conv`; both read its pre-activation gradient.  Running the two as ONE launch
     // (dgrad and wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per
@@ -651,6 +675,12 @@ struct Bwd {
     }
     // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
     int finish_wgrads() {
+        // what is still queued (the stem's weight gradient) has nothing left to overlap with: main stream
+        for (int i = 0; i < n_pending; ++i) {
+            int rc = launch_wgrad(pending[i].conv, pending[i].dA_override, c.stream);
+            if (rc) return rc;
+        }
+        n_pending = 0;
         for (int si = 0; si < n_side; ++si) {   // join: the reductions below read the side streams' partials
             if (!used_side[si]) continue;
             IMK_HIP(hipEventRecord(c.p->ev_join[si], c.p->side[si]));
@@ -759,11 +789,13 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.wgrad_dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr, t.d_bna[j]));
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
         OK(b.wgrad_dgrad(t.d_ca[j], dU, nullptr));
+        OK(b.flush_wgrads());   // the block's weight gradients (and the head's, for the first block) -> side stream
     }
     // bottleneck: dy = 2x2 sum of dU[decoder 6]
     OK(b.bn_bwd(t.b_bn, 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[0])));
     OK(b.wgrad_dgrad(t.b_c1, c.dA(t.b_c3), c.act(t.b_c3)));
     OK(b.wgrad_dgrad(t.b_c3, reinterpret_cast<f16 *>(c.base + c.ws.dP[3]), nullptr));
+    OK(b.flush_wgrads());
     // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
     for (int i = 3; i >= 0; --i) {
         OK(b.bn_bwd(t.e_bn[i], 1, reinterpret_cast<f16 *>(c.base + c.ws.dU[3 - i]),
@@ -771,6 +803,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.wgrad_dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
         f16 *dst = i > 0 ? reinterpret_cast<f16 *>(c.base + c.ws.dP[i - 1]) : c.dy(t.in_bn);
         OK(b.wgrad_dgrad(t.e_c3[i], dst, nullptr, i > 0 ? -1 : t.in_bn));
+        OK(b.flush_wgrads());
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));
