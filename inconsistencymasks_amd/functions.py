@@ -459,8 +459,7 @@ def _grad_allreduce(model):
     d = _dist()
     if not d:
         return 1.0
-    d.all_reduce(model.grads)       # one flat fp32 bucket per step (RCCL over xGMI)
-    d.all_reduce(model.stats)       # loss and found_inf ride along (4 floats)
+    d.all_reduce(model.grads_and_stats)   # one flat fp32 bucket per step (RCCL over xGMI); loss, found_inf ride along
     return 1.0 / d.get_world_size()
 
 

@@ -198,8 +198,10 @@ class UNet:
     def init_train_state(self):
         self.train_state = torch.empty(self.plan.state_bytes, dtype=torch.uint8, device=self.device)
         check(lib.imk_unet_state_init(self.plan.ptr, self.train_state.data_ptr(), _stream()), "imk_unet_state_init")
-        self.grads = torch.zeros(self.plan.n_trainable, dtype=torch.float32, device=self.device)
-        self.stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # gradients and the 4 step statistics share one buffer: a data-parallel step is ONE all-reduce (grads_and_stats)
+        self.grads_and_stats = torch.zeros(self.plan.n_trainable + 4, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_and_stats[:self.plan.n_trainable]
+        self.stats = self.grads_and_stats[self.plan.n_trainable:]
 
     def fwd_bwd(self, x_u8, y_u8, loss_kind):
         """One forward/backward on device batches; fills self.grads (unscaled) and self.stats."""

@@ -20,8 +20,9 @@ WORKER = textwrap.dedent("""
     mean = round(tot / cnt, 0)
     class M: pass
     m = M()
-    m.grads = torch.full((5,), float(dist.get_rank() + 1))
-    m.stats = torch.tensor([float(dist.get_rank()), 0.0, 1.0, 0.0])
+    m.grads_and_stats = torch.cat([torch.full((5,), float(dist.get_rank() + 1)),          # the model's one flat bucket:
+                                   torch.tensor([float(dist.get_rank()), 0.0, 1.0, 0.0])])   # gradients | step statistics
+    m.grads, m.stats = m.grads_and_stats[:5], m.grads_and_stats[5:]
     scale = F._grad_allreduce(m)
     print(json.dumps({"rank": dist.get_rank(), "n": len(mine), "mean": mean, "g": (m.grads * scale).tolist(),
                       "stats": m.stats.tolist()}))
