@@ -8,7 +8,7 @@ struct ImkCtl {
     float inv_loss_scale;
     int good_steps;        // consecutive finite steps since the last scale change
     int step;              // number of applied optimizer steps
-    float found_inf;       // set to 1 by any gradient kernel that sees a non-finite value in this step
+    float found_inf;       // unused (the overflow flag of a step lives in its stats[1], where the all-reduce sees it)
     float pad[3];
 };
 
@@ -26,10 +26,9 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
 int imk_loss_blocks(long long n_pix);
 // training: head (BN on load, fp32 1x1 conv, sigmoid / softmax) + loss + d(loss * scale)/d(logits), no probability tensor
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
-                         int K, int softmax, long long n_pix, const uint8_t *y, ImkCtl *ctl, f16 *dlogit,
-                         float *loss_partial, hipStream_t stream);
-int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
-                             hipStream_t stream);
+                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats,
+                         f16 *dlogit, float *loss_partial, hipStream_t stream);
+int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, float *stats, hipStream_t stream);
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream);

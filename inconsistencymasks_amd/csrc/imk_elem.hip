@@ -361,8 +361,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                                                         const float *__restrict__ sh, const float *__restrict__ w,
                                                         const float *__restrict__ bias, int cin, int K, int softmax,
                                                         long long n_pix, const uint8_t *__restrict__ y,
-                                                        ImkCtl *__restrict__ ctl, int cs_out,
-                                                        f16 *__restrict__ dlogit, float *__restrict__ loss_partial) {
+                                                        const ImkCtl *__restrict__ ctl, float *__restrict__ stats,
+                                                        int cs_out, f16 *__restrict__ dlogit,
+                                                        float *__restrict__ loss_partial) {
     extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
     float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
     for (int i = threadIdx.x; i < K * CS; i += 256) {
@@ -374,9 +375,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
     __syncthreads();
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     const float S = ctl->loss_scale;
-    // start of the step's gradient part: clear the overflow flag (every kernel that can set it runs after this one,
-    // the optimizer step that consumed the previous value ran before it)
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->found_inf = 0.f;
+    // start of the step's gradient part: clear the overflow flag stats[1] (every kernel that can set it runs after this
+    // one, the optimizer step that consumed the previous value ran before it) and note the scale / step in use
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[1] = 0.f; stats[2] = S; stats[3] = (float)ctl->step; }
     float l = 0.f;
     if (p < n_pix) {
         float xin[CS];
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
 //       softmax ACTIVATION's cached logits, so there is no probability clipping in loss or gradient; p_t is only
 //       floored at FLT_MIN so that an fp32 underflow reports 87.3 instead of inf)
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int n, double denom,
-                                                            const ImkCtl *__restrict__ ctl, float *__restrict__ stats) {
+                                                            float *__restrict__ stats) {
     __shared__ double r[256];
     double s = 0;
     for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {     // 8 independent loads in flight per thread; same summation order
@@ -461,12 +462,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
         if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        stats[0] = (float)(r[0] / denom);
-        stats[1] = ctl->found_inf;
-        stats[2] = ctl->loss_scale;
-        stats[3] = (float)ctl->step;
-    }
+    if (threadIdx.x == 0) stats[0] = (float)(r[0] / denom);   // stats[1..3]: head_loss_kernel and the gradient kernels
 }
 
 // ---- optimizer --------------------------------------------------------------------------------------
@@ -571,13 +567,13 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
 int imk_loss_blocks(long long n_pix) { return (int)((n_pix + 255) / 256); }
 
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
-                         int K, int softmax, long long n_pix, const uint8_t *y, ImkCtl *ctl, f16 *dlogit,
-                         float *loss_partial, hipStream_t stream) {
+                         int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats,
+                         f16 *dlogit, float *loss_partial, hipStream_t stream) {
     if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = imk_loss_blocks(n_pix);
     const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
     const int cs_out = imk_pad8(K);
-#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, cs_out, dlogit, loss_partial)
+#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, stats, cs_out, dlogit, loss_partial)
     switch (cs) {
         case 8: IMK_HL(8); break;
         case 16: IMK_HL(16); break;
@@ -591,10 +587,9 @@ int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const f
 }
 
 
-int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, const ImkCtl *ctl, float *stats,
-                             hipStream_t stream) {
+int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, float *stats, hipStream_t stream) {
     const double denom = kind == 0 ? (double)n_pix * K : (double)n_pix;
-    loss_finalize_kernel<<<1, 256, 0, stream>>>(loss_partial, imk_loss_blocks(n_pix), denom, ctl, stats);
+    loss_finalize_kernel<<<1, 256, 0, stream>>>(loss_partial, imk_loss_blocks(n_pix), denom, stats);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

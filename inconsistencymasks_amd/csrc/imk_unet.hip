@@ -545,6 +545,7 @@ struct Bwd {
     const uint8_t *x;
     float *grads;
     ImkCtl *ctl;
+    float *found_inf;       // = stats + 1: set to 1 by any gradient kernel that sees a non-finite value
     int n_side;             // side streams in use (0: everything on c.stream); weight-gradient work is dealt round-robin
     long long side_max_pixels;   // layers with at most this many pixels run their wgrad on a side stream
     ImkWgFinalJobs jobs{};
@@ -661,7 +662,7 @@ struct Bwd {
         }
         n_pending = 0;
         // ... and their split reductions right behind them, so that only the last layers' are left for the end of the step
-        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, ws);
+        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, found_inf, ws);
         jobs = ImkWgFinalJobs{};
         return rc;
     }
@@ -686,7 +687,7 @@ struct Bwd {
             IMK_HIP(hipEventRecord(c.p->ev_join[si], c.p->side[si]));
             IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join[si], 0));
         }
-        return imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, &ctl->found_inf, c.stream);
+        return imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, found_inf, c.stream);
     }
     // BN backward for `bn`: per-channel coefficients of  dz = A*dy + B*z + C  (+ gamma/beta gradients).  The
     // reduction (sum dy, sum dy*z) comes from the kernel that produced dy when there was exactly one (dy_rows),
@@ -710,7 +711,7 @@ struct Bwd {
             rows = imk_bn_prep_blocks(c.B, d.h, d.w, cs);
         }
         return imk_launch_bn_bwd_coef(partial, rows, b.cout, cs, (double)c.B * d.h * d.w, c.params + b.off_w, save, save + cs,
-                                      &ctl->inv_loss_scale, coef, grads + b.off_w, grads + b.off_b, &ctl->found_inf, c.stream);
+                                      &ctl->inv_loss_scale, coef, grads + b.off_w, grads + b.off_b, found_inf, c.stream);
     }
 };
 }  // namespace
@@ -752,7 +753,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         const ImkLayer &o = plan->layers[t.out];
         const int bn = t.d_bnb[3];
         OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(bn), c.bn_shift(bn), params + o.off_w, params + o.off_b, o.cin,
-                                imk_pad8(o.cin), o.cout, cf.act_out, n_pix, y, sv.ctl, dlogit, loss_partial, stream));
+                                imk_pad8(o.cin), o.cout, cf.act_out, n_pix, y, sv.ctl, stats, dlogit, loss_partial, stream));
     }
 
     ensure_side_streams(plan);
@@ -763,9 +764,14 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : (1LL << 62); }();
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, x, grads, sv.ctl, (plan->side_ok && side_px > 0 && !g_single_stream) ? n_side_env : 0, side_px};
+    Bwd b{c, x, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !g_single_stream) ? n_side_env : 0, side_px};
     // head: its "dA" is dlogit
     OK(b.wgrad(t.out, dlogit));
+    // the loss value only needs head_loss_kernel's partials: its reduction rides on the side stream, behind the head's
+    // weight gradient, instead of sitting at the end of the step
+    const bool loss_on_side = b.n_side > 0 && b.n_fork > 0;
+    if (loss_on_side)
+        OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, plan->side[(b.n_fork - 1) % b.n_side]));
     {
         const ImkLayer &l = plan->layers[t.out];
         ImkConvArgs a{};
@@ -808,7 +814,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));
     OK(b.finish_wgrads());
-    OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, sv.ctl, stats, stream));
+    if (!loss_on_side) OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, stream));
 #undef OK
     return IMK_OK;
 }

@@ -58,14 +58,14 @@ __global__ void finalize_kernel(const float *partial, int rows, float *result) {
 }
 
 int main() {
-    const int n_tiles = 32 * 256;   // 32 images of 256 tiles -> 32 MiB in, 32 MiB out
+    const int n_tiles = getenv("PROBE_TILES") ? atoi(getenv("PROBE_TILES")) : 32 * 256;   // default: 32 images of 256 tiles -> 32 MiB in, 32 MiB out
     uint4 *in, *out; float *partial, *result; int *counter;
     hipMalloc(&in, (size_t)n_tiles * 4096); hipMalloc(&out, (size_t)n_tiles * 4096);
     hipMalloc(&partial, 1024 * 16 * 4); hipMalloc(&result, 64); hipMalloc(&counter, 4);
     hipMemset(in, 0, (size_t)n_tiles * 4096); hipMemset(counter, 0, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 2; ++mode) {
-        for (int grid : {256, 1024, 4096}) {
+        for (int grid : {128, 256, 512, 1024}) {
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
                 for (int i = 0; i < 200; ++i) {
