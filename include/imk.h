@@ -167,7 +167,9 @@ int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, voi
                      float *grads, float *stats, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* tensorflow_addons AdamW (functions.py:215): var -= wd*var; Adam(b1,b2,eps) with bias-corrected lr.
- * Skips the update (and halves the dynamic loss scale) when stats[1] != 0; re-packs the weights.
+ * Skips the update (and halves the dynamic loss scale) when stats[1] != 0; re-packs the conv weights for the next
+ * training step.  It does NOT refresh the folded inference BatchNorm statistics (training never reads them):
+ * call imk_unet_pack_weights before the next imk_unet_forward / imk_unet_forward_im.
  * grad_scale multiplies grads first (1/world_size after a sum all-reduce).                            */
 int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, void *state,
                         const float *grads, const float *stats, float grad_scale,

@@ -398,7 +398,7 @@ extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return pla
 // ctl / stats: non-null after an optimizer step -- the first packing launch then also closes the step (loss-scale and
 // step-counter update), which saves a launch of its own.
 static int pack_weights(const imk_unet_plan *plan, const float *params, void *packed, hipStream_t stream, ImkCtl *ctl,
-                        const float *stats) {
+                        const float *stats, bool fold_bn) {
     IMK_CHECK_ARG(plan && params && packed);
     uint8_t *pk = (uint8_t *)packed;
     const int out_idx = plan->find("out");
@@ -427,11 +427,11 @@ static int pack_weights(const imk_unet_plan *plan, const float *params, void *pa
     int rc = flush_pack();
     if (rc) return rc;
     if (pj.ctl) return IMK_EINVAL;   // the step must have been closed by a packing launch
-    return imk_launch_bn_fold_jobs(fj, stream);
+    return fold_bn ? imk_launch_bn_fold_jobs(fj, stream) : IMK_OK;
 }
 
 extern "C" int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream_) {
-    return pack_weights(plan, params, packed, (hipStream_t)stream_, nullptr, nullptr);
+    return pack_weights(plan, params, packed, (hipStream_t)stream_, nullptr, nullptr, true);
 }
 
 extern "C" int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode) {
@@ -827,5 +827,6 @@ extern "C" int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, voi
     int rc = imk_launch_adamw(params, sv.m, sv.v, grads, plan->n_trainable, sv.ctl, stats, grad_scale, lr, wd, beta1, beta2,
                               eps, (hipStream_t)stream_);
     if (rc) return rc;
-    return pack_weights(plan, params, packed, (hipStream_t)stream_, sv.ctl, stats);
+    // conv weights only: training does not read the folded inference statistics (imk_unet_pack_weights refreshes them)
+    return pack_weights(plan, params, packed, (hipStream_t)stream_, sv.ctl, stats, false);
 }

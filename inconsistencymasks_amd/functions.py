@@ -171,8 +171,7 @@ class EnsembleIM:
         self.models = list(models)
         self.plan = models[0].plan
         for m in models:
-            if not m._packed_ok:
-                m.repack()
+            m.ready_for_inference()
         import ctypes
         n = len(models)
         self._params = (ctypes.c_void_p * n)(*[m.params.data_ptr() for m in models])

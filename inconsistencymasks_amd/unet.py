@@ -93,18 +93,24 @@ class UNet:
         self.params = flat.to(self.device)
         self.packed = torch.empty(self.plan.packed_bytes, dtype=torch.uint8, device=self.device)
         self._ws = {}
-        self._packed_ok = False
+        self._packed_ok = False      # packed conv weights match params
+        self._fold_ok = False        # folded inference BN statistics match params (moving statistics)
         self.train_state = None
 
     # ---- parameters -------------------------------------------------------------------------------
+    def ready_for_inference(self):
+        """training steps re-pack the conv weights but leave the folded BN statistics stale: refresh if needed"""
+        if not (self._packed_ok and self._fold_ok):
+            self.repack()
+
     def repack(self):
         check(lib.imk_unet_pack_weights(self.plan.ptr, self.params.data_ptr(), self.packed.data_ptr(), _stream()),
               "imk_unet_pack_weights")
-        self._packed_ok = True
+        self._packed_ok = self._fold_ok = True
 
     def set_params(self, flat):
         self.params.copy_(torch.as_tensor(flat, dtype=torch.float32).to(self.device))
-        self._packed_ok = False
+        self._packed_ok = self._fold_ok = False
 
     def state_dict(self):
         """name -> CPU tensor, Keras shapes (conv kernels HWIO)."""
@@ -166,8 +172,7 @@ class UNet:
 
     def predict_device(self, x_u8):
         """uint8 device tensor [B,H,W,C] -> float32 device tensor [B,H,W,K]."""
-        if not self._packed_ok:
-            self.repack()
+        self.ready_for_inference()
         b = x_u8.shape[0]
         ws = self.workspace(b, 0)
         probs = torch.empty((b, self.plan.h, self.plan.w, self.plan.n_out), dtype=torch.float32, device=self.device)
@@ -209,6 +214,7 @@ class UNet:
             self.init_train_state()
         if not self._packed_ok:
             self.repack()
+        self._fold_ok = False        # the step updates the moving statistics
         b = x_u8.shape[0]
         ws = self.workspace(b, 1)
         check(lib.imk_unet_fwd_bwd(self.plan.ptr, self.params.data_ptr(), self.packed.data_ptr(),
