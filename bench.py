@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--images", type=int, default=U_UNLABELED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch event timing (roofline fields empty)")
-    ap.add_argument("--prof-period", type=int, default=5, help="time every k-th conv launch with HIP events")
+    ap.add_argument("--prof-period", type=int, default=23, help="time every k-th conv launch with HIP events")
     ap.add_argument("--pretrain-steps", type=int, default=300)
     ap.add_argument("--bn-settle-steps", type=int, default=600)
     args = ap.parse_args()
@@ -235,8 +235,9 @@ def main():
     setup_prof = prof_collect()
     rec = []
     t0 = time.perf_counter()
-    # Sampling (every 5th launch) keeps the cost of the event records (~10 % of a training step if every launch is
-    # bracketed) near 2 %; 5 is coprime to the 39 conv launches of a training step and the 17 of a forward.
+    # Sampling: an event record is a barrier packet on the stream (~5 us before the next kernel starts), so bracketing
+    # every conv launch costs ~10 % of a training step and every 5th still 5 %; every 23rd launch (prime, coprime to the
+    # 39 conv launches of a training step and the 17 of a forward) costs ~1 % and still yields ~450 samples.
     for k in range(args.steps):
         generation(rec)
     barrier()
@@ -283,7 +284,7 @@ def main():
                         "with every kernel alone on one stream (imk_debug_single_stream)"}
     # the same generation once more with every kernel alone on the stream: the kernel's own rate
     imk_lib.imk_debug_single_stream(1)
-    imk_lib.imk_prof_enable(args.prof_period if not args.no_prof else 0)
+    imk_lib.imk_prof_enable(5 if not args.no_prof else 0)     # outside the timed region: dense sampling
     prof_collect()
     generation()
     barrier()
