@@ -212,9 +212,9 @@ def main():
         student._packed_ok = False
         student.init_train_state()
         perm = torch.randperm(n_train, device=dev, generator=gen_perm)
+        tx, ty = tx[perm], ty[perm]          # the epoch's shuffle as one gather; batches are then contiguous views
         for s in range(steps):
-            idx = perm[s * BATCH:(s + 1) * BATCH]
-            student.fwd_bwd(tx[idx].contiguous(), ty[idx].contiguous(), 0)
+            student.fwd_bwd(tx[s * BATCH:(s + 1) * BATCH], ty[s * BATCH:(s + 1) * BATCH], 0)
             scale = F._grad_allreduce(student)
             student.adamw_step(LR, WD, grad_scale=scale)
         e2.record()

@@ -447,11 +447,12 @@ class _EpochLoader:
     def next_batch(self):
         if self.x is None:
             self._load()
-        if not self._order:
-            perm = self.rng.permutation(len(self.files))
-            self._order = [perm[i:i + self.batch] for i in range(0, len(perm), self.batch)]
-        idx = torch.as_tensor(self._order.pop(0), device="cuda")
-        return self.x[idx].contiguous(), self.y[idx].contiguous()
+        if not self._order:      # new pass: one shuffled copy of the set, batches are contiguous views of it
+            perm = torch.as_tensor(self.rng.permutation(len(self.files)), device="cuda")
+            self._px, self._py = self.x[perm], self.y[perm]
+            self._order = [(i, min(i + self.batch, len(perm))) for i in range(0, len(perm), self.batch)]
+        lo, hi = self._order.pop(0)
+        return self._px[lo:hi], self._py[lo:hi]
 
 
 def _grad_allreduce(model):
