@@ -112,6 +112,27 @@ def cpu_baseline():
             "t_infer_per_image_s": round(t_inf, 5), "t_im_per_image_s": round(t_im, 6), "t_train_step_s": round(t_step, 4)}
 
 
+def png_io_rate(images):
+    """PNG encode / decode rate of the host path the directory API uses (Pillow on a thread pool; SURVEY H5: excluded
+    from the headline on both the GPU and the CPU side, reported separately)."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    threads = int(os.environ.get("IMK_IO_THREADS", 8))
+    def enc(a):
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, format="PNG", compress_level=1)
+        return b.getvalue()
+    def dec(b):
+        return np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        t0 = time.perf_counter(); blobs = list(pool.map(enc, images)); t1 = time.perf_counter()
+        back = list(pool.map(dec, blobs)); t2 = time.perf_counter()
+    assert np.array_equal(back[0], images[0])
+    return {"encode_images_per_s": round(len(images) / (t1 - t0), 1), "decode_images_per_s": round(len(images) / (t2 - t1), 1),
+            "threads": threads, "sample": f"{len(images)} images 256x256x3, Pillow compress_level=1"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +351,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
