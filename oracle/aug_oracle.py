@@ -2,7 +2,8 @@
 
 Follows augment_image_and_mask (functions.py:2779-2826), add_noise_and_blur (:1481-1506) and add_noise (:1463-1478) for
 one image with the random draws made explicit (the reference draws them from Python's / numpy's unseeded global
-streams).  PARITY UNPINNED for the OpenCV pieces: cv2 is not installed here, so GaussianBlur((k,k),0) is restated from
+streams).  The noise arithmetic (add, clip, dtype) is PINNED to outputs of the reference's add_noise
+(tests/golden/augment.npz).  PARITY UNPINNED for the OpenCV pieces: cv2 is not installed here, so GaussianBlur((k,k),0) is restated from
 OpenCV's documented behaviour for 8-bit images (fixed small kernels for sigma = 0, BORDER_REFLECT_101, exact
 fixed-point accumulation rounded half up) and convertScaleAbs as saturate(round-half-even(|a*x+b|)).  The flips and
 rotations are checked against numpy's flip / rot90 in tests/test_oracle_golden.py.  The noise generator is this
@@ -65,6 +66,12 @@ def noise_field(shape, noise_max, seed):
     return ((h * np.uint64(2 * noise_max)) >> np.uint64(32)).astype(np.int64).reshape(shape) - noise_max
 
 
+def apply_noise(image, noise):
+    """image + noise, clipped to 0..255 (functions.py:1476-1478) -- pinned by tests/golden/augment.npz, which holds
+    outputs of the reference's own add_noise together with the noise field it drew."""
+    return np.clip(image.astype(np.int64) + noise, 0, 255).astype(np.uint8)
+
+
 def augment(image, mask, flip_v, flip_h, rot, bright_on, alpha, beta, blur_k, noise_max, seed):
     """image [H,W,C] u8, mask [H,W,Cm] u8 or None -> (aug_image, aug_mask)."""
     img = geometric(image, flip_v, flip_h, rot)
@@ -73,5 +80,5 @@ def augment(image, mask, flip_v, flip_h, rot, bright_on, alpha, beta, blur_k, no
         img = convert_scale_abs(img, alpha, beta)
     img = gaussian_blur(img, blur_k)
     if noise_max > 0:
-        img = np.clip(img.astype(np.int64) + noise_field(img.shape, noise_max, seed), 0, 255).astype(np.uint8)
+        img = apply_noise(img, noise_field(img.shape, noise_max, seed))
     return img, msk

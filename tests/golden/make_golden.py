@@ -19,6 +19,9 @@ What is pinned (SURVEY.md §8 a'):
   writer_isic.npz    create_pseudo_labels_im_ISIC_2018, EK=DK=0           (a8)
   writer_multi.npz   create_pseudo_labels_im_multiclass, EK=DK=0          (a9)
   metrics.npz        get_IoU_binary / dice_score_numpy_binary             (eval helpers)
+  augment.npz        add_noise (functions.py:1463-1478): the only numpy-only piece of the augmentation chain.  The
+                     noise field the reference drew is recorded next to its output (numpy's global stream re-seeded),
+                     so the add / clip / dtype arithmetic is pinned; the draw itself is not reproducible by design.
 """
 import hashlib
 import os
@@ -371,6 +374,26 @@ def gen_metrics(F):
     print("metrics:", len(cases), "cases")
 
 
+def gen_augment(F):
+    rng = np.random.default_rng(9)
+    out = {}
+    cases = []
+    for i, (shape, m) in enumerate([((16, 24, 3), 25), ((32, 32, 3), 5), ((8, 8, 1), 15), ((12, 20, 3), 1)]):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[0, :4] = 0
+        img[1, :4] = 255                       # both clip edges
+        np.random.seed(100 + i)
+        got = F.add_noise(img.copy(), m)
+        np.random.seed(100 + i)
+        noise = np.random.randint(m * -1, m, size=img.shape)     # the same draw the call above made
+        k = f"n{i}"
+        out[k + "_img"], out[k + "_noise"], out[k + "_out"], out[k + "_m"] = img, noise.astype(np.int16), got, np.array([m])
+        cases.append(k)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
+    print("augment:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     F, cv2 = import_reference()
     with np.errstate(all="ignore"):
@@ -379,3 +402,4 @@ if __name__ == "__main__":
         gen_multiclass(F)
         gen_writers(F, cv2)
         gen_metrics(F)
+        gen_augment(F)

@@ -218,3 +218,15 @@ def test_aug_oracle_geometry_and_blur_properties():
     n = A.noise_field((64, 64, 3), 5, 1234)
     assert n.min() == -5 and n.max() == 4
     assert not np.array_equal(n, A.noise_field((64, 64, 3), 5, 1235))
+
+
+def test_aug_oracle_noise_arithmetic_matches_reference_add_noise(golden_dir):
+    """add_noise is the one numpy-only piece of the reference's augmentation chain: its outputs (with the noise field it
+    drew) pin the oracle's add / clip / dtype arithmetic, which the GPU kernel is then compared with bit for bit"""
+    from oracle import aug_oracle as A
+    g = np.load(os.path.join(golden_dir, "augment.npz"))
+    for k in g["cases"]:
+        img, noise, want, m = g[k + "_img"], g[k + "_noise"], g[k + "_out"], int(g[k + "_m"][0])
+        assert noise.min() >= -m and noise.max() <= m - 1            # the reference's range: [-m, m)
+        got = A.apply_noise(img, noise.astype(np.int64))
+        assert got.dtype == np.uint8 and np.array_equal(got, want)
