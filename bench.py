@@ -349,7 +349,7 @@ def main():
             "roofline": roofline,
             "im_kernel": im_kernel,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is a 1-GPU-run item (rank 0 only)
             out["cpu_baseline"] = cpu_baseline()
             out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
         print(json.dumps(out))
