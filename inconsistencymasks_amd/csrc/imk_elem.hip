@@ -304,14 +304,17 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float *__restric
 }
 
 // ---- output head: BN on load -> 1x1 conv in fp32 -> sigmoid / softmax --------------------------------
-// one thread per pixel; weights broadcast from LDS.  K <= 64.
+// One thread per pixel computes its K outputs into an LDS row (odd pitch: conflict-free), weights broadcast from LDS;
+// the block's 256 x K probabilities are contiguous in the [pixel][K] output, so they leave as one coalesced stream
+// (a thread writing its own K floats, 4*K bytes apart from its neighbour's, ran at 1/50 of that for K = 35).  K <= 64.
 template <int CS>
 __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, const float *__restrict__ sc,
                                                    const float *__restrict__ sh, const float *__restrict__ w /*[cin][K]*/,
                                                    const float *__restrict__ bias, int cin, int K, int softmax,
                                                    long long n_pix, float *__restrict__ probs) {
-    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
-    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
+    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS], then out[256][K | 1]
+    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS, *s_out = s_sh + CS;
+    const int pitch = K | 1;
     for (int i = threadIdx.x; i < K * CS; i += 256) {
         const int k = i / CS, c = i - k * CS;
         s_w[i] = (c < cin) ? w[(size_t)c * K + k] : 0.f;
@@ -319,36 +322,45 @@ __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, co
     for (int i = threadIdx.x; i < K; i += 256) s_b[i] = bias[i];
     for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
     __syncthreads();
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_pix) return;
-    float xin[CS];
+    const long long p0 = (long long)blockIdx.x * 256;
+    const long long p = p0 + threadIdx.x;
+    float *row = s_out + threadIdx.x * pitch;
+    if (p < n_pix) {
+        float xin[CS];
 #pragma unroll
-    for (int q = 0; q < CS / 8; ++q) {
-        const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
+        for (int q = 0; q < CS / 8; ++q) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+            for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+        }
+        if (!softmax) {
+            for (int k = 0; k < K; ++k) {
+                float acc = s_b[k];
+#pragma unroll
+                for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
+                row[k] = 1.0f / (1.0f + expf(-acc));
+            }
+        } else {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                float acc = s_b[k];
+#pragma unroll
+                for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
+                row[k] = acc;
+                mx = fmaxf(mx, acc);
+            }
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) { const float e = expf(row[k] - mx); row[k] = e; sum += e; }
+            const float inv = 1.0f / sum;
+            for (int k = 0; k < K; ++k) row[k] *= inv;
+        }
     }
-    float *out = probs + p * K;
-    if (!softmax) {
-        for (int k = 0; k < K; ++k) {
-            float acc = s_b[k];
-#pragma unroll
-            for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
-            out[k] = 1.0f / (1.0f + expf(-acc));
-        }
-    } else {
-        float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) {
-            float acc = s_b[k];
-#pragma unroll
-            for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
-            out[k] = acc;
-            mx = fmaxf(mx, acc);
-        }
-        float sum = 0.f;
-        for (int k = 0; k < K; ++k) { const float e = expf(out[k] - mx); out[k] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int k = 0; k < K; ++k) out[k] *= inv;
+    __syncthreads();
+    const long long n_here = (n_pix - p0 < 256 ? n_pix - p0 : 256) * K;   // floats this block owns, contiguous
+    float *dst = probs + p0 * K;
+    for (long long i = threadIdx.x; i < n_here; i += 256) {
+        const int px = (int)(i / K), k = (int)(i - (long long)px * K);
+        dst[i] = s_out[px * pitch + k];
     }
 }
 
@@ -552,14 +564,22 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
                     int K, int softmax, long long n_pix, float *probs, hipStream_t stream) {
     if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = (int)((n_pix + 255) / 256);
-    const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
+    const size_t lds = ((size_t)K * cs + K + 2 * cs + 256 * (size_t)(K | 1)) * sizeof(float);
+#define IMK_HEAD(CS)                                                                                                     \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel<CS>),                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        head_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs);                    \
+    } while (0)
     switch (cs) {
-        case 8: head_kernel<8><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
-        case 16: head_kernel<16><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
-        case 24: head_kernel<24><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
-        case 32: head_kernel<32><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, probs); break;
+        case 8: IMK_HEAD(8); break;
+        case 16: IMK_HEAD(16); break;
+        case 24: IMK_HEAD(24); break;
+        case 32: IMK_HEAD(32); break;
         default: return IMK_EUNSUPPORTED;
     }
+#undef IMK_HEAD
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

@@ -1,13 +1,21 @@
-"""GPU: wall time of a training step / an inference call (no profiling hooks), median of several runs."""
+"""GPU: wall time of a training step / an inference call (no profiling hooks), median of several runs.
+CONFIG=isic|hela|suim|city picks one of BASELINE.json's shapes (default isic)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from inconsistencymasks_amd.unet import UNet
+CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "hela": (256, 256, 1, 3, 1.0, "sigmoid", 0),
+       "suim": (256, 256, 3, 9, 1.0, "softmax", 1), "city": (208, 416, 3, 35, 1.0, "softmax", 1)}
+name = os.environ.get("CONFIG", "isic")
+H, W, C, K, ALPHA, ACT, LOSS = CFG[name]
 B = int(os.environ.get("INFER_B", 128))
-x = torch.randint(0, 256, (B, 256, 256, 3), dtype=torch.uint8, device="cuda")
-y = (torch.rand((32, 256, 256, 1), device="cuda") > 0.7).to(torch.uint8)
-m = UNet(256, 256, 3, 1, 0.5, "sigmoid", seed=3)
+x = torch.randint(0, 256, (B, H, W, C), dtype=torch.uint8, device="cuda")
+if LOSS == 0:
+    y = (torch.rand((32, H, W, K), device="cuda") > 0.7).to(torch.uint8)
+else:
+    y = torch.randint(0, K, (32, H, W), dtype=torch.uint8, device="cuda")
+m = UNet(H, W, C, K, ALPHA, ACT, seed=3)
 xs = x[:32].contiguous()
 def timeit(fn, n, reps=5):
     for _ in range(3): fn()
@@ -17,6 +25,6 @@ def timeit(fn, n, reps=5):
         for _ in range(n): fn()
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / n * 1e3)
     return sorted(ts)[len(ts) // 2]
-print("env", {k: v for k, v in os.environ.items() if k.startswith("IMK_")})
-print("train step B=32: %.3f ms" % timeit(lambda: m.train_step(xs, y, 0, 3e-3, 1e-4), 40))
+print("config", name, "env", {k: v for k, v in os.environ.items() if k.startswith("IMK_")})
+print("train step B=32: %.3f ms" % timeit(lambda: m.train_step(xs, y, LOSS, 3e-3, 1e-4), 40))
 print("inference B=%d: %.3f ms (%.2f us/img)" % (B, timeit(lambda: m.predict_device(x), 20), 0))
