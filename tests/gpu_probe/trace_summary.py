@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
 rows.sort()
 stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4")]          # uint8 stem: start of a forward
-folds = [i for i, r in enumerate(rows) if r[2].startswith("bn_fold_batched_kernel")]     # end of an optimizer step
+folds = [i for i, r in enumerate(rows) if r[2].startswith("pack_conv_batched_kernel")]   # end of an optimizer step
 heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2]]                          # end of an inference call
 def show(seg, title):
     t0 = seg[0][0]
