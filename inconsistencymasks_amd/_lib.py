@@ -4,7 +4,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libimk.so")
+LIB_PATH = os.environ.get("IMK_LIB_PATH", os.path.join(PKG, "libimk.so"))   # override: A/B builds of the library
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 

@@ -42,11 +42,19 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles
     return c;
 }
 
-// chunks (of 8 channels) per K pass: everything in one pass up to 256 channels, else equal passes of <= 32 chunks
+// Chunks (of 8 channels) per K pass.  The per-tile kernel walks the input channels in passes of at most IMK_PASS_CAP
+// chunks, each pass staging its channel slice of the tile and of the packed weights into LDS (k order = pass, tap,
+// chunk in pass).  Short passes keep the LDS footprint near 60 KB whatever the layer width, so 2-3 workgroups share a
+// CU and one's staging overlaps another's MFMAs: measured per inference call of 128 images (alpha = 1 nets) with caps
+// 32 / 8 / 4 / 2: SUIM 1.97 / 1.74 / 1.64 / 1.82 ms, Cityscapes 3.68 / - / 2.93 / 3.17 ms; ISIC (alpha 0.5) 0.71 / 0.71 /
+// 0.70 / 0.73 ms.
 __host__ __device__ inline int imk_cdiv_d(int a, int b) { return (a + b - 1) / b; }
+#ifndef IMK_PASS_CAP
+#define IMK_PASS_CAP 4
+#endif
 __host__ __device__ inline int imk_pass_chunks(int nc8) {
-    if (nc8 <= 32) return nc8;
-    const int n_pass = imk_cdiv_d(nc8, 32);
+    if (nc8 <= IMK_PASS_CAP) return nc8;
+    const int n_pass = imk_cdiv_d(nc8, IMK_PASS_CAP);
     return imk_cdiv_d(nc8, n_pass);
 }
 
@@ -220,9 +228,9 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 // =====================================================================================================
 // forward / dgrad
 // =====================================================================================================
-// Channel passes: layers with more than 256 input channels (alpha > 1 bottleneck, IM+ at alpha = 2) do not fit one LDS
-// tile; their K dimension is walked in n_pass passes of nc8p chunks (<= 32 chunks = 256 channels), each pass staging its
-// channel slice of the tile and of the packed weights.  k order = (pass, tap, chunk in pass) -- see pack_conv_kernel.
+// Channel passes: the K dimension is walked in n_pass passes of nc8p chunks (imk_pass_chunks above), each pass staging
+// its channel slice of the tile and of the packed weights; any width up to 512 channels runs this way.
+// k order = (pass, tap, chunk in pass) -- see pack_conv_batched_kernel.
 struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds; };
 
 // bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
