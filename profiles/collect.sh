@@ -11,9 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the default bench command, plain (the headline line) and under the kernel trace (+stats)
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
-# 2. HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in separate passes, on a short variant of the same workload
+# 2. HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in separate passes of the same command (summarize.py keeps
+#    the launches of the generations only, i.e. the launch mix of the timed region)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --no-cpu-baseline --no-prof --steps 1 --warmup 0 --pretrain-steps 20 --bn-settle-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --no-cpu-baseline --no-prof > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 # 3. timeline of one training step and one ensemble-sized inference call (kernel by kernel), and the SQ counters that say
 #    what the waves wait for; both on tests/gpu_probe/step_trace.py (6 training steps + 3 inference calls)

@@ -41,7 +41,15 @@ def main(out):
         files = glob.glob(os.path.join(out, f"pmc_{cname}", "*", "*_counter_collection.csv"))
         if not files:
             continue
-        for r in csv.DictReader(open(files[0])):
+        rows = list(csv.DictReader(open(files[0])))
+        # only the generations (warm-up, timed, exclusive pass): everything from the first fused-IM launch on -- the
+        # 1800 pre-training steps of the synthetic ensemble before it would swamp the launch mix of the timed region
+        first = min((int(r["Dispatch_Id"]) for r in rows if "im_binary" in r["Kernel_Name"]), default=0)
+        first_gen = max((int(r["Dispatch_Id"]) for r in rows if int(r["Dispatch_Id"]) < first and "conv_pipe_kernel<4" in r["Kernel_Name"]),
+                        default=0)   # the stem of that first ensemble forward
+        for r in rows:
+            if int(r["Dispatch_Id"]) < first_gen:
+                continue
             k = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
             d = tr.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n_FETCH_SIZE": 0, "n_WRITE_SIZE": 0})
             d[cname] += float(r["Counter_Value"])
