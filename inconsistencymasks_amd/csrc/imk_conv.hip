@@ -269,7 +269,6 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[m][p] = f32x4{0, 0, 0, 0};
     const f16 *wp = a.wpk + (size_t)lane * 8;
-
     for (int pass = 0; pass < n_pass; ++pass) {
         const int c8_lo = pass * nc8p;
         const int nc8_cur = min(nc8p, nc8 - c8_lo);
@@ -279,14 +278,17 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
             // The copy is asynchronous (global_load_lds_dwordx4: global -> LDS without registers, one contiguous KB per
             // wave and instruction), so all of it is in flight while the input tile is staged below.
-            const int n16 = MT * nsp * 64;   // 16-byte chunks; a multiple of 64, so the bound is wave-uniform
-            for (int i = t; i < n16; i += NT) {
-                const int m = i / (nsp * 64);
+            // (no division in the copy loop: one (channel tile, chunk) walk per m)
+            const int n16m = nsp * 64;       // 16-byte chunks per channel tile; a multiple of 64: wave-uniform bounds
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
                 int ct = by * MT + m;
                 if (ct >= mt_total) ct = mt_total - 1;   // padding rows of the last group: outputs are never stored
-                const f16 *src = a.wpk + (((size_t)ct * ns_total + (size_t)pass * nsp) * 64 + (i - m * nsp * 64)) * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(s_w + (size_t)(i - lane) * 8), 16, 0, 0);
+                const f16 *src = a.wpk + ((size_t)ct * ns_total + (size_t)pass * nsp) * 512;
+                f16 *dstm = s_w + (size_t)m * n16m * 8;
+                for (int j = t; j < n16m; j += NT)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)j * 8),
+                                                     (__attribute__((address_space(3))) void *)(dstm + (size_t)(j - lane) * 8), 16, 0, 0);
             }
         }
         // ---- stage this pass's channel slice of the input tile ------------------------------------------
@@ -371,6 +373,10 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    // A lane owns 4 channels of one pixel per (m, p): stored directly, that is 8 bytes every cs_out * 2 bytes -- a third of
+    // every 64-byte line.  So the tile goes through LDS ([pixel][MT * 16 channels], the region the input tile occupied)
+    // and leaves as 16-byte chunks, MT * 32 contiguous bytes per pixel.  The ReLU masks and BN outputs that the gradient
+    // epilogues read are all requested up front (one latency, not one per (m, p)).
     const int x = tc.tx0 + n;
     float s1[MT][4], s2[MT][4];
 #pragma unroll
@@ -379,40 +385,75 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
         for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
     const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
     const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
+    // biases of this lane's channels: one batch of loads, in flight across the barrier below
+    float bias[MT][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int co0 = (ct0 + m) * 16 + 4 * g;
-        if (co0 >= a.cs_out) continue;
-        float bias[4] = {0, 0, 0, 0};
-        if (a.epi == EP_RELU && a.bias)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias[r] = (co0 + r < a.cout) ? a.bias[co0 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int co = (ct0 + m) * 16 + 4 * g + r;
+            bias[m][r] = (a.epi == EP_RELU && a.bias && co < a.cout) ? a.bias[co] : 0.f;
+        }
+    constexpr int OPITCH = MT * 16 + 8;                       // halfs per pixel row of the output tile in LDS
+    f16 *s_out = reinterpret_cast<f16 *>(smem);
+    __syncthreads();                                           // every wave is done reading the input tile
+    // one straight-line copy of the (m, p) loops per epilogue kind (the kind is uniform: decided once, outside)
+    auto write_tile = [&](auto EPI_T, auto STAT_T) {
+        constexpr int EPI = decltype(EPI_T)::value;
+        constexpr int STAT = decltype(STAT_T)::value;          // 0 none, 1 sum / sum of squares, 2 sum dy / sum dy*z
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int y = tc.ty0 + wave * P + p;
-            if (y >= H || x >= W) continue;
-            const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0;
-            f16x4 v;
-            if (a.epi == EP_RELU) {
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = (ct0 + m) * 16 + 4 * g;
+            // the ReLU mask / BN output this channel tile's gradient epilogue reads: the P loads go out together
+            f16x4 mk[P], zz[P];
+            if (EPI == EP_MASK || STAT == 2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[m][p][r] + bias[r], 0.f);
-            } else if (a.epi == EP_MASK) {
-                const f16x4 mk = *reinterpret_cast<const f16x4 *>(a.mask + o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)mk[r] > 0.f) ? (f16)acc[m][p][r] : (f16)0.f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (f16)acc[m][p][r];
+                for (int p = 0; p < P; ++p) {
+                    const int y = tc.ty0 + wave * P + p;
+                    const bool live = co0 < a.cs_out && y < H && x < W;
+                    const size_t o = live ? ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0 : 0;   // dead lanes: any valid address
+                    if (EPI == EP_MASK) mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + o);
+                    if (STAT == 2) zz[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + o);
+                }
             }
-            *reinterpret_cast<f16x4 *>(a.out + o) = v;
-            if (dystat) {
-                const f16x4 zz = *reinterpret_cast<const f16x4 *>(a.dystat_z + o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * (float)zz[r]; }
-            } else if (want_stats) {
+            for (int p = 0; p < P; ++p) {
+                f16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * f; }
+                for (int r = 0; r < 4; ++r) {
+                    if (EPI == EP_RELU) v[r] = (f16)fmaxf(acc[m][p][r] + bias[m][r], 0.f);
+                    else if (EPI == EP_MASK) v[r] = ((float)mk[p][r] > 0.f) ? (f16)acc[m][p][r] : (f16)0.f;
+                    else v[r] = (f16)acc[m][p][r];
+                }
+                *reinterpret_cast<f16x4 *>(s_out + ((wave * P + p) * 16 + n) * OPITCH + m * 16 + 4 * g) = v;
+                if (STAT) {
+                    const int y = tc.ty0 + wave * P + p;
+                    const float live = (co0 < a.cs_out && y < H && x < W) ? 1.f : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float f = live * (float)v[r];
+                        s1[m][r] += f;
+                        s2[m][r] += f * (STAT == 2 ? (float)zz[p][r] : f);
+                    }
+                }
             }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    if (a.epi == EP_RELU) { if (want_stats) write_tile(I0{}, I1{}); else write_tile(I0{}, I0{}); }
+    else if (a.epi == EP_MASK) { if (dystat) write_tile(I2{}, I2{}); else write_tile(I2{}, I0{}); }
+    else { if (dystat) write_tile(I1{}, I2{}); else write_tile(I1{}, I0{}); }
+    __syncthreads();
+    {   // copy-out: 16-byte chunks, (MT * 2) per pixel; channel tiles beyond cs_out are skipped
+        const int cpp = MT * 2;                                // chunks per pixel
+        const int n_live = min(cpp, (a.cs_out - ct0 * 16) / 8);   // cs_out is a multiple of 8
+        for (int i = t; i < TH * 16 * cpp; i += NT) {
+            const int pixl = i / cpp, ch = i - pixl * cpp;
+            const int py = pixl >> 4, px = pixl & 15;
+            const int y = tc.ty0 + py, xx = tc.tx0 + px;
+            if (ch < n_live && y < H && xx < W)
+                *reinterpret_cast<f16x8 *>(a.out + ((size_t)(tc.b * H + y) * W + xx) * a.cs_out + ct0 * 16 + ch * 8) =
+                    *reinterpret_cast<const f16x8 *>(s_out + pixl * OPITCH + ch * 8);
         }
     }
     if (want_stats) {  // workgroup-uniform branch
@@ -1148,6 +1189,8 @@ static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
         break;
     }
     if (nsp * n_pass <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
+    const size_t out_bytes = (size_t)TH * 16 * (mt * 16 + 8) * sizeof(f16);   // the epilogue's output tile reuses the LDS
+    if (lds < out_bytes) lds = out_bytes;
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
     L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds};
     L.th = TH; L.mt = mt; L.gx = n_sp; L.gy = imk_cdiv(mt_total, mt); L.lds = lds;
