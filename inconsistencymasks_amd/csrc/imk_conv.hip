@@ -307,6 +307,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             }
         } else {
             constexpr int BATCH = 4;
+            // divisions by the small run-time divisors nc8_cur (1..IMK_PASS_CAP) and WT (16 / 18) as multiply-shift:
+            // floor(n * ceil(2^16 / d) / 2^16) == n / d for n * d < 2^16 (here n < 1500, d <= 18)
+            const int mg_c = (65536 + nc8_cur - 1) / nc8_cur, mg_w = (65536 + WT - 1) / WT;
             const int n_batches = (n_items + BATCH * NT - 1) / (BATCH * NT);   // uniform trip count (barrier inside)
             for (int bt = 0; bt < n_batches; ++bt) {
                 const int i0 = t + bt * BATCH * NT;
@@ -317,9 +320,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
                 for (int u = 0; u < BATCH; ++u) {
                     const int i = i0 + u * NT;
                     const int ii = i < n_items ? i : t;          // idle slots repeat this thread's first item
-                    const int pix = ii / nc8_cur;
+                    const int pix = (ii * mg_c) >> 16;            // ii / nc8_cur, exact for these ranges (see mg_c)
                     const int c8 = ii - pix * nc8_cur;
-                    const int py = pix / WT, px = pix - py * WT;
+                    const int py = (pix * mg_w) >> 16, px = pix - py * WT;   // pix / WT
                     const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
                     dst[u] = i < n_items ? (pix * ps + c8) * 16 : -1;
                     c8s[u] = c8_lo + c8;
