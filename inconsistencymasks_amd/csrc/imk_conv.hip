@@ -759,7 +759,12 @@ constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 
 struct ImkWgradGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco; };
 
 // bx = split (walks tiles bx, bx + nbx, ...), by = (input-channel tile, output-channel tile) pair of nby
-template <int LM>
+// The prefetch loads are unconditional (clamped coordinates, idle slots repeat slot 0) and BNB (BatchNorm backward on the
+// gradient operand: a second tensor to load) is a template parameter: with a load inside a lane- or launch-dependent
+// branch the compiler protects the reuse of its destination registers with `s_waitcnt vmcnt(0)` in front of EVERY load of
+// the next tile, i.e. the seven loads of a prefetch went out one memory latency after the other (cycle stamps: 3.6-4.3 k
+// of a workgroup's 8 k cycles per tile).
+template <int LM, bool BNB>
 __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const ImkWgradGeom &gm, int bx, int by, int nbx, int nby) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, n_tiles = gm.n_tiles, cit_n = gm.cit_n, cot_n = gm.cot_n;
     const int nc8_in = gm.nci, nc8_out = gm.nco;
@@ -780,7 +785,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 
     stage_affine_table(a.x, s_aff);
     float *s_coef = s_aff + 4 * a.x.cs_in;          // [A | B | C] of the dA-side BatchNorm backward (optional)
-    const bool bnbwd = a.dA_z != nullptr;
+    constexpr bool bnbwd = BNB;
     if (bnbwd)
         for (int i = t; i < 3 * a.cs_out; i += 256) s_coef[i] = a.dA_coef[i];
 
@@ -802,7 +807,8 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int i = t + 256 * k;
-        const int pix = cx == 2 ? i >> 1 : i, ch = cx == 2 ? (i & 1) : 0;
+        const int ii = i < n_x ? i : t;      // idle slots repeat slot 0 (t < n_x always): their load is a cache hit
+        const int pix = cx == 2 ? ii >> 1 : ii, ch = cx == 2 ? (ii & 1) : 0;
         x_c8[k] = 2 * cit + ch;
         x_py[k] = pix / WT;
         x_px[k] = pix - x_py[k] * WT;
@@ -812,7 +818,8 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
         const int i = t + 256 * k;
-        const int pix = cd == 2 ? i >> 1 : i, ch = cd == 2 ? (i & 1) : 0;
+        const int ii = i < n_d ? i : t;
+        const int pix = cd == 2 ? ii >> 1 : ii, ch = cd == 2 ? (ii & 1) : 0;
         d_c8[k] = 2 * cot + ch;
         d_py[k] = pix >> 4;
         d_px[k] = pix & 15;
@@ -831,25 +838,23 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int y = tc.ty0 + x_py[k] - halo, x = tc.tx0 + x_px[k] - halo;
-            if (x_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
-                raw_load<LM>(a.x, tc.b, y, x, H, W, x_c8[k], xr[k]);
-                vx |= 1u << k;
-            }
+            const bool ok = x_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+            raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, x_c8[k], xr[k]);
+            vx |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             const int y = tc.ty0 + d_py[k], x = tc.tx0 + d_px[k];
-            if (d_lds[k] >= 0 && y < H && x < W) {
-                const size_t o = ((size_t)(tc.b * H + y) * W + x) * a.cs_out + d_c8[k] * 8;
-                dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + o);
-                if (bnbwd) dz[k] = *reinterpret_cast<const f16x8 *>(a.dA_z + o);
-                vd |= 1u << k;
-            }
+            const bool ok = d_lds[k] >= 0 && y < H && x < W;
+            const size_t o = ((size_t)(tc.b * H + min(y, H - 1)) * W + min(x, W - 1)) * a.cs_out + d_c8[k] * 8;
+            dr[k] = *reinterpret_cast<const f16x8 *>(a.dA + o);
+            if (bnbwd) dz[k] = *reinterpret_cast<const f16x8 *>(a.dA_z + o);
+            vd |= (ok ? 1u : 0u) << k;
         }
     };
 
     int tile = bx;
-    if (tile < n_tiles) issue(tile);
+    issue(tile < n_tiles ? tile : n_tiles - 1);
     __syncthreads();   // affine table visible
     while (tile < n_tiles) {
 #pragma unroll
@@ -879,7 +884,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
         }
         __syncthreads();
         const int next = tile + nbx;
-        if (next < n_tiles) issue(next);     // in flight during the MFMAs below
+        issue(next < n_tiles ? next : tile);     // in flight during the MFMAs below (the last one re-reads this tile)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 2 * (wave + 4 * kk);          // tile rows r0, r0+1 form this k-step's 32 pixels
@@ -926,9 +931,9 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
     }
 }
 
-template <int LM>
+template <int LM, bool BNB>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgradGeom gm) {
-    wgrad_mfma_body<LM>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    wgrad_mfma_body<LM, BNB>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 constexpr int WG_RED_CHUNK = 16;   // splits summed per stage-1 chunk of the weight-gradient reduction
@@ -1411,11 +1416,14 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     if (rc) return rc;
     const dim3 grid(L.gx, L.gy);
     switch (a.x.lmode) {
-        case LM_RAW: wgrad_mfma_kernel<LM_RAW><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
-        case LM_AFFINE: wgrad_mfma_kernel<LM_AFFINE><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
-        case LM_POOL: wgrad_mfma_kernel<LM_POOL><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
-        case LM_UPADD: wgrad_mfma_kernel<LM_UPADD><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
-        default: wgrad_mfma_kernel<LM_U8><<<grid, 256, L.lds, stream>>>(a, L.gm); break;
+#define IMK_WG(LM) do { if (a.dA_z) wgrad_mfma_kernel<LM, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
+                        else wgrad_mfma_kernel<LM, false><<<grid, 256, L.lds, stream>>>(a, L.gm); } while (0)
+        case LM_RAW: IMK_WG(LM_RAW); break;
+        case LM_AFFINE: IMK_WG(LM_AFFINE); break;
+        case LM_POOL: IMK_WG(LM_POOL); break;
+        case LM_UPADD: IMK_WG(LM_UPADD); break;
+        default: IMK_WG(LM_U8); break;
+#undef IMK_WG
     }
     IMK_LAUNCH_CHECK();
     return IMK_OK;
