@@ -28,9 +28,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         return;
     }
     double s1 = 0.0, s2 = 0.0;
-    for (int i = t; i < n_part; i += 256) {
-        s1 += (double)partial[(size_t)i * 2 * cs + ch];
-        s2 += (double)partial[(size_t)i * 2 * cs + cs + ch];
+    for (int i0 = t; i0 < n_part; i0 += 8 * 256) {     // 16 independent loads in flight per thread; same summation order
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, n_part - 1);           // unconditional loads (no branch between them) ...
+            v1[u] = partial[(size_t)i * 2 * cs + ch];
+            v2[u] = partial[(size_t)i * 2 * cs + cs + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double live = (i0 + u * 256 < n_part) ? 1.0 : 0.0;   // ... rows beyond the end count as zero
+            s1 += live * (double)v1[u];
+            s2 += live * (double)v2[u];
+        }
     }
     __shared__ double r1[256], r2[256];
     r1[t] = s1; r2[t] = s2;
@@ -276,9 +287,20 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float *__restric
         return;
     }
     double s1 = 0.0, s2 = 0.0;
-    for (int i = t; i < n_part; i += 256) {
-        s1 += (double)partial[(size_t)i * 2 * cs + ch];
-        s2 += (double)partial[(size_t)i * 2 * cs + cs + ch];
+    for (int i0 = t; i0 < n_part; i0 += 8 * 256) {     // 16 independent loads in flight per thread; same summation order
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, n_part - 1);           // unconditional loads (no branch between them) ...
+            v1[u] = partial[(size_t)i * 2 * cs + ch];
+            v2[u] = partial[(size_t)i * 2 * cs + cs + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double live = (i0 + u * 256 < n_part) ? 1.0 : 0.0;   // ... rows beyond the end count as zero
+            s1 += live * (double)v1[u];
+            s2 += live * (double)v2[u];
+        }
     }
     __shared__ double r1[256], r2[256];
     r1[t] = s1; r2[t] = s2;
