@@ -959,10 +959,10 @@ __global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
     const float *p = jb.partial + (size_t)tile * 256 + t;
     float v[WG_RED_CHUNK];
 #pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = (s0 + i < s1) ? p[(size_t)(s0 + i) * stride] : 0.f;
+    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = p[(size_t)min(s0 + i, s1 - 1) * stride];   // unconditional: all 16 in flight
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += v[i];
+    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += (s0 + i < s1) ? v[i] : 0.f;
     jb.red[((size_t)chunk * jb.n_tiles + tile) * 256 + t] = acc;
 }
 
@@ -977,10 +977,10 @@ __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, c
     const float *p = jb.red + (size_t)tile * 256 + e;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int c = sg + 4 * i; v[i] = (c < jb.n_chunks) ? p[(size_t)c * stride] : 0.f; }
+    for (int i = 0; i < 16; ++i) v[i] = p[(size_t)min(sg + 4 * i, jb.n_chunks - 1) * stride];   // unconditional loads
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc += v[i];
+    for (int i = 0; i < 16; ++i) acc += (sg + 4 * i < jb.n_chunks) ? v[i] : 0.f;
     s_p[sg][e] = acc;
     __syncthreads();
     if (sg != 0) return;
