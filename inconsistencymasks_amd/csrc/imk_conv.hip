@@ -542,8 +542,6 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int per_img = tiles_x * tiles_y;
     auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
 
-    stage_affine_table(a.x, s_aff);
-
     // packed weights and per-lane LDS offsets of every k-step: once per workgroup
     f16x8 af[MAX_NS];
     int off[MAX_NS];
@@ -620,6 +618,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 
     int tile = blockIdx.x;
     issue(tile < n_tiles ? tile : n_tiles - 1);
+    stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in; nothing older is pending in the loop
     __syncthreads();                      // affine table visible
     while (tile < n_tiles) {
