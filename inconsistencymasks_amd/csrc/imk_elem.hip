@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                                                         const ImkCtl *__restrict__ ctl, float *__restrict__ stats,
                                                         int cs_out, f16 *__restrict__ dlogit,
                                                         float *__restrict__ loss_partial) {
-    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS]
-    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS;
+    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS], then (softmax) logits[256][K | 1]
+    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS, *s_rows = s_sh + CS;
     for (int i = threadIdx.x; i < K * CS; i += 256) {
         const int k = i / CS, c = i - k * CS;
         s_w[i] = (c < cin) ? w[(size_t)c * K + k] : 0.f;
@@ -447,10 +447,12 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                 *reinterpret_cast<f16x8 *>(d + k0) = g8;
             }
         } else {
+            // the K logits of this pixel are computed once and parked in an LDS row (odd pitch: conflict-free)
+            float *row = s_rows + threadIdx.x * (K | 1);
             float mx = -INFINITY;
-            for (int k = 0; k < K; ++k) mx = fmaxf(mx, logit(k));
+            for (int k = 0; k < K; ++k) { const float lg = logit(k); row[k] = lg; mx = fmaxf(mx, lg); }
             float sum = 0.f;
-            for (int k = 0; k < K; ++k) sum += expf(logit(k) - mx);
+            for (int k = 0; k < K; ++k) { const float e = expf(row[k] - mx); row[k] = e; sum += e; }
             const float inv = 1.0f / sum;
             const int t = y[p];
             const float inv_n = 1.0f / (float)n_pix;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                 for (int j = 0; j < 8; ++j) {
                     const int k = k0 + j;
                     if (k < K) {
-                        const float pk = expf(logit(k) - mx) * inv;
+                        const float pk = row[k] * inv;
                         if (k == t) l = -logf(fmaxf(pk, 1.17549435e-38f));
                         g8[j] = (f16)(S * (pk - (k == t ? 1.0f : 0.0f)) * inv_n);
                     }
@@ -615,9 +617,10 @@ int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const f
                          f16 *dlogit, float *loss_partial, hipStream_t stream) {
     if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = imk_loss_blocks(n_pix);
-    const size_t lds = ((size_t)K * cs + K + 2 * cs) * sizeof(float);
+    const size_t lds = ((size_t)K * cs + K + 2 * cs + (softmax ? 256 * (size_t)(K | 1) : 0)) * sizeof(float);
     const int cs_out = imk_pad8(K);
-#define IMK_HL(CS) head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, stats, cs_out, dlogit, loss_partial)
+#define IMK_HL(CS) if (lds > 64 * 1024) IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_loss_kernel<CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, stats, cs_out, dlogit, loss_partial)
     switch (cs) {
         case 8: IMK_HL(8); break;
         case 16: IMK_HL(16); break;
