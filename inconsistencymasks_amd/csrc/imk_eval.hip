@@ -67,24 +67,39 @@ __global__ __launch_bounds__(256) void eval_binary_kernel(const float *__restric
 __global__ __launch_bounds__(256) void eval_multi_kernel(const float *__restrict__ probs, const uint8_t *__restrict__ gt,
                                                          int hw, int K, uint8_t *__restrict__ pred_out,
                                                          unsigned long long *__restrict__ counts) {
+    // 256 pixels x K probabilities are one contiguous slab of the [pixel][K] tensor: it comes in as a coalesced
+    // stream (a thread reading its own K floats, 4*K bytes from its neighbour's, wastes most of every line) and each
+    // thread then scans its row in LDS (odd pitch: conflict-free).
+    extern __shared__ float s_p[];                 // [256][K | 1]
     __shared__ unsigned int hist[3 * 256 + 1];
     for (int i = threadIdx.x; i < 3 * 256 + 1; i += 256) hist[i] = 0;
-    __syncthreads();
+    const int pitch = K | 1;
     const int b = blockIdx.y;
     const size_t base = (size_t)b * hw;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
-        const float *q = probs + (base + p) * K;
-        float best = q[0];
-        int arg = 0;
-        for (int k = 1; k < K; ++k) {        // first maximum wins (np.argmax); NaN handling as imk_im_multiclass: inputs finite
-            const float v = q[k];
-            if (v > best) { best = v; arg = k; }
+    for (int p0 = blockIdx.x * 256; p0 < hw; p0 += gridDim.x * 256) {
+        __syncthreads();                           // histogram zeroed / previous slab consumed
+        const int n_here = min(256, hw - p0);
+        const float *src = probs + (base + p0) * K;
+        for (int i = threadIdx.x; i < n_here * K; i += 256) {
+            const int px = i / K;
+            s_p[px * pitch + (i - px * K)] = src[i];
         }
-        const int g = gt[base + p];
-        if (pred_out) pred_out[base + p] = (uint8_t)arg;
-        atomicAdd(&hist[g], 1u);
-        atomicAdd(&hist[256 + arg], 1u);
-        if (g == arg) { atomicAdd(&hist[512 + g], 1u); atomicAdd(&hist[768], 1u); }
+        __syncthreads();
+        const int p = p0 + threadIdx.x;
+        if (p < hw) {
+            const float *q = s_p + threadIdx.x * pitch;
+            float best = q[0];
+            int arg = 0;
+            for (int k = 1; k < K; ++k) {        // first maximum wins (np.argmax); inputs are finite
+                const float v = q[k];
+                if (v > best) { best = v; arg = k; }
+            }
+            const int g = gt[base + p];
+            if (pred_out) pred_out[base + p] = (uint8_t)arg;
+            atomicAdd(&hist[g], 1u);
+            atomicAdd(&hist[256 + arg], 1u);
+            if (g == arg) { atomicAdd(&hist[512 + g], 1u); atomicAdd(&hist[768], 1u); }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * 256 + 1; i += 256)
@@ -114,7 +129,10 @@ extern "C" int imk_eval_multiclass(const float *probs, const uint8_t *gt, int ba
     const int hw = h * w;
     int bx = (int)imk_cdiv(hw, 256 * 8);
     if (bx > 64) bx = 64;
-    eval_multi_kernel<<<dim3(bx, batch), 256, 0, stream>>>(probs, gt, hw, k, pred_out, (unsigned long long *)counts);
+    const size_t lds = (size_t)256 * (k | 1) * sizeof(float);   // <= 65 KB: one opt-in above the 64 KB default
+    if (lds > 64 * 1024)
+        IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    eval_multi_kernel<<<dim3(bx, batch), 256, lds, stream>>>(probs, gt, hw, k, pred_out, (unsigned long long *)counts);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
