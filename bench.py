@@ -88,6 +88,14 @@ def cpu_baseline():
     t0 = time.perf_counter()
     preds = [U.predict_batch1(m, x[:n_img], C, K, ALPHA, "sigmoid") for m in models]
     t_inf = (time.perf_counter() - t0) / n_img                    # per image, all N models
+    # the same forwards as ONE batch per model (so that the ratio is not inflated by the reference's
+    # batch-1 choice); reported beside the headline figure, which stays reference-structured
+    import torch as _t
+    t0 = time.perf_counter()
+    with _t.no_grad():
+        for m in models:
+            U.forward(m, x[:n_img], C, K, ALPHA, "sigmoid")
+    t_inf_batched = (time.perf_counter() - t0) / n_img
     t0 = time.perf_counter()
     for i in range(n_img):
         r = im_oracle.im_binary(np.stack([p[i] for p in preds], 0), 0.5, False)
@@ -109,7 +117,10 @@ def cpu_baseline():
     return {"value": round(U_UNLABELED / t_gen, 3), "unit": "images/s", "cores": n_threads, "kind": "port",
             "sample": f"{n_img} images x {N_MODELS} models batch-1 fp32 forward + numpy IM, {n_steps} train steps of "
                       f"batch {BATCH}; extrapolated to U={U_UNLABELED}, {steps} steps; {_usable_cpus()} CPUs usable",
-            "t_infer_per_image_s": round(t_inf, 5), "t_im_per_image_s": round(t_im, 6), "t_train_step_s": round(t_step, 4)}
+            "t_infer_per_image_s": round(t_inf, 5), "t_im_per_image_s": round(t_im, 6), "t_train_step_s": round(t_step, 4),
+            "batched_variant": {"t_infer_per_image_s": round(t_inf_batched, 5),
+                                "value": round(U_UNLABELED / (U_UNLABELED * (t_inf_batched + t_im) + steps * t_step), 3),
+                                "note": f"forwards as one batch of {n_img} per model instead of batch 1"}}
 
 
 def png_io_rate(images):
