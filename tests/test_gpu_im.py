@@ -129,3 +129,34 @@ def test_morph_and_block(im):
     im.block_apply(t, ti, tm)
     assert np.array_equal(_np(ti), img * (m == 0)[..., None])
     assert np.array_equal(_np(tm), masks * (m == 0)[:, None])
+
+
+@pytest.mark.parametrize("n,h,w,k", [(3, 256, 256, 9), (2, 208, 416, 35)])
+def test_multiclass_properties_full_size(im, n, h, w, k):
+    """Size-independent properties at the BASELINE multiclass shapes (SUIM N=3 K=9; Cityscapes N=2 K=35, 208x416):
+    IM == not all argmaxes equal, final = model-0 label where consistent else 0, im_size = count, blocking."""
+    b = 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    probs = torch.rand((n, b, h, w, k), device="cuda", generator=g)
+    probs[1:, :, : h // 2] = probs[0:1, :, : h // 2]                  # top half: every model agrees
+    img = torch.randint(1, 256, (b, h, w, 3), device="cuda", dtype=torch.uint8, generator=g)
+    r = im.im_multiclass(probs, img, True, True)
+    lab = probs.argmax(-1)
+    agree = (lab == lab[0:1]).all(0)
+    assert torch.equal(r["im"] > 0, ~agree)
+    assert not torch.any(r["im"][:, : h // 2] > 0)
+    assert torch.equal(r["final"].long(), torch.where(agree, lab[0], torch.zeros_like(lab[0])))
+    assert torch.equal(r["im_size"], (~agree).sum(dim=(1, 2)))
+    assert torch.equal(r["img_out"], img * agree[..., None])
+
+
+def test_sharding_invariance(im):
+    """a batch processed in shards (as the ranks of a multi-GPU run do) gives bit-identical outputs"""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    preds = torch.rand((2, 37, 64, 64, 1), device="cuda", generator=g)
+    img = torch.randint(0, 256, (37, 64, 64, 3), device="cuda", dtype=torch.uint8, generator=g)
+    whole = im.im_binary(preds, 0.5, False, img, True, True)
+    cuts = [0, 5, 19, 37]
+    parts = [im.im_binary(preds[:, a:b].contiguous(), 0.5, False, img[a:b].contiguous(), True, True) for a, b in zip(cuts, cuts[1:])]
+    for key in ("masks", "im", "im_size", "pred_size", "img_out"):
+        assert torch.equal(whole[key], torch.cat([p[key] for p in parts], 0))
