@@ -95,7 +95,17 @@ typedef struct imk_unet_cfg {
     int act_out;     /* 0 = sigmoid, 1 = softmax                             */
 } imk_unet_cfg;
 
-typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory */
+typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory (U-Net and EvalNet plans) */
+
+/* EvalNet (evalnet.py:24-73), see the section at the end of this file */
+typedef struct imk_evalnet_cfg {
+    int h, w;            /* input height / width; multiples of 64 (6 poolings)                         */
+    int ca, cb;          /* channels of input A (image) and input B (mask stack); 1..4 each            */
+    int n_out;           /* units per Dense head: 1 (get_evalnet) or inputB_channels (get_evalnet_miou) */
+    int two_heads;       /* 0: one sigmoid head (evalnet.py:45); 1: 'iou' + 'detection' (evalnet.py:70-71) */
+    int normalize_a, normalize_b;   /* the x/255 Lambda of each input block (evalnet.py:5-6)            */
+    int ch[5];           /* int(16a), int(32a), int(64a), int(128a), int(256a)  (evalnet.py:28-41)      */
+} imk_evalnet_cfg;
 
 int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out);
 void imk_unet_plan_destroy(imk_unet_plan *plan);
@@ -210,6 +220,38 @@ int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt
  * [3][0] = #(pred==gt).  k <= 256. */
 int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
                         int64_t *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * EvalNet (evalnet.py:24-73): the quality-scoring network of IM++ / AIM++
+ * ----------------------------------------------------------------------------------------------
+ * Replaces get_evalnet / get_evalnet_miou + model.predict([A, B]) (functions.py:5837-5941 call sites) and the
+ * model.fit step of train_evalnet_ISIC_2018 / train_evalnet_miou_model_hela (functions.py:4464-4506, 4673-4722).
+ * Two uint8 inputs A [B,H,W,ca] (image) and B [B,H,W,cb] (mask stack); each tower is input_block + conv_block, the
+ * towers are concatenated, five conv_blocks follow, then GlobalAvgPool2D and the Dense sigmoid head(s).
+ * The plan is an imk_unet_plan: imk_unet_param_count / _num_layers / _layer_info / _packed_bytes / _pack_weights /
+ * _state_bytes / _state_init / _adamw_step / _plan_destroy apply unchanged.  Layer names: "a.in.c", "a.in.bn", "a.c3",
+ * "a.c1", "a.bn", the same with "b.", "m1.c3", "m1.c1", "m1.bn" ... "m5.bn", then "dense" or "iou", "detection"
+ * (Dense kernels [C, n_out] + bias, reported as 1x1 convs); parameter order = Keras creation order. */
+int imk_evalnet_plan_create(const imk_evalnet_cfg *cfg, imk_unet_plan **out);
+int64_t imk_evalnet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode /* 0 inference, 1 training */);
+
+/* out [B, n_heads*n_out] f32 sigmoid outputs (two heads: iou units first, then detection units); inference-mode BN */
+int imk_evalnet_forward(const imk_unet_plan *plan, const float *params, const void *packed, const uint8_t *xa,
+                        const uint8_t *xb, int batch, float *out, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Training pass: forward with batch statistics (moving statistics updated in params), losses, backward.
+ *   y [B, n_heads*n_out] f32 targets.  Loss: head 0 mean squared error; head 1 binary cross-entropy (functions.py:4708
+ *   loss=['mse','binary_crossentropy'], summed);  a single head: mean squared error (functions.py:4492).
+ *   out (may be NULL): the training-mode outputs;  grads [n_trainable] f32 (unscaled);
+ *   stats [8] f32: {total loss, overflow flag, loss scale, step, loss of head 0, loss of head 1, -, -}.
+ * Follow with imk_unet_adamw_step. */
+int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state, const uint8_t *xa,
+                        const uint8_t *xb, const float *y, int batch, float *out, float *grads, float *stats,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Debug/parity: like imk_unet_tensor_info, for EvalNet plans */
+int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
+                            int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
 /* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
  * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on

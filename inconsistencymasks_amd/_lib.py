@@ -14,6 +14,11 @@ class UnetCfg(ctypes.Structure):
                 ("ch", c_int * 5), ("act_out", c_int)]
 
 
+class EvalnetCfg(ctypes.Structure):
+    _fields_ = [("h", c_int), ("w", c_int), ("ca", c_int), ("cb", c_int), ("n_out", c_int), ("two_heads", c_int),
+                ("normalize_a", c_int), ("normalize_b", c_int), ("ch", c_int * 5)]
+
+
 class AugParams(ctypes.Structure):
     _fields_ = [("flip_v", c_int), ("flip_h", c_int), ("rot", c_int), ("bright_on", c_int), ("alpha", c_float),
                 ("beta", c_float), ("blur_k", c_int), ("noise_max", c_int), ("seed", ctypes.c_uint32)]
@@ -56,6 +61,15 @@ SIGNATURES = {
     "imk_unet_state_init": (c_int, [c_void_p, c_void_p, c_void_p]),
     "imk_unet_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "imk_evalnet_plan_create": (c_int, [ctypes.POINTER(EvalnetCfg), ctypes.POINTER(c_void_p)]),
+    "imk_evalnet_workspace_bytes": (c_int64, [c_void_p, c_int, c_int]),
+    "imk_evalnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                    c_void_p]),
+    "imk_evalnet_tensor_info": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64),
+                                        ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                        ctypes.POINTER(c_int)]),
+    "imk_evalnet_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "imk_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "imk_eval_binary": (c_int, [c_void_p, c_float, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_eval_multiclass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -139,7 +139,7 @@ __device__ __forceinline__ f16x8 load_chunk(const ImkInput &in, int b, int y, in
             const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
             f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)(j < in.cin ? (float)p[j] / 255.0f : 0.0f);
+            for (int j = 0; j < 8; ++j) o[j] = (f16)(j < in.cin ? (float)p[j] / in.u8_div : 0.0f);
             return o;
         }
     }
@@ -186,7 +186,8 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
 }
 
 template <int LM>
-__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin) {
+__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin,
+                                               float u8_div) {
     if constexpr (LM == LM_RAW) {
         return r.v[0];
     } else if constexpr (LM == LM_AFFINE) {
@@ -220,7 +221,7 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
     } else {
         f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / 255.0f : 0.0f);
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / u8_div : 0.0f);
         return o;
     }
 }
@@ -333,7 +334,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
                     if (dst[u] >= 0) {
-                        f16x8 v = raw_transform<LM>(r[u], s_aff, a.x.cs_in, c8s[u], a.x.cin);
+                        f16x8 v = raw_transform<LM>(r[u], s_aff, a.x.cs_in, c8s[u], a.x.cin, a.x.u8_div);
                         if (!(ok & (1u << u))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                         *reinterpret_cast<f16x8 *>(s_tile + dst[u]) = v;
                     }
@@ -629,13 +630,13 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             const uint8_t *pb = s_u8 + (t >> 4) * u8_nseg + (t & 15) * u8_cin;   // pixel t of the tile
             f16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (f16)((j < 4 && j < u8_cin) ? (float)pb[j] / 255.0f : 0.0f);
+            for (int j = 0; j < 8; ++j) v[j] = (f16)((j < 4 && j < u8_cin) ? (float)pb[j] / a.x.u8_div : 0.0f);
             *reinterpret_cast<f16x8 *>(s_tile + it_lds[0]) = v;
         } else {
 #pragma unroll
             for (int k = 0; k < MAX_ITEMS; ++k) {
                 if (it_lds[k] >= 0) {
-                    f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin);
+                    f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div);
                     if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
                 }
@@ -860,7 +861,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
         for (int k = 0; k < NX; ++k) {
             if (x_lds[k] >= 0) {
                 f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (vx & (1u << k)) v = raw_transform<LM>(xr[k], s_aff, a.x.cs_in, x_c8[k], a.x.cin);
+                if (vx & (1u << k)) v = raw_transform<LM>(xr[k], s_aff, a.x.cs_in, x_c8[k], a.x.cin, a.x.u8_div);
                 *reinterpret_cast<f16x8 *>(s_x + x_lds[k]) = v;
             }
         }

@@ -17,7 +17,8 @@ int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, doub
                            float *save_mean, float *save_invstd, hipStream_t stream);
 int imk_bn_prep_blocks(int B, int H, int W, int cs);
 int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
-                           const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream);
+                           const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream,
+                           int g_other_cs = 0);   // mode 1 without g_direct: channel stride of g_other (0: cs)
 int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *save_mean, const float *save_invstd, const float *inv_scale_ptr, float *coef,
                            float *dgamma, float *dbeta, float *found_inf, hipStream_t stream);
@@ -32,6 +33,19 @@ int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, 
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream);
+
+// EvalNet (evalnet.py:24-47): concatenation of the towers' pooled BatchNorm outputs; the tail (BN + pool on load, global
+// average pool, Dense + sigmoid head(s), and in training the losses, the gradient of the pooled map and the per-sample
+// Dense gradients) and the batch reduction of the latter
+int imk_launch_concat_pool(const f16 *za, const float *sca, const float *sha, int csa, const f16 *zb, const float *scb,
+                           const float *shb, int csb, int B, int Hh, int Wh, f16 *cat, hipStream_t stream);
+size_t imk_evalnet_head_partial_floats(int B, int n_heads, int K, int C);
+int imk_launch_evalnet_head(const f16 *z, const float *sc, const float *sh, const float *const *w, const float *const *bias,
+                            int n_heads, int K, int C, int cs, int B, int H, int W, float *out, const float *y,
+                            const ImkCtl *ctl, float *stats, f16 *dP, float *partial, hipStream_t stream);
+int imk_launch_evalnet_head_reduce(const float *partial, int B, int n_heads, int K, int C, const float *inv_scale_ptr,
+                                   float *dw0, float *db0, float *dw1, float *db1, float *found_inf, float *stats,
+                                   hipStream_t stream);
 
 // End of an optimizer step (Keras dynamic loss scale: halve on overflow, double after 2000 consecutive finite steps;
 // step counter).  Called by one thread of the weight re-packing kernel, which runs right after adamw_kernel.

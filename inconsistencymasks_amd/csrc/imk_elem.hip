@@ -88,6 +88,7 @@ struct BnPrepArgs {
     f16 *dy_out;          // POOL / SUM2: assembled dy
     float *partial;       // [gridDim.x][2*cs]
     int B, H, W, cs;
+    int go_cs;            // POOL: channel stride of g_other (>= cs: a channel slice of a wider tensor, EvalNet's concat)
 };
 
 // block reduction over the pixel slots (fixed tree => deterministic), one partial row per block
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
                     xs[u] = x; ys[u] = y;
                     if (MODE == 1) {
                         const int Hh = a.H / 2, Wh = a.W / 2;
-                        d1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + (((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * nc8 + c8) * 8);
+                        d1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + ((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * a.go_cs + c8 * 8);
                         d0[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                         if (a.g_direct) d0[u] = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
                         // the other three elements of the 2x2 pooling window (row-major order kept below)
@@ -531,6 +532,159 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
+// ---- EvalNet (evalnet.py:24-47) ---------------------------------------------------------------------------------
+// concatenate([towerA, towerB]) of the two towers' BatchNorm + MaxPooling2D outputs (evalnet.py:17-19, 36): one thread
+// per (pooled pixel, 8-channel chunk of the concatenated tensor)
+__global__ __launch_bounds__(256) void concat_pool_kernel(const f16 *__restrict__ za, const float *__restrict__ sca,
+                                                          const float *__restrict__ sha, int csa,
+                                                          const f16 *__restrict__ zb, const float *__restrict__ scb,
+                                                          const float *__restrict__ shb, int csb, int B, int Hh, int Wh,
+                                                          f16 *__restrict__ cat) {
+    const int nc8 = (csa + csb) / 8;
+    const long long n = (long long)B * Hh * Wh * nc8;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % nc8);
+    const long long pix = i / nc8;
+    const int x = (int)(pix % Wh);
+    const long long r = pix / Wh;
+    const int y = (int)(r % Hh), b = (int)(r / Hh);
+    const bool second = c8 * 8 >= csa;
+    const f16 *z = second ? zb : za;
+    const int cs = second ? csb : csa, c0 = second ? c8 * 8 - csa : c8 * 8;
+    const float *sc = (second ? scb : sca) + c0, *sh = (second ? shb : sha) + c0;
+    const int W = 2 * Wh;
+    const f16 *p = z + ((size_t)(b * 2 * Hh + 2 * y) * W + 2 * x) * cs + c0;
+    const f16x8 v0 = *reinterpret_cast<const f16x8 *>(p), v1 = *reinterpret_cast<const f16x8 *>(p + cs);
+    const f16x8 v2 = *reinterpret_cast<const f16x8 *>(p + (size_t)W * cs), v3 = *reinterpret_cast<const f16x8 *>(p + (size_t)W * cs + cs);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // same rounding as the LM_POOL load of the conv kernels
+        const float a = (float)v0[j] * sc[j] + sh[j], bq = (float)v1[j] * sc[j] + sh[j];
+        const float c = (float)v2[j] * sc[j] + sh[j], d = (float)v3[j] * sc[j] + sh[j];
+        o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
+    }
+    *reinterpret_cast<f16x8 *>(cat + (size_t)pix * (csa + csb) + c8 * 8) = o;
+}
+
+// The tail of EvalNet for one sample per workgroup: BatchNorm + MaxPooling2D of the last block (on load), GlobalAvgPool2D,
+// the Dense head(s) with sigmoid (evalnet.py:43-45, 69-71), and in training the losses (head 0: mean squared error, head 1:
+// binary cross-entropy -- functions.py:4708), d(loss * scale)/d(pooled tensor) and the per-sample Dense gradients.
+struct EvalHeadArgs {
+    const f16 *z;            // [B,H,W,cs] output of the last 1x1 conv (pre-BN)
+    const float *sc, *sh;    // [cs] BatchNorm scale / shift
+    const float *w[2], *bias[2];   // Dense kernels [C,K] and biases [K]
+    int n_heads, K, C, cs, B, H, W;
+    float *out;              // [B, n_heads*K] sigmoid outputs
+    const float *y;          // training: [B, n_heads*K] targets, else null
+    const ImkCtl *ctl;
+    float *stats;
+    f16 *dP;                 // [B,H/2,W/2,cs]
+    float *partial;          // [B][n_heads*K*(C+1) + 2]: per sample dW (o-major), db, loss terms of the two heads
+};
+
+__global__ __launch_bounds__(256) void evalnet_head_kernel(EvalHeadArgs a) {
+    extern __shared__ float s_f[];            // feat[cs], then logits / dlogits [n_heads*K]
+    float *s_o = s_f + a.cs;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int Hh = a.H / 2, Wh = a.W / 2, NO = a.n_heads * a.K;
+    const bool train = a.y != nullptr;
+    if (train && b == 0 && t == 0) { a.stats[1] = 0.f; a.stats[2] = a.ctl->loss_scale; a.stats[3] = (float)a.ctl->step; }
+    // features: mean over the pooled map of max(2x2 window of fp16(z*sc + sh))
+    for (int c = t; c < a.cs; c += 256) {
+        float acc = 0.f;
+        if (c < a.C) {
+            const float sc = a.sc[c], sh = a.sh[c];
+            for (int y = 0; y < Hh; ++y)
+                for (int x = 0; x < Wh; ++x) {
+                    const f16 *p = a.z + ((size_t)(b * a.H + 2 * y) * a.W + 2 * x) * a.cs + c;
+                    const float v0 = (float)p[0] * sc + sh, v1 = (float)p[a.cs] * sc + sh;
+                    const float v2 = (float)p[(size_t)a.W * a.cs] * sc + sh, v3 = (float)p[(size_t)a.W * a.cs + a.cs] * sc + sh;
+                    acc += (float)(f16)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                }
+            acc /= (float)(Hh * Wh);
+        }
+        s_f[c] = acc;
+    }
+    __syncthreads();
+    // Dense: one wave per output unit
+    for (int o = t >> 6; o < NO; o += 4) {
+        const int h = o / a.K, k = o - h * a.K;
+        float acc = 0.f;
+        for (int c = t & 63; c < a.C; c += 64) acc += s_f[c] * a.w[h][(size_t)c * a.K + k];
+        acc = wave_sum<64>(acc);
+        if ((t & 63) == 0) s_o[o] = acc + a.bias[h][k];
+    }
+    __syncthreads();
+    float loss_h[2] = {0.f, 0.f};
+    if (t < NO) {
+        const float lg = s_o[t], p = 1.0f / (1.0f + expf(-lg));
+        a.out[(size_t)b * NO + t] = p;
+        if (train) {
+            const int h = t / a.K;
+            const float yv = a.y[(size_t)b * NO + t], S = a.ctl->loss_scale, inv_n = 1.0f / ((float)a.B * (float)a.K);
+            float g;
+            if (h == 0) {   // mean squared error
+                const float e = p - yv;
+                loss_h[0] = e * e;
+                g = 2.0f * e * p * (1.0f - p);
+            } else {        // binary cross-entropy on the sigmoid's logit (Keras uses the activation's cached logits)
+                loss_h[1] = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
+                g = p - yv;
+            }
+            s_o[t] = S * g * inv_n;
+        }
+    }
+    if (!train) return;
+    __syncthreads();
+    float *part = a.partial + (size_t)b * ((size_t)NO * (a.C + 1) + 2);
+    if (t < 64) {   // loss terms of this sample (NO <= 64 outputs sit in the first wave)
+        const float l0 = wave_sum<64>(loss_h[0]), l1 = wave_sum<64>(loss_h[1]);
+        if (t == 0) { part[(size_t)NO * (a.C + 1)] = l0; part[(size_t)NO * (a.C + 1) + 1] = l1; }
+    }
+    // per-sample Dense gradients dW[o][c] = dlogit[o] * feat[c], db[o] = dlogit[o]
+    for (int i = t; i < NO * a.C; i += 256) { const int o = i / a.C, c = i - o * a.C; part[i] = s_o[o] * s_f[c]; }
+    if (t < NO) part[(size_t)NO * a.C + t] = s_o[t];
+    // gradient w.r.t. the pooled map: every window gets dfeat / (Hh*Wh)
+    for (int c = t; c < a.cs; c += 256) {
+        float g = 0.f;
+        if (c < a.C)
+            for (int o = 0; o < NO; ++o) { const int h = o / a.K, k = o - h * a.K; g += s_o[o] * a.w[h][(size_t)c * a.K + k]; }
+        const f16 gv = (f16)(g / (float)(Hh * Wh));
+        for (int q = 0; q < Hh * Wh; ++q) a.dP[((size_t)b * Hh * Wh + q) * a.cs + c] = gv;
+    }
+}
+
+// sum the per-sample Dense gradients over the batch (fixed order), unscale, flag non-finite values; block 0 also
+// reduces the loss terms: stats[0] = total, stats[4] = head 0 (mse), stats[5] = head 1 (bce)
+__global__ __launch_bounds__(256) void evalnet_head_reduce_kernel(const float *__restrict__ partial, int B, int n_heads, int K,
+                                                                 int C, const float *__restrict__ inv_scale_ptr,
+                                                                 float *__restrict__ dw0, float *__restrict__ db0,
+                                                                 float *__restrict__ dw1, float *__restrict__ db1,
+                                                                 float *__restrict__ found_inf, float *__restrict__ stats) {
+    const int NO = n_heads * K, per = NO * (C + 1) + 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NO * (C + 1)) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += partial[(size_t)b * per + i];
+        s *= *inv_scale_ptr;
+        if (!isfinite(s)) *found_inf = 1.0f;
+        if (i < NO * C) {
+            const int o = i / C, c = i - o * C, h = o / K, k = o - h * K;
+            (h ? dw1 : dw0)[(size_t)c * K + k] = s;
+        } else {
+            const int o = i - NO * C, h = o / K, k = o - h * K;
+            (h ? db1 : db0)[k] = s;
+        }
+    }
+    if (i == 0) {
+        double l0 = 0, l1 = 0;
+        for (int b = 0; b < B; ++b) { l0 += partial[(size_t)b * per + per - 2]; l1 += partial[(size_t)b * per + per - 1]; }
+        const float m0 = (float)(l0 / ((double)B * K)), m1 = (float)(l1 / ((double)B * K));
+        stats[0] = m0 + m1; stats[4] = m0; stats[5] = m1;
+    }
+}
+
 }  // namespace
 
 // -----------------------------------------------------------------------------------------------------
@@ -565,8 +719,10 @@ int imk_bn_prep_blocks(int B, int H, int W, int cs) {
 }
 
 int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
-                           const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream) {
-    BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs};
+                           const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream,
+                           int g_other_cs) {
+    BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs, g_other_cs > 0 ? g_other_cs : cs};
+    if (a.go_cs != cs && (mode != 1 || g_direct)) return IMK_EUNSUPPORTED;
     const int nb = imk_bn_prep_blocks(B, H, W, cs);
     if (mode == 0) bn_bwd_prep_kernel<0><<<nb, 256, 0, stream>>>(a);
     else if (mode == 1 && H % 2 == 0 && W % 2 == 0 && g_direct) bn_bwd_prep_pool_kernel<<<nb, 256, 0, stream>>>(a);
@@ -652,4 +808,35 @@ int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, 
     adamw_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(p, m, v, g, n, ctl, stats, grad_scale, lr, wd, b1, b2, eps);
     IMK_LAUNCH_CHECK();
     return IMK_OK;   // the step counter / loss scale update rides on the re-packing launch that follows (imk_ctl_end_step)
+}
+
+int imk_launch_concat_pool(const f16 *za, const float *sca, const float *sha, int csa, const f16 *zb, const float *scb,
+                           const float *shb, int csb, int B, int Hh, int Wh, f16 *cat, hipStream_t stream) {
+    const long long n = (long long)B * Hh * Wh * ((csa + csb) / 8);
+    concat_pool_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(za, sca, sha, csa, zb, scb, shb, csb, B, Hh, Wh, cat);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+size_t imk_evalnet_head_partial_floats(int B, int n_heads, int K, int C) { return (size_t)B * ((size_t)n_heads * K * (C + 1) + 2); }
+
+int imk_launch_evalnet_head(const f16 *z, const float *sc, const float *sh, const float *const *w, const float *const *bias,
+                            int n_heads, int K, int C, int cs, int B, int H, int W, float *out, const float *y,
+                            const ImkCtl *ctl, float *stats, f16 *dP, float *partial, hipStream_t stream) {
+    if (n_heads < 1 || n_heads > 2 || n_heads * K > 64 || (H & 1) || (W & 1)) return IMK_EUNSUPPORTED;
+    EvalHeadArgs a{z, sc, sh, {w[0], n_heads > 1 ? w[1] : nullptr}, {bias[0], n_heads > 1 ? bias[1] : nullptr},
+                   n_heads, K, C, cs, B, H, W, out, y, ctl, stats, dP, partial};
+    evalnet_head_kernel<<<B, 256, (size_t)(cs + 64) * sizeof(float), stream>>>(a);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_evalnet_head_reduce(const float *partial, int B, int n_heads, int K, int C, const float *inv_scale_ptr,
+                                   float *dw0, float *db0, float *dw1, float *db1, float *found_inf, float *stats,
+                                   hipStream_t stream) {
+    const int n = n_heads * K * (C + 1);
+    evalnet_head_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(partial, B, n_heads, K, C, inv_scale_ptr, dw0, db0, dw1, db1,
+                                                                   found_inf, stats);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
 }

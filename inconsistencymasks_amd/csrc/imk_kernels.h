@@ -8,7 +8,7 @@ enum ImkLoadMode {
     LM_AFFINE = 1,  // fp16(z*sc + sh)                                   (BN on load)
     LM_POOL = 2,    // 2x2 max of fp16(z*sc + sh), z at [B,2H,2W,cs]     (BN + MaxPooling2D, unet.py:16-17)
     LM_UPADD = 3,   // fp16( fp16(zlo*sc+sh)[y/2,x/2] + fp16(zsk*sc2+sh2) )  (UpSampling2D + add, unet.py:32-33)
-    LM_U8 = 4,      // fp16(u8/255), [B,H,W,cin] bytes                   (Lambda x/255, unet.py:5)
+    LM_U8 = 4,      // fp16(u8/u8_div), [B,H,W,cin] bytes                (Lambda x/255, unet.py:5)
     LM_BNBWD = 5,   // (A*dy + B*z + C) * [z > 0]: BatchNorm backward + ReLU backward applied on load;
                     // in = dy, in2 = z (the BN's input), sc = per-channel coefficients [A | B | C] (3*cs floats)
 };
@@ -25,6 +25,7 @@ struct ImkInput {
     const float *sc2, *sh2;
     int lmode;
     int cin, cs_in;        // logical / padded-to-8 channel count (LM_U8: cs_in = 8)
+    float u8_div;          // LM_U8: 255 (Lambda x/255, unet.py:5) or 1 (evalnet.py:5, normalize=False)
 };
 
 struct ImkConvArgs {

@@ -1,0 +1,468 @@
+// Host orchestration shared by the two networks of the reference (imk_unet.hip: unet.py:4-67, imk_evalnet.hip:
+// evalnet.py:4-47), both stacks of Conv3x3+ReLU -> Conv1x1+ReLU -> BatchNorm blocks: flat parameter layout, weight
+// packing, per-layer workspace, one conv launch with its BatchNorm statistics, and the backward helpers (dgrad, weight
+// gradients on a side stream, BatchNorm backward).  The network files add the topology and the order of the launches.
+// Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include "imk_elem.h"
+#include "imk_kernels.h"
+#include "imk_plan.h"
+
+extern bool g_imk_materialize;     // imk_debug_materialize(1): inference also stores the intermediates of fused kernels
+extern bool g_imk_single_stream;   // imk_debug_single_stream(1): no side streams (kernels run alone: exclusive timings)
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+// ---- layers ----------------------------------------------------------------------------------------
+inline int add_conv(imk_unet_plan *p, const char *name, int k, int cin, int cout, int res) {
+    ImkLayer l{};
+    l.name = name; l.kind = 0; l.ksize = k; l.cin = cin; l.cout = cout; l.res = res;
+    p->layers.push_back(l);
+    return (int)p->layers.size() - 1;
+}
+inline int add_bn(imk_unet_plan *p, const char *name, int c, int res, int producer) {
+    ImkLayer l{};
+    l.name = name; l.kind = 1; l.ksize = 0; l.cin = c; l.cout = c; l.res = res; l.producer = producer;
+    p->layers.push_back(l);
+    const int idx = (int)p->layers.size() - 1;
+    p->layers[producer].bn_after = idx;
+    return idx;
+}
+inline void set_src(imk_unet_plan *p, int conv, int lmode, int src, int src_bn = -1, int src2 = -1, int src2_bn = -1) {
+    ImkLayer &l = p->layers[conv];
+    l.lmode = lmode; l.src = src; l.src_bn = src_bn; l.src2 = src2; l.src2_bn = src2_bn;
+}
+
+// flat parameter layout (trainable section, then moving statistics) and the packed-weight buffer
+inline void finish_layout(imk_unet_plan *p) {
+    int64_t off = 0;
+    for (auto &l : p->layers) {
+        if (l.kind == 0) { l.off_w = off; off += (int64_t)l.ksize * l.ksize * l.cin * l.cout; l.off_b = off; off += l.cout; }
+        else { l.off_w = off; off += l.cout; l.off_b = off; off += l.cout; }
+        l.off_mean = l.off_var = -1;
+    }
+    p->n_trainable = off;
+    for (auto &l : p->layers)
+        if (l.kind == 1) { l.off_mean = off; off += l.cout; l.off_var = off; off += l.cout; }
+    p->n_total = off;
+
+    size_t pk = 0;
+    for (auto &l : p->layers) {
+        l.pk_fwd = l.pk_bwd = l.pk_chain = -1;
+        if (l.kind == 0) {
+            if (l.flags & IMK_LF_DENSE) continue;   // fp32 only
+            const bool u8 = l.lmode == LM_U8;   // a stem reads the uint8 image
+            l.pk_bytes_fwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 0, imk_conv_pair_layout(l.cin, l.cout, u8)) * 2;
+            l.pk_bytes_bwd = (int64_t)imk_packed_conv_halfs(l.ksize, l.cin, l.cout, 1, imk_conv_pair_layout(l.cout, l.cin, false)) * 2;
+            l.pk_fwd = (int64_t)pk; pk = up(pk + l.pk_bytes_fwd);
+            l.pk_bwd = (int64_t)pk; pk = up(pk + l.pk_bytes_bwd);
+            if (l.ksize == 1 && l.cin <= 16 && l.cout <= 16) { l.pk_chain = (int64_t)pk; pk = up(pk + 1024); }
+        } else {
+            l.pk_scale = (int64_t)pk; pk = up(pk + 2 * (size_t)imk_pad8(l.cout) * sizeof(float));
+        }
+    }
+    p->packed_bytes = (int64_t)pk;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------
+struct LayerWs {
+    size_t out = 0;            // conv: output tensor fp16 [B,H,W,cs]
+    size_t dA = 0;             // conv (train): gradient w.r.t. pre-activation output
+    size_t dy = 0;             // bn (train): gradient w.r.t. the BN output
+    size_t stats_partial = 0;  // bn (train): [n_tiles][2cs]
+    size_t scale = 0;          // bn (train): scale[cs], shift[cs]
+    size_t save = 0;           // bn (train): mean[cs], invstd[cs]
+    size_t bwd_partial = 0;    // bn (train)
+    size_t coef = 0;           // bn (train): [3][cs]
+    size_t wg_partial = 0;     // conv (train): this layer's weight-gradient partials (+ stage-1 scratch)
+    int n_stats_tiles = 0;
+    int n_bwd_rows = 0;        // bn (train): capacity of bwd_partial in rows
+};
+struct Ws {
+    std::vector<LayerWs> L;
+    // U-Net
+    size_t dU[4] = {0, 0, 0, 0};   // train: gradient w.r.t. decoder j's upsample+add output
+    size_t dP[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // train: gradient w.r.t. the pooled output of a block (U-Net: encoder i+1;
+                                               // EvalNet: trunk block i+1, [5] = the last block's, written by the head)
+    size_t probs = 0, dlogit = 0, loss_partial = 0;
+    // EvalNet
+    size_t cat = 0, dcat = 0;      // concatenated pooled tower outputs [B,H/2,W/2,2F] and their gradient
+    size_t head_partial = 0;       // train: per-sample Dense gradients and loss terms
+    size_t total = 0;
+};
+
+struct Dim { int h, w; };
+inline Dim res_dim(const imk_unet_cfg &c, int res) { return Dim{c.h >> res, c.w >> res}; }
+
+// the per-layer part of the workspace: activations, and in training the gradients / statistics of every layer
+template <typename Take>
+inline void make_ws_layers(const imk_unet_plan *p, int B, int mode, Ws &w, Take &&take) {
+    const int n = (int)p->layers.size();
+    w.L.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const ImkLayer &l = p->layers[i];
+        const Dim d = res_dim(p->cfg, l.res);
+        const size_t px = (size_t)B * d.h * d.w;
+        if (l.kind == 0) {
+            if (l.flags & IMK_LF_DENSE) continue;
+            if (!(l.flags & IMK_LF_HEAD)) w.L[i].out = take(px * imk_pad8(l.cout) * 2);
+            if (mode == 1) {
+                w.L[i].dA = take(px * imk_pad8(l.cout) * 2);
+                w.L[i].wg_partial = take(imk_wgrad_partial_floats(B, d.h, d.w, l.ksize, l.cin, l.cout) * sizeof(float));
+            }
+        } else if (mode == 1) {
+            const int cs = imk_pad8(l.cout);
+            const ImkLayer &pc = p->layers[l.producer];
+            w.L[i].n_stats_tiles = imk_conv_num_tiles(B, d.h, d.w, imk_pad8(pc.cin), pc.ksize);
+            w.L[i].stats_partial = take((size_t)w.L[i].n_stats_tiles * 2 * cs * sizeof(float));
+            w.L[i].scale = take(2 * (size_t)cs * sizeof(float));
+            w.L[i].save = take(2 * (size_t)cs * sizeof(float));
+            w.L[i].n_bwd_rows = imk_bn_prep_blocks(B, d.h, d.w, cs);
+            const int conv_rows = B * imk_cdiv(d.h, 8) * imk_cdiv(d.w, 16);   // most rows a dgrad epilogue can write
+            if (conv_rows > w.L[i].n_bwd_rows) w.L[i].n_bwd_rows = conv_rows;
+            w.L[i].bwd_partial = take((size_t)w.L[i].n_bwd_rows * 2 * cs * sizeof(float));
+            w.L[i].coef = take(3 * (size_t)cs * sizeof(float));
+            w.L[i].dy = take(px * cs * 2);
+        }
+    }
+}
+
+// ---- one pass ----------------------------------------------------------------------------------------
+struct Ctx {
+    const imk_unet_plan *p;
+    Ws ws;
+    uint8_t *base;        // workspace
+    const float *params;
+    const uint8_t *packed;
+    int B;
+    bool train;
+    hipStream_t stream;
+    const uint8_t *x_in[2] = {nullptr, nullptr};   // the uint8 network inputs (U-Net: [0] only)
+    f16 *act(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].out); }
+    f16 *dA(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].dA); }
+    f16 *dy(int bn) const { return reinterpret_cast<f16 *>(base + ws.L[bn].dy); }
+    const float *bn_scale(int bn) const {
+        return train ? reinterpret_cast<const float *>(base + ws.L[bn].scale)
+                     : reinterpret_cast<const float *>(packed + p->layers[bn].pk_scale);
+    }
+    const float *bn_shift(int bn) const { return bn_scale(bn) + imk_pad8(p->layers[bn].cout); }
+    const f16 *wfwd(int conv) const { return reinterpret_cast<const f16 *>(packed + p->layers[conv].pk_fwd); }
+    const f16 *wbwd(int conv) const { return reinterpret_cast<const f16 *>(packed + p->layers[conv].pk_bwd); }
+};
+
+// the input description of every conv (shared by forward and wgrad), from the plan's graph
+inline ImkInput conv_input(const Ctx &c, int conv) {
+    const ImkLayer &l = c.p->layers[conv];
+    ImkInput in{};
+    in.cin = l.cin;
+    in.cs_in = imk_pad8(l.cin);
+    in.lmode = l.lmode;
+    if (l.lmode == LM_U8) {
+        in.in = c.x_in[l.src == IMK_SRC_XB ? 1 : 0];
+        in.cs_in = 8;
+        in.u8_div = (l.flags & IMK_LF_U8_RAW) ? 1.0f : 255.0f;
+        return in;
+    }
+    in.in = l.src == IMK_SRC_CAT ? reinterpret_cast<const void *>(c.base + c.ws.cat) : c.act(l.src);
+    if (l.src_bn >= 0) { in.sc = c.bn_scale(l.src_bn); in.sh = c.bn_shift(l.src_bn); }
+    if (l.src2 >= 0) { in.in2 = c.act(l.src2); in.sc2 = c.bn_scale(l.src2_bn); in.sh2 = c.bn_shift(l.src2_bn); }
+    return in;
+}
+
+// conv2 >= 0: fuse the 1x1 conv `conv2` (whose only input is conv's output) into the same kernel when possible.
+// Returns 1 in *fused if it did.
+inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool *fused = nullptr) {
+    const ImkLayer &l = c.p->layers[conv];
+    const Dim d = res_dim(c.p->cfg, l.res);
+    ImkConvArgs a{};
+    a.x = conv_input(c, conv);
+    a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
+    a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+    a.wpk = c.wfwd(conv);
+    a.bias = c.params + l.off_b;
+    a.out = c.act(conv);
+    a.epi = EP_RELU;
+    int stat_conv = conv;
+    if (fused) *fused = false;
+    if (conv2 >= 0) {
+        const ImkLayer &l2 = c.p->layers[conv2];
+        if (l2.pk_chain >= 0 && imk_conv_can_chain(a, l2.cout)) {
+            a.wpk2 = reinterpret_cast<const f16 *>(c.packed + l2.pk_chain);
+            a.bias2 = c.params + l2.off_b;
+            a.out2 = c.act(conv2);
+            a.cout2 = l2.cout; a.cs_out2 = imk_pad8(l2.cout);
+            if (!c.train && !g_imk_materialize) a.out = nullptr;   // the intermediate never leaves the chip
+            stat_conv = conv2;
+            if (fused) *fused = true;
+        }
+    }
+    const int bn = c.p->layers[stat_conv].bn_after;
+    int rows = 0;
+    if (c.train && bn >= 0) {
+        a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].stats_partial);
+        a.stats_rows = &rows;
+    }
+    int rc = imk_launch_conv(a, c.stream);
+    if (rc) return rc;
+    if (c.train && bn >= 0) {
+        const ImkLayer &b = c.p->layers[bn];
+        const int cs = imk_pad8(b.cout);
+        float *sc = reinterpret_cast<float *>(c.base + c.ws.L[bn].scale);
+        float *sv = reinterpret_cast<float *>(c.base + c.ws.L[bn].save);
+        if (rows <= 0 || rows > c.ws.L[bn].n_stats_tiles) return IMK_EWORKSPACE;
+        rc = imk_launch_bn_finalize(a.stats_partial, rows, b.cout, cs, (double)c.B * d.h * d.w,
+                                    c.params + b.off_w, c.params + b.off_b, params_rw + b.off_mean, params_rw + b.off_var,
+                                    sc, sc + cs, sv, sv + cs, c.stream);
+    }
+    return rc;
+}
+
+// Conv3x3+ReLU -> Conv1x1+ReLU of a block: one kernel where the channel counts allow it, else two
+inline int run_conv_pair(Ctx &c, int c3, int c1, float *params_rw) {
+    bool f = false;
+    int rc = run_conv_fwd(c, c3, params_rw, c1, &f);
+    if (rc || f) return rc;
+    return run_conv_fwd(c, c1, params_rw);
+}
+
+// ---- training ----------------------------------------------------------------------------------------
+struct StateView { float *m, *v; ImkCtl *ctl; };
+inline StateView state_view(const imk_unet_plan *p, void *state) {
+    uint8_t *b = (uint8_t *)state;
+    const size_t n = up((size_t)p->n_trainable * sizeof(float));
+    return StateView{(float *)b, (float *)(b + n), (ImkCtl *)(b + 2 * n)};
+}
+
+struct Bwd {
+    Ctx &c;
+    float *grads;
+    ImkCtl *ctl;
+    float *found_inf;       // = stats + 1: set to 1 by any gradient kernel that sees a non-finite value
+    int n_side;             // side streams in use (0: everything on c.stream); weight-gradient work is dealt round-robin
+    long long side_max_pixels;   // layers with at most this many pixels run their wgrad on a side stream
+    ImkWgFinalJobs jobs{};
+    int n_fork = 0;
+    bool used_side[imk_unet_plan::MAX_SIDE] = {};
+
+    int dy_rows[64] = {};   // per BN: statistics rows written by the kernel that produced dy (0 = none, run the prep pass)
+
+    // Where the pre-activation gradient of `conv` comes from: convs that feed a BatchNorm get it on load from that
+    // BN's (dy, z, coefficients); the 3x3 convs get the materialised, ReLU-masked dgrad output of the following 1x1.
+    void grad_input(int conv, ImkInput &in) const {
+        const ImkLayer &l = c.p->layers[conv];
+        in.cin = l.cout; in.cs_in = imk_pad8(l.cout);
+        const int bn = l.bn_after;
+        if (bn >= 0) {
+            in.in = c.dy(bn); in.in2 = c.act(conv); in.lmode = LM_BNBWD;
+            in.sc = reinterpret_cast<const float *>(c.base + c.ws.L[bn].coef);
+        } else {
+            in.in = c.dA(conv); in.lmode = LM_RAW;
+        }
+    }
+    // dgrad of `conv` -> dst, optionally masked by the ReLU of the tensor `mask`.  If dst is the output gradient of
+    // a BatchNorm whose only gradient source this is (stat_bn >= 0), the kernel also emits that BN's backward
+    // statistics (sum dy, sum dy*z), which saves the separate reduction pass.
+    void dgrad_args(int conv, f16 *dst, const f16 *mask, int stat_bn, int *rows, ImkConvArgs &a) const {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        grad_input(conv, a.x);
+        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
+        a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
+        a.wpk = c.wbwd(conv);
+        a.out = dst;
+        a.mask = mask;
+        a.epi = mask ? EP_MASK : EP_PLAIN;
+        if (stat_bn >= 0) {
+            a.dystat_z = c.act(c.p->layers[stat_bn].producer);
+            a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[stat_bn].bwd_partial);
+            a.stats_rows = rows;
+        }
+    }
+    int dgrad_done(int stat_bn, int rows) {
+        if (stat_bn >= 0) {
+            if (rows <= 0 || rows > c.ws.L[stat_bn].n_bwd_rows) return IMK_EWORKSPACE;
+            dy_rows[stat_bn] = rows;
+        }
+        return IMK_OK;
+    }
+    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        ImkConvArgs a{};
+        int rows = 0;
+        dgrad_args(conv, dst, mask, stat_bn, &rows, a);
+        int rc = imk_launch_conv(a, c.stream);
+        if (rc) return rc;
+        return dgrad_done(stat_bn, rows);
+    }
+    void wgrad_args(int conv, const f16 *dA_override, ImkWgradArgs &a) const {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        a.x = conv_input(c, conv);
+        if (dA_override) {
+            a.dA = dA_override;
+        } else {
+            ImkInput gi{};
+            grad_input(conv, gi);
+            a.dA = reinterpret_cast<const f16 *>(gi.in);
+            if (gi.lmode == LM_BNBWD) { a.dA_z = reinterpret_cast<const f16 *>(gi.in2); a.dA_coef = gi.sc; }
+        }
+        a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+        a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
+        a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
+    }
+    int wgrad_job(int conv, const ImkWgradArgs &a) {
+        const ImkLayer &l = c.p->layers[conv];
+        return imk_wgf_add_job(jobs, a.partial, a.n_split, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+    }
+    // Weight/bias gradient of `conv`: depends only on dA[conv] (just produced on the main stream) and on forward
+    // tensors, and nothing downstream in the backward pass depends on it -> it goes to the side stream.  Forking costs
+    // an event record on the main stream (a barrier packet: ~6 us before the next kernel starts), so the weight
+    // gradients of a whole resolution block are queued and forked together (flush_wgrads: 11 forks per step, not 24).
+    struct Pending { int conv; const f16 *dA_override; };
+    Pending pending[8];
+    int n_pending = 0;
+    int launch_wgrad(int conv, const f16 *dA_override, hipStream_t ws) {
+        ImkWgradArgs a{};
+        wgrad_args(conv, dA_override, a);
+        int rc = imk_launch_wgrad(a, ws);
+        if (rc) return rc;
+        return wgrad_job(conv, a);
+    }
+    int wgrad(int conv, const f16 *dA_override = nullptr) {
+        const ImkLayer &l = c.p->layers[conv];
+        const Dim d = res_dim(c.p->cfg, l.res);
+        const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
+        if (n_side > 0 && small) {
+            if (n_pending == 8) { int rc = flush_wgrads(); if (rc) return rc; }
+            pending[n_pending++] = Pending{conv, dA_override};
+            // full-resolution layers: fork at once -- their kernels are long (the bubble is small against them) and the
+            // last block's weight gradients would otherwise all start after the main chain has ended
+            return l.res == 0 ? flush_wgrads() : IMK_OK;
+        }
+        return launch_wgrad(conv, dA_override, c.stream);
+    }
+    int flush_wgrads() {
+        if (n_pending == 0) return IMK_OK;
+        const int si = n_fork % n_side;
+        hipStream_t ws = c.p->side[si];
+        hipEvent_t ev = c.p->ev_fork[n_fork++];
+        IMK_HIP(hipEventRecord(ev, c.stream));
+        IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
+        used_side[si] = true;
+        for (int i = 0; i < n_pending; ++i) {
+            int rc = launch_wgrad(pending[i].conv, pending[i].dA_override, ws);
+            if (rc) return rc;
+        }
+        n_pending = 0;
+        // ... and their split reductions right behind them, so that only the last layers' are left for the end of the step
+        int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, found_inf, ws);
+        jobs = ImkWgFinalJobs{};
+        return rc;
+    }
+    // wgrad (side stream) + dgrad of `conv`; both read its pre-activation gradient.  Running the two as ONE launch
+    // (dgrad and wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per
+    // step) -- the common LDS footprint of the fused kernel leaves one workgroup per CU.
+    int wgrad_dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        int rc = wgrad(conv);
+        if (rc) return rc;
+        return dgrad(conv, dst, mask, stat_bn);
+    }
+    // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
+    int finish_wgrads() {
+        // what is still queued (the stem's weight gradient) has nothing left to overlap with: main stream
+        for (int i = 0; i < n_pending; ++i) {
+            int rc = launch_wgrad(pending[i].conv, pending[i].dA_override, c.stream);
+            if (rc) return rc;
+        }
+        n_pending = 0;
+        for (int si = 0; si < n_side; ++si) {   // join: the reductions below read the side streams' partials
+            if (!used_side[si]) continue;
+            IMK_HIP(hipEventRecord(c.p->ev_join[si], c.p->side[si]));
+            IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join[si], 0));
+        }
+        return imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, found_inf, c.stream);
+    }
+    // BN backward for `bn`: per-channel coefficients of  dz = A*dy + B*z + C  (+ gamma/beta gradients).  The
+    // reduction (sum dy, sum dy*z) comes from the kernel that produced dy when there was exactly one (dy_rows),
+    // else from a pass that also assembles dy from its sources (mode 1: skip gradient + max-pool scatter,
+    // mode 2: 2x2 sum of the upsampled branch).  The consumers apply the coefficients on load (LM_BNBWD).
+    int bn_bwd(int bn, int mode, const f16 *g_direct, const f16 *g_other, int g_other_cs = 0) {
+        const ImkLayer &b = c.p->layers[bn];
+        const Dim d = res_dim(c.p->cfg, b.res);
+        const int cs = imk_pad8(b.cout);
+        const int prod = b.producer;
+        const LayerWs &lw = c.ws.L[bn];
+        float *partial = reinterpret_cast<float *>(c.base + lw.bwd_partial);
+        float *coef = reinterpret_cast<float *>(c.base + lw.coef);
+        const float *save = reinterpret_cast<const float *>(c.base + lw.save);
+        const f16 *z = c.act(prod);
+        int rows = dy_rows[bn];
+        if (mode != 0 || rows == 0) {
+            int rc = imk_launch_bn_bwd_prep(mode, mode == 0 ? c.dy(bn) : g_direct, g_other, z, c.bn_scale(bn), c.bn_shift(bn),
+                                            c.dy(bn), partial, c.B, d.h, d.w, cs, c.stream, g_other_cs);
+            if (rc) return rc;
+            rows = imk_bn_prep_blocks(c.B, d.h, d.w, cs);
+        }
+        return imk_launch_bn_bwd_coef(partial, rows, b.cout, cs, (double)c.B * d.h * d.w, c.params + b.off_w, save, save + cs,
+                                      &ctl->inv_loss_scale, coef, grads + b.off_w, grads + b.off_b, found_inf, c.stream);
+    }
+};
+
+// Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
+// Side streams + fork/join events of a plan, created on first use (training: weight gradients; ensemble inference: one
+// model per stream).
+inline bool ensure_side_streams(const imk_unet_plan *plan) {
+    std::call_once(plan->side_once, [plan]() {
+        bool ok = true;
+        for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
+            ok = ok && hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        plan->side_ok = ok;
+    });
+    return plan->side_ok;
+}
+
+// ctl / stats: non-null after an optimizer step -- the first packing launch then also closes the step (loss-scale and
+// step-counter update), which saves a launch of its own.
+inline int pack_weights(const imk_unet_plan *plan, const float *params, void *packed, hipStream_t stream, ImkCtl *ctl,
+                        const float *stats, bool fold_bn) {
+    IMK_CHECK_ARG(plan && params && packed);
+    uint8_t *pk = (uint8_t *)packed;
+    ImkPackJobs pj{};
+    ImkFoldJobs fj{};
+    pj.ctl = ctl; pj.stats = stats;
+    auto flush_pack = [&]() -> int { int rc = imk_launch_pack_jobs(pj, stream); pj.n = 0; pj.ctl = nullptr; return rc; };
+    for (size_t i = 0; i < plan->layers.size(); ++i) {
+        const ImkLayer &l = plan->layers[i];
+        if (l.kind == 0) {
+            if (l.flags & IMK_LF_DENSE) continue;
+            for (int tr = 0; tr < 3; ++tr) {
+                if (tr == 0 && (l.flags & IMK_LF_HEAD)) continue;   // the head runs in fp32 from `params` directly
+                if (tr == 2 && (l.pk_chain < 0 || (l.flags & IMK_LF_HEAD))) continue;
+                f16 *dst = (f16 *)(pk + (tr == 2 ? l.pk_chain : (tr ? l.pk_bwd : l.pk_fwd)));
+                const int pair = tr == 2 ? (imk_conv_pair_layout(l.cin, l.cout, false) && l.cin <= 8)
+                                         : (tr ? imk_conv_pair_layout(l.cout, l.cin, false) : imk_conv_pair_layout(l.cin, l.cout, l.lmode == LM_U8));
+                pj.j[pj.n++] = ImkPackJob{params + l.off_w, dst, l.ksize, l.cin, l.cout, tr, pair};
+                if (pj.n == IMK_PACK_MAX_JOBS) { int rc = flush_pack(); if (rc) return rc; }
+            }
+        } else {
+            if (fj.n == IMK_FOLD_MAX_JOBS) return IMK_EUNSUPPORTED;
+            fj.j[fj.n++] = ImkFoldJob{params + l.off_w, params + l.off_b, params + l.off_mean, params + l.off_var,
+                                      (float *)(pk + l.pk_scale), l.cout, imk_pad8(l.cout)};
+        }
+    }
+    int rc = flush_pack();
+    if (rc) return rc;
+    if (pj.ctl) return IMK_EINVAL;   // the step must have been closed by a packing launch
+    return fold_bn ? imk_launch_bn_fold_jobs(fj, stream) : IMK_OK;
+}
+
+}  // namespace

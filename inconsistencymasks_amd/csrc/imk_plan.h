@@ -1,4 +1,6 @@
-// Host-side description of the tiny U-Net (unet.py:4-67) shared by the forward / training code.
+// Host-side description of a network built from the reference's blocks -- the tiny U-Net (unet.py:4-67) and EvalNet
+// (evalnet.py:4-47): a list of conv / BatchNorm layers plus, per layer, where its input comes from.  Shared by the
+// forward / training code of both (imk_net.h).
 #pragma once
 #include <mutex>
 #include <string>
@@ -17,10 +19,27 @@ struct ImkLayer {
     int64_t pk_bytes_fwd, pk_bytes_bwd;
     int64_t pk_chain;            // 1x1 convs: chain operand (fused behind the preceding 3x3), else -1
     int64_t pk_scale;            // bn: fp32 scale[cpad], shift[cpad] for inference (folded moving stats)
+    // graph, filled by the network builder
+    int src = -1;                // conv: the conv whose output it reads, or IMK_SRC_XA / _XB (the uint8 network inputs) /
+                                 // IMK_SRC_CAT (EvalNet's concatenated towers)
+    int src_bn = -1;             // conv: BatchNorm applied to `src` on load (-1: none)
+    int src2 = -1, src2_bn = -1; // conv, LM_UPADD: the skip tensor and its BatchNorm
+    int lmode = 0;               // conv: ImkLoadMode
+    int bn_after = -1;           // conv: the BatchNorm that normalises its output (-1: none)
+    int producer = -1;           // bn: the conv that feeds it
+    int flags = 0;               // IMK_LF_*
+};
+enum { IMK_SRC_XA = -2, IMK_SRC_XB = -3, IMK_SRC_CAT = -4 };
+enum {
+    IMK_LF_HEAD = 1,     // the U-Net's output conv: forward in fp32 from the flat parameters (only its dgrad operand is packed)
+    IMK_LF_DENSE = 4,    // EvalNet's Dense heads: fp32 only, no packed weights, no workspace
+    IMK_LF_U8_RAW = 2,   // uint8 stem without the x/255 Lambda (evalnet.py:5-6, normalize=False)
 };
 
 struct imk_unet_plan {
-    imk_unet_cfg cfg;
+    imk_unet_cfg cfg;            // EvalNet plans: h, w, c_in (= input A's channels), n_out and ch are filled too
+    int net = 0;                 // 0 U-Net, 1 EvalNet
+    imk_evalnet_cfg ecfg{};
     std::vector<ImkLayer> layers;
     int64_t n_total, n_trainable;
     int64_t packed_bytes;

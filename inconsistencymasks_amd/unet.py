@@ -29,6 +29,12 @@ class Plan:
         self.h, self.w, self.c_in, self.n_out, self.alpha, self.act_out = h, w, c_in, n_out, alpha, act_out
         self._p = ctypes.c_void_p()
         check(lib.imk_unet_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._p)), "imk_unet_plan_create")
+        self._describe()
+
+    _ws_fn = "imk_unet_workspace_bytes"
+
+    def _describe(self):
+        """parameter layout of the created plan (shared with EvalNet plans, which are the same C object)"""
         t, tr = ctypes.c_int64(), ctypes.c_int64()
         check(lib.imk_unet_param_count(self._p, ctypes.byref(t), ctypes.byref(tr)), "imk_unet_param_count")
         self.n_total, self.n_trainable = t.value, tr.value
@@ -46,9 +52,9 @@ class Plan:
         return self._p
 
     def workspace_bytes(self, batch, mode):
-        n = lib.imk_unet_workspace_bytes(self._p, batch, mode)
+        n = getattr(lib, self._ws_fn)(self._p, batch, mode)
         if n < 0:
-            check(int(n), "imk_unet_workspace_bytes")
+            check(int(n), self._ws_fn)
         return n
 
     def __del__(self):
@@ -75,15 +81,24 @@ def he_normal(shape, fan_in, gen):
 class UNet:
     """The tiny U-Net of unet.py as a flat parameter vector + a kernel plan."""
 
+    N_STATS = 4     # loss, overflow flag, loss scale, step
+
     def __init__(self, h, w, c_in, n_out, alpha, act_out="sigmoid", seed=None, device="cuda"):
-        self.plan = Plan(h, w, c_in, n_out, alpha, act_out)
+        self._init_from_plan(Plan(h, w, c_in, n_out, alpha, act_out), seed, device)
+
+    def _init_from_plan(self, plan, seed, device, dense=()):
+        self.plan = plan
         self.device = torch.device(device)
         gen = torch.Generator()
         if seed is not None:
             gen.manual_seed(int(seed))
         flat = torch.zeros(self.plan.n_total, dtype=torch.float32)
         for l in self.plan.layers:
-            if l["kind"] == 0:
+            if l["kind"] == 0 and l["name"] in dense:      # Keras Dense default: glorot_uniform
+                ci, co = l["cin"], l["cout"]
+                lim = math.sqrt(6.0 / (ci + co))
+                flat[l["off_w"]:l["off_w"] + ci * co] = (torch.rand(ci * co, generator=gen) * 2 - 1) * lim
+            elif l["kind"] == 0:
                 k, ci, co = l["ksize"], l["cin"], l["cout"]
                 flat[l["off_w"]:l["off_w"] + k * k * ci * co] = he_normal((k * k * ci * co,), k * k * ci, gen)
             else:
@@ -203,8 +218,8 @@ class UNet:
     def init_train_state(self):
         self.train_state = torch.empty(self.plan.state_bytes, dtype=torch.uint8, device=self.device)
         check(lib.imk_unet_state_init(self.plan.ptr, self.train_state.data_ptr(), _stream()), "imk_unet_state_init")
-        # gradients and the 4 step statistics share one buffer: a data-parallel step is ONE all-reduce (grads_and_stats)
-        self.grads_and_stats = torch.zeros(self.plan.n_trainable + 4, dtype=torch.float32, device=self.device)
+        # gradients and the step statistics share one buffer: a data-parallel step is ONE all-reduce (grads_and_stats)
+        self.grads_and_stats = torch.zeros(self.plan.n_trainable + self.N_STATS, dtype=torch.float32, device=self.device)
         self.grads = self.grads_and_stats[:self.plan.n_trainable]
         self.stats = self.grads_and_stats[self.plan.n_trainable:]
 
