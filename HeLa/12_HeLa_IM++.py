@@ -1,0 +1,12 @@
+"""HeLa IM++ generations (EvalNet-weighted augmentation of the IM pseudo-labels) on MI355X: counterpart of the reference
+driver HeLa/12_HeLa_IM++.py (same loops, schedules, file / model / CSV names); the loop body lives in
+inconsistencymasks_amd/impp_driver.py."""
+import os
+import sys
+
+sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from inconsistencymasks_amd.impp_driver import run_hela  # noqa: E402
+
+if __name__ == "__main__":
+    run_hela(aug=False)

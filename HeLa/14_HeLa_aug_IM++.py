@@ -1,0 +1,12 @@
+"""HeLa AIM++ generations (EvalNet-weighted augmentation of the IM pseudo-labels) on MI355X: counterpart of the reference
+driver HeLa/14_HeLa_aug_IM++.py (same loops, schedules, file / model / CSV names); the loop body lives in
+inconsistencymasks_amd/impp_driver.py."""
+import os
+import sys
+
+sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from inconsistencymasks_amd.impp_driver import run_hela  # noqa: E402
+
+if __name__ == "__main__":
+    run_hela(aug=True)

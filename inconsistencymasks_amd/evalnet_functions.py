@@ -1,0 +1,272 @@
+"""Host-side mirror of the reference's EvalNet call sites for the HeLa IM++ / AIM++ drivers (HeLa/12_HeLa_IM++.py,
+HeLa/14_HeLa_aug_IM++.py): same function names, positional arguments, directory layout, file names and CSV format.
+Ensemble inference + IM, EvalNet inference / training, morphology and augmentation run on the GPU through libimk.so;
+PNG I/O and the CSV bookkeeping stay on the host.  Re-exported by functions.py."""
+import csv
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import im as _im
+from .augment import augment_batch, draw_params
+from .evalnet import EvalNet
+
+
+def _F():
+    from . import functions
+    return functions
+
+
+# ---------------------------------------------------------------------------------------------------
+# training data of the mIoU EvalNet from ensemble IM predictions (functions.py:3881-4006)
+# ---------------------------------------------------------------------------------------------------
+def create_training_data_evalnet_miou_im_hela(models, h, w, c, main_input_path, main_output_path, num_loops, n_min_models=2,
+                                              n_max_models=4, brightness_range_alpha=(0.8, 1.2),
+                                              brightness_range_beta=(-10, 10), max_blur=1, max_noise=10,
+                                              free_rotation=False, seed=None):
+    """Per loop and labelled image: a random sub-ensemble (n_min..n_max models) -> three binary IMs (>=) -> combined IM,
+    randomly eroded / dilated with a kernel from {0, 3, 5} -> blocked brightfield + masks written as
+    `{stem}_aug_{loop}.png`, labels.csv row (name; IoU alive, dead, pos against the ground truth; detection flags).
+
+    Two behaviours of the reference that are kept because they shape EvalNet's inputs:
+      * `final_mask * 255` on the uint8 {0,255} masks wraps to {0,1} (functions.py:3939-3942): the masks are written, and
+        later read by the EvalNet generator, with values 0 / 1;
+      * the randomly augmented copy (functions.py:3983-3990) is overwritten by the plain one under the same name
+        (:3993-3996), so only the plain files exist afterwards -- the augmentation is not computed here.
+    The sub-ensembles of a loop are batched by model subset."""
+    F = _F()
+    rng = random.Random(F.SEED if seed is None else seed)
+    sub = ("brightfield", "alive", "dead", "mod_position")
+    din = {k: os.path.join(main_input_path, k) for k in sub}
+    dout = {k: os.path.join(main_output_path, k) for k in sub}
+    for d in dout.values():
+        os.makedirs(d, exist_ok=True)
+    names = sorted(os.listdir(din["brightfield"]))
+    n_max = min(n_max_models, len(models))
+    n_min = min(n_min_models, n_max)
+    rows = []
+    ensembles = {}
+    with F._pool() as pool:
+        for nl in range(num_loops):
+            plan = []                       # per image: (subset, erode kernel, dilate kernel), drawn in the reference's order
+            for _ in names:
+                n_sel = rng.randint(n_min, n_max)
+                subset = tuple(sorted(rng.sample(range(len(models)), n_sel)))
+                plan.append((subset, rng.choice([0, 3, 5]), rng.choice([0, 3, 5])))
+                rng.random()                # the augment-or-not coin of functions.py:3983
+            loop_rows = {}
+            groups = {}
+            for i, (subset, _, _) in enumerate(plan):
+                groups.setdefault(subset, []).append(i)
+            for subset, idx_all in groups.items():
+                if subset not in ensembles:
+                    ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
+                ens = ensembles[subset]
+                for s in range(0, len(idx_all), F.INFER_BATCH):
+                    idx = idx_all[s:s + F.INFER_BATCH]
+                    rd = lambda k: torch.from_numpy(np.stack(list(pool.map(
+                        lambda i: F.read_png(os.path.join(din[k], names[i]), 1), idx)), 0)).cuda()
+                    bf, gt = rd("brightfield"), torch.cat([rd("alive"), rd("dead"), rd("mod_position")], 3)
+                    r = ens.run(bf, 0.5, True, False, False)
+                    im = r["im"]
+                    ek = torch.tensor([plan[i][1] for i in idx], device="cuda")
+                    dk = torch.tensor([plan[i][2] for i in idx], device="cuda")
+                    for op, ks in (("erode", ek), ("dilate", dk)):     # erode first, then dilate (functions.py:3945-3953)
+                        for k in (3, 5):
+                            sel = torch.nonzero(ks == k).flatten()
+                            if sel.numel():
+                                im[sel] = _im.morph(im[sel].contiguous(), k, op)
+                    masks = r["masks"]
+                    bf = bf.clone()
+                    _im.block_apply(im, bf, masks)
+                    pred = masks > 0
+                    g = gt.permute(0, 3, 1, 2) > 0
+                    inter = (pred & g).sum(dim=(2, 3)).cpu().numpy()
+                    union = (pred | g).sum(dim=(2, 3)).cpu().numpy()
+                    gt_nz = g.sum(dim=(2, 3)).cpu().numpy()
+                    ious = inter / (union + 1e-7)                       # get_IoU_binary, functions.py:1767-1788
+                    det = np.stack([gt_nz[:, 0] >= h * w * 0.01, gt_nz[:, 1] >= h * w * 0.01, gt_nz[:, 2] >= h * w * 0.001], 1)
+                    bf_np = bf.cpu().numpy()
+                    m_np = (masks > 0).to(torch.uint8).cpu().numpy()    # {0,1}: the uint8 wrap of `mask * 255`
+                    jobs = []
+                    for row, i in enumerate(idx):
+                        out_name = f"{names[i][:-4]}_aug_{nl}.png"
+                        loop_rows[i] = (out_name, ious[row, 0], ious[row, 1], ious[row, 2], int(det[row, 0]), int(det[row, 1]),
+                                        int(det[row, 2]))
+                        jobs.append((os.path.join(dout["brightfield"], out_name), bf_np[row, :, :, 0]))
+                        for k, key in enumerate(("alive", "dead", "mod_position")):
+                            jobs.append((os.path.join(dout[key], out_name), m_np[row, k]))
+                    list(pool.map(lambda a: F.write_png(*a), jobs))
+            rows += [loop_rows[i] for i in range(len(names))]
+    with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
+        wr = csv.writer(f, delimiter=";")
+        for row in rows:
+            wr.writerow(row)
+
+
+# ---------------------------------------------------------------------------------------------------
+# EvalNet training (functions.py:4673-4722 with the generator of :4823-4882)
+# ---------------------------------------------------------------------------------------------------
+def _read_labels(main_path, num_classes=3):
+    rows = []
+    with open(os.path.join(main_path, "labels.csv"), encoding="utf-8", newline="") as f:
+        for r in csv.reader(f, delimiter=";"):
+            if r:
+                rows.append((r[0], np.asarray(r[1:1 + 2 * num_classes], dtype=np.float32)))
+    return rows
+
+
+def _load_evalnet_set(main_path, rows, pool):
+    """brightfield (grey) [N,H,W,1], masks alive|dead|mod_position [N,H,W,3] (raw uint8 values), labels [N,6] on the device"""
+    F = _F()
+
+    def one(r):
+        mask_name = r[0]
+        image_name = mask_name.split("___")[0] + ".png" if "___" in mask_name else mask_name   # functions.py:4863-4866
+        bf = F.read_png(os.path.join(main_path, "brightfield", image_name), 1)
+        gt = np.concatenate([F.read_png(os.path.join(main_path, k, mask_name), 1) for k in ("alive", "dead", "mod_position")], 2)
+        return bf, gt
+
+    items = list(pool.map(one, rows))
+    xa = torch.from_numpy(np.stack([i[0] for i in items], 0)).cuda()
+    xb = torch.from_numpy(np.stack([i[1] for i in items], 0)).cuda()
+    y = torch.from_numpy(np.stack([r[1] for r in rows], 0)).cuda()
+    return xa, xb, y
+
+
+def _evaluate_evalnet(model, xa, xb, y, batch_size, steps, k):
+    """model.evaluate(generator, steps): inference-mode forward over `steps` batches -> (total, mse, bce, mae, acc)"""
+    tot = np.zeros(4)
+    for s in range(steps):
+        sl = slice(s * batch_size, (s + 1) * batch_size)
+        out = model.predict_device(xa[sl].contiguous(), xb[sl].contiguous()).double()
+        t = y[sl].double()
+        p_iou, p_det, t_iou, t_det = out[:, :k], out[:, k:], t[:, :k], t[:, k:]
+        pc = p_det.clamp(1e-7, 1 - 1e-7)
+        tot += np.array([float(((p_iou - t_iou) ** 2).mean()), float(-(t_det * pc.log() + (1 - t_det) * (1 - pc).log()).mean()),
+                         float((p_iou - t_iou).abs().mean()), float(((p_det > 0.5).double() == t_det).double().mean())])
+    mse, bce, mae, acc = tot / max(steps, 1)
+    return mse + bce, mse, bce, mae, acc
+
+
+def save_evalnet(model, path):
+    from safetensors.torch import save_file
+    p = model.plan
+    meta = {"net": "evalnet", "h": str(p.h), "w": str(p.w), "ca": str(p.ca), "cb": str(p.cb), "n_out": str(p.n_out),
+            "alpha": repr(p.alpha), "two_heads": str(int(p.two_heads)), "normalize_a": str(p.cfg.normalize_a),
+            "normalize_b": str(p.cfg.normalize_b)}
+    save_file({k: v.contiguous() for k, v in model.state_dict().items()}, path, metadata=meta)
+
+
+def load_evalnet(path, device="cuda"):
+    from safetensors import safe_open
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata()
+        sd = {k: f.get_tensor(k) for k in f.keys()}
+    m = EvalNet(int(meta["h"]), int(meta["w"]), int(meta["ca"]), int(meta["cb"]), int(meta["n_out"]), float(meta["alpha"]),
+                bool(int(meta["two_heads"])), bool(int(meta["normalize_a"])), bool(int(meta["normalize_b"])), device=device)
+    m.load_state_dict(sd)
+    return m
+
+
+def train_evalnet_miou_model_hela(model, train_main_path, val_main_path, filepath_h5, batch_size, epochs, seed=None):
+    """functions.py:4673-4722: AdamW(LR, WD), loss ['mse', 'binary_crossentropy'], best epoch by val_loss (min), then
+    the best model evaluated on the validation generator.  Returns (total_loss, iou_loss, detection_loss, iou_mae,
+    detection_acc).  Every rank of a multi-GPU launch trains the same model from the same seed (the sets are small)."""
+    F = _F()
+    k = model.plan.n_out
+    rng = np.random.default_rng(F.SEED if seed is None else seed)
+    tr_rows, va_rows = _read_labels(train_main_path, k), _read_labels(val_main_path, k)
+    with F._pool() as pool:
+        xa, xb, y = _load_evalnet_set(train_main_path, tr_rows, pool)
+        va, vb, vy = _load_evalnet_set(val_main_path, va_rows, pool)
+    steps, val_steps = len(tr_rows) // batch_size, len(va_rows) // batch_size
+    vperm = torch.as_tensor(rng.permutation(len(va_rows)), device="cuda")   # the validation generator shuffles too
+    va, vb, vy = va[vperm], vb[vperm], vy[vperm]
+    model.init_train_state()
+    best = float("inf")
+    order = []
+    for ep in range(epochs):
+        for _ in range(steps):
+            if not order:      # dataframe.sample(frac=1): a new shuffled pass, one short batch at its end (functions.py:4842-4850)
+                perm = torch.as_tensor(rng.permutation(len(tr_rows)), device="cuda")
+                pa, pb, py = xa[perm], xb[perm], y[perm]
+                order = [(i, min(i + batch_size, len(perm))) for i in range(0, len(perm), batch_size)]
+            lo, hi = order.pop(0)
+            model.fwd_bwd(pa[lo:hi], pb[lo:hi], py[lo:hi])
+            model.adamw_step(F.LR, F.WD)
+        val_loss = _evaluate_evalnet(model, va, vb, vy, batch_size, val_steps, k)[0]
+        if val_loss < best:                       # ModelCheckpoint(monitor='val_loss', mode='min', save_best_only=True)
+            best = val_loss
+            if F._rank_world()[0] == 0:
+                save_evalnet(model, filepath_h5)
+    d = F._dist()
+    if d:
+        d.barrier()
+    best_model = load_evalnet(filepath_h5)
+    return tuple(float(v) for v in _evaluate_evalnet(best_model, va, vb, vy, batch_size, val_steps, k))
+
+
+# ---------------------------------------------------------------------------------------------------
+# EvalNet-weighted augmentation of the pseudo-labelled set (functions.py:5837-5941)
+# ---------------------------------------------------------------------------------------------------
+def num_augs_from_miou(miou, min_threshold, max_threshold):
+    """functions.py:5921-5930"""
+    step = (max_threshold - min_threshold) / 5
+    if miou > max_threshold:
+        n = 5
+    elif miou > min_threshold:
+        n = 1 + int((miou - min_threshold) / step)
+    else:
+        n = 1
+    return min(n, 5)
+
+
+def create_augment_images_and_masks_with_evalnet_ensemble_hela(evalnets, h, w, c, min_threshold, max_threshold,
+                                                               main_input_path, main_output_path,
+                                                               brightness_range_alpha=(0.6, 1.4),
+                                                               brightness_range_beta=(-20, 20), max_blur=3, max_noise=20,
+                                                               free_rotation=True):
+    """Every pseudo-labelled sample gets 1..5 augmented copies `{stem}___{j}.png`, the number growing with the mean
+    IoU the EvalNet ensemble predicts for it (classes whose mean detection score is below 0.5 do not count).
+    EvalNet sees the masks as 0 / 1 here (mask / 255, functions.py:5881-5883)."""
+    F = _F()
+    sub = ("brightfield", "alive", "dead", "mod_position")
+    din = {k: os.path.join(main_input_path, k) for k in sub}
+    dout = {k: os.path.join(main_output_path, k) for k in sub}
+    for d in dout.values():
+        os.makedirs(d, exist_ok=True)
+    mine = F.shard_list(os.listdir(din["brightfield"]))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation)
+    with F._pool() as pool:
+        for s in range(0, len(mine), F.INFER_BATCH):
+            chunk = mine[s:s + F.INFER_BATCH]
+            rd = lambda k: torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(din[k], n), 1), chunk)), 0)).cuda()
+            bf = rd("brightfield")
+            m255 = torch.cat([rd("alive"), rd("dead"), rd("mod_position")], 3)
+            m01 = (m255.float() / 255.0).round().clamp(0, 255).to(torch.uint8)      # what predict() receives: mask / 255
+            outs = torch.stack([e.predict_device(bf, m01) for e in evalnets], 0).double().mean(0).cpu().numpy()
+            k = outs.shape[1] // 2
+            n_augs = []
+            for row in outs:
+                valid = [row[ci] for ci in range(k) if row[k + ci] >= 0.5]
+                n_augs.append(num_augs_from_miou(sum(valid) / len(valid) if valid else 0, min_threshold, max_threshold))
+            n_augs = torch.tensor(n_augs, device="cuda")
+            jobs = []
+            for j in range(5):
+                sel = torch.nonzero(n_augs > j).flatten()
+                if not sel.numel():
+                    break
+                o, om = augment_batch(bf[sel].contiguous(), m255[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                o, om = o.cpu().numpy(), ((om >= 128).to(torch.uint8) * 255).cpu().numpy()   # (mask/255 >= 0.5) * 255
+                for row, i in enumerate(sel.tolist()):
+                    name = f"{chunk[i][:-4]}___{j}.png"
+                    jobs.append((os.path.join(dout["brightfield"], name), o[row, :, :, 0]))
+                    for ci, key in enumerate(("alive", "dead", "mod_position")):
+                        jobs.append((os.path.join(dout[key], name), om[row, :, :, ci]))
+            list(pool.map(lambda a: F.write_png(*a), jobs))
+    if F._dist():
+        F._dist().barrier()

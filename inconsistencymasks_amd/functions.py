@@ -901,3 +901,11 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
         res += list(benchmark_hela(best_model, gt, pd, h, w, c))
     print(f"{modelname} mIoU_val: {res[0]}   mean_cell_count_error_val: {res[2]}")
     return tuple(res)
+
+
+# ---------------------------------------------------------------------------------------------------
+# EvalNet call sites of the IM++ / AIM++ drivers (functions.py:3881-4006, 4673-4722, 5837-5941)
+# ---------------------------------------------------------------------------------------------------
+from .evalnet_functions import (create_augment_images_and_masks_with_evalnet_ensemble_hela,  # noqa: E402,F401
+                                create_training_data_evalnet_miou_im_hela, load_evalnet, num_augs_from_miou, save_evalnet,
+                                train_evalnet_miou_model_hela)

@@ -329,3 +329,61 @@ def test_hela_driver_toy_run(tmp_path):
     im = F.read_png(str(unl / "im" / n), 1)[..., 0] > 0
     for k in ("brightfield", "alive", "dead"):
         assert not F.read_png(str(unl / k / n), 1)[..., 0][im].any()
+
+
+HELA_PP_SETUP_EXTRA = """
+import shutil
+for j in (1, 2):   # the IM++ drivers start from the `HELA_subset_aug_{{runid}}` ensemble (HeLa/14_HeLa_aug_IM++.py:75,180)
+    shutil.copy(os.path.join(paths.HELA_MODEL_DIR, f"HeLa_subset_1_topK_{{j}}.h5"),
+                os.path.join(paths.HELA_MODEL_DIR, f"HELA_subset_aug_1_topK_{{j}}.h5"))
+sample(8, os.path.join(paths.HELA_BASE_DIR, "train_labeled_aug"), "laug")
+"""
+
+
+def test_hela_aug_im_plus_plus_toy_run(tmp_path):
+    """HeLa/14_HeLa_aug_IM++.py on a toy set: EvalNet training data from sub-ensemble IMs (labels.csv, {0,1} masks),
+    EvalNet candidates + top-K by iou_mae, EvalNet-weighted augmentation (1..5 copies `___j`), one U-Net generation."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    extra = "NUM_EPOCHS_EVALNET = 2\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 2\nNUM_LOOPS_VAL = 1\n"
+    text = HELA_CONFIG.format(base=base).replace("TOP_Ks = 2\n", "TOP_Ks = 2\n" + extra)
+    text += "ALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n"
+    cfg.write_text(text)
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_GENS": "0", "IM_CANDIDATES": "0,1",
+           "IM_EVALNET_CANDIDATES": "0,1,2"}
+    subprocess.run([sys.executable, "-c", HELA_SETUP.format(root=ROOT) + HELA_PP_SETUP_EXTRA.format()], env=env, check=True,
+                   cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "HeLa", "14_HeLa_aug_IM++.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    # EvalNet training data: 2 loops x 16 labelled images, label rows = name + 3 IoUs + 3 detection flags
+    ev = base / "evalnet_aug_im" / "run_1"
+    rows = [l.split(";") for l in (ev / "train" / "labels.csv").read_text().strip().splitlines()]
+    assert len(rows) == 32 and all(len(r) == 7 for r in rows)
+    assert all(0.0 <= float(v) <= 1.0 for r in rows for v in r[1:4]) and all(v in ("0", "1") for r in rows for v in r[4:])
+    assert len(os.listdir(ev / "train" / "alive")) == 32 and len(os.listdir(ev / "val" / "alive")) == 8
+    m = F.read_png(str(ev / "train" / "alive" / rows[0][0]), 1)
+    assert set(np.unique(m)) <= {0, 1}                        # the uint8 wrap of `mask * 255` (functions.py:3939)
+    # the cells are larger than 1 % of the image: detection flags of alive/dead present in every sample's GT
+    assert any(r[4] == "1" for r in rows)
+    models = sorted(os.listdir(base / "models"))
+    assert "HELA_evalnet_miou_aug_im_1_topK_1.h5" in models and "HELA_evalnet_miou_aug_im_1_topK_2.h5" in models
+    ev_rows = (base / "csv" / "results_HELA_evalnet_miou_aug_im_1_2.csv").read_text().strip().splitlines()
+    assert ev_rows[0].split(";") == ["modelname", "total_loss", "iou_loss", "detection_loss", "iou_mae", "detection_mae"]
+    assert len(ev_rows) == 4
+    stem = "HELA_aug_IM_plus_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    unl = base / "train_unlabeled_predictions" / "aug_IM_plus_plus" / stem
+    names = os.listdir(unl / "brightfield")
+    n_aug = [n for n in names if "___" in n]
+    per_image = {}
+    for n in n_aug:
+        per_image.setdefault(n.split("___")[0], []).append(int(n.split("___")[1][:-4]))
+    assert len(per_image) == 24 and all(sorted(v) == list(range(len(v))) and 1 <= len(v) <= 5 for v in per_image.values())
+    assert len(names) == len(n_aug) + 24 + 8                  # + the plain IM pseudo-labels + train_labeled_aug
+    for k in ("alive", "dead", "mod_position"):
+        assert sorted(os.listdir(unl / k)) == sorted(names)
+    res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(res) == 3 and len(res[1].split(";")) == 10
