@@ -196,3 +196,59 @@ def test_metrics_from_integer_counts_match_reference_goldens_exactly(golden_dir)
         gt, pr = g[k + "_gt"], g[k + "_pr"]
         pa, iou = E.pa_iou_from_counts(_multi_counts(gt.astype(np.uint8), pr.astype(np.uint8)), gt.size)
         assert pa == float(g[k + "_pa"][0]) and iou == float(g[k + "_iou"][0])
+
+
+@pytest.mark.parametrize("cfg", [(256, 256, 1, 3, 3, 2.0, True), (256, 256, 3, 1, 1, 1.0, False), (64, 128, 1, 3, 3, 0.5, True)])
+def test_evalnet_plan_matches_oracle_layer_table(built_lib, cfg):
+    """evalnet.py:24-73: Keras creation order (tower A, tower B, five trunk blocks, Dense head(s)) and parameter layout"""
+    from inconsistencymasks_amd.evalnet import EvalPlan
+    from oracle import evalnet_oracle as E
+    h, w, ca, cb, k, alpha, two = cfg
+    p = EvalPlan(h, w, ca, cb, k, alpha, two, True, not two)
+    assert (p.n_total, p.n_trainable) == E.count_params(ca, cb, k, alpha, two)
+    table = E.layer_table(ca, cb, k, alpha, two)
+    assert [l["name"] for l in p.layers] == [t[0] for t in table]
+    off = 0
+    for l, t in zip(p.layers, table):
+        assert (l["kind"], l["ksize"], l["cin"], l["cout"]) == ({"conv": 0, "bn": 1}[t[1]], t[2], t[3], t[4])
+        assert l["off_w"] == off
+        off += t[2] * t[2] * t[3] * t[4] + t[4] if l["kind"] == 0 else 2 * t[4]
+    assert off == p.n_trainable
+    assert p.workspace_bytes(8, 1) > p.workspace_bytes(8, 0) > 0 and p.packed_bytes > 0
+
+
+def test_evalnet_param_count_by_hand(built_lib):
+    """get_evalnet_miou(256, 256, 1, 3, alpha=2) (HeLa/14_HeLa_aug_IM++.py:106, config.ini:46), Keras count by hand:
+    towers 10 624 + 10 688, trunk 19 648 + 22 912 + 90 880 + 361 984 + 1 444 864, two Dense(3) heads 2 x 1 539"""
+    from inconsistencymasks_amd.evalnet import EvalPlan
+    assert EvalPlan(256, 256, 1, 3, 3, 2.0, True, True, False).n_total == 1964678
+
+
+def test_evalnet_plan_rejects_bad_config(built_lib):
+    from inconsistencymasks_amd._lib import ImkError
+    from inconsistencymasks_amd.evalnet import EvalPlan
+    with pytest.raises(ImkError):
+        EvalPlan(208, 416, 3, 1, 1, 1.0, False, True, True)      # six poolings need multiples of 64
+    with pytest.raises(ImkError):
+        EvalPlan(256, 256, 3, 9, 9, 1.0, True, True, False)      # more than 4 mask channels: not built
+
+
+def test_evalnet_oracle_losses_and_aug_count():
+    """loss forms of functions.py:4708 (mse + bce on cached logits == clipped-probability bce away from saturation) and the
+    augmentation count rule of functions.py:5921-5930 (known answers by definition)"""
+    torch = pytest.importorskip("torch")
+    from inconsistencymasks_amd.evalnet_functions import num_augs_from_miou
+    from oracle import evalnet_oracle as E
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn((5, 6), generator=g)
+    y = torch.rand((5, 6), generator=g)
+    y[:, 3:] = (y[:, 3:] > 0.5).float()
+    out = torch.sigmoid(logits)
+    total, l0, l1 = E.loss_fn(out, logits, y, True)
+    pc = out[:, 3:].clamp(1e-7, 1 - 1e-7)
+    bce = -(y[:, 3:] * pc.log() + (1 - y[:, 3:]) * (1 - pc).log()).mean()
+    assert abs(float(l1) - float(bce)) < 1e-6 and abs(float(l0) - float(((out[:, :3] - y[:, :3]) ** 2).mean())) < 1e-7
+    assert abs(float(total) - float(l0 + l1)) < 1e-7
+    lo, hi = 0.59, 0.62                                  # config.ini:54-55
+    assert [num_augs_from_miou(v, lo, hi) for v in (0.0, 0.59, 0.5901, 0.597, 0.603, 0.609, 0.615, 0.62, 0.6201, 1.0)] == \
+        [1, 1, 1, 2, 3, 4, 5, 5, 5, 5]
