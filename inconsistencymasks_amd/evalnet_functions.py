@@ -19,6 +19,99 @@ def _F():
     return functions
 
 
+def _draw_plan(rng, n_images, n_models, n_min_models, n_max_models):
+    """per image, in the reference's order of draws (functions.py:3623-3640, 3931-3953): size and members of the
+    sub-ensemble, erode and dilate kernel from {0, 3, 5}, the augment-or-not coin"""
+    n_max = min(n_max_models, n_models)
+    n_min = min(n_min_models, n_max)
+    plan = []
+    for _ in range(n_images):
+        n_sel = rng.randint(n_min, n_max)
+        subset = tuple(sorted(rng.sample(range(n_models), n_sel)))
+        plan.append((subset, rng.choice([0, 3, 5]), rng.choice([0, 3, 5]), rng.random() < 0.5))
+    return plan
+
+
+def _random_morph(im, plan, idx):
+    """erode, then dilate each image's IM with its own kernel (functions.py:3630-3638)"""
+    for op, col in (("erode", 1), ("dilate", 2)):
+        ks = torch.tensor([plan[i][col] for i in idx], device="cuda")
+        for k in (3, 5):
+            sel = torch.nonzero(ks == k).flatten()
+            if sel.numel():
+                im[sel] = _im.morph(im[sel].contiguous(), k, op)
+    return im
+
+
+def _groups(plan):
+    g = {}
+    for i, p in enumerate(plan):
+        g.setdefault(p[0], []).append(i)
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------
+# training data of the binary EvalNet from ensemble IM predictions (functions.py:3572-3670)
+# ---------------------------------------------------------------------------------------------------
+def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_path, main_output_path, num_loops,
+                                           n_min_models=2, n_max_models=4, rgb=True, brightness_range_alpha=(0.6, 1.4),
+                                           brightness_range_beta=(-20, 20), max_blur=3, max_noise=20, free_rotation=False,
+                                           seed=None):
+    """Per loop and labelled image: a random sub-ensemble -> binary IM (>), randomly eroded / dilated -> blocked image +
+    mask, IoU of the blocked mask against the ground truth (rounded to 4 decimals) as the label; half of the samples are
+    written augmented (geometry on image and mask, photometry on the image).  `{stem}_aug_{loop}.png`, labels.csv."""
+    F = _F()
+    if not rgb and c == 3:
+        raise NotImplementedError("rgb=False is not used by any reference script")
+    rng = random.Random(F.SEED if seed is None else seed)
+    np_rng = np.random.default_rng(rng.getrandbits(32))
+    iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
+    os.makedirs(iout, exist_ok=True)
+    os.makedirs(mout, exist_ok=True)
+    names = sorted(os.listdir(images_path))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation, rng=rng, np_rng=np_rng)
+    rows, ensembles = [], {}
+    with F._pool() as pool:
+        for nl in range(num_loops):
+            plan = _draw_plan(rng, len(names), len(models), n_min_models, n_max_models)
+            loop_rows = {}
+            for subset, idx_all in _groups(plan).items():
+                if subset not in ensembles:
+                    ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
+                for s in range(0, len(idx_all), F.INFER_BATCH):
+                    idx = idx_all[s:s + F.INFER_BATCH]
+                    x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
+                    gt = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1), idx)), 0)).cuda()
+                    r = ensembles[subset].run(x, F.THRESHOLD, False, False, False)
+                    im = _random_morph(r["im"], plan, idx)
+                    masks, img = r["masks"], x.clone()
+                    _im.block_apply(im, img, masks)
+                    pred, g = masks[:, 0] > 0, gt[..., 0] > 0
+                    inter = (pred & g).sum(dim=(1, 2)).cpu().numpy()
+                    union = (pred | g).sum(dim=(1, 2)).cpu().numpy()
+                    ious = inter / (union + 1e-7)
+                    mk = masks.permute(0, 2, 3, 1).contiguous()
+                    aug = torch.tensor([plan[i][3] for i in idx], device="cuda")
+                    sel = torch.nonzero(aug).flatten()
+                    if sel.numel():      # functions.py:3657-3658
+                        o, om = augment_batch(img[sel].contiguous(), mk[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                        img[sel], mk[sel] = o, om
+                    img_np, mk_np = img.cpu().numpy(), mk.cpu().numpy()
+                    jobs = []
+                    for row, i in enumerate(idx):
+                        out_name = f"{names[i][:-4]}_aug_{nl}.png"
+                        loop_rows[i] = (out_name, round(float(ious[row]), 4))
+                        jobs.append((os.path.join(iout, out_name), img_np[row]))
+                        jobs.append((os.path.join(mout, out_name), mk_np[row, :, :, 0]))
+                    list(pool.map(lambda a: F.write_png(*a), jobs))
+            rows += [loop_rows[i] for i in range(len(names))]
+    with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
+        wr = csv.writer(f, delimiter=";")
+        for row in rows:
+            wr.writerow(row)
+
+
 # ---------------------------------------------------------------------------------------------------
 # training data of the mIoU EvalNet from ensemble IM predictions (functions.py:3881-4006)
 # ---------------------------------------------------------------------------------------------------
@@ -44,22 +137,13 @@ def create_training_data_evalnet_miou_im_hela(models, h, w, c, main_input_path, 
     for d in dout.values():
         os.makedirs(d, exist_ok=True)
     names = sorted(os.listdir(din["brightfield"]))
-    n_max = min(n_max_models, len(models))
-    n_min = min(n_min_models, n_max)
     rows = []
     ensembles = {}
     with F._pool() as pool:
         for nl in range(num_loops):
-            plan = []                       # per image: (subset, erode kernel, dilate kernel), drawn in the reference's order
-            for _ in names:
-                n_sel = rng.randint(n_min, n_max)
-                subset = tuple(sorted(rng.sample(range(len(models)), n_sel)))
-                plan.append((subset, rng.choice([0, 3, 5]), rng.choice([0, 3, 5])))
-                rng.random()                # the augment-or-not coin of functions.py:3983
+            plan = _draw_plan(rng, len(names), len(models), n_min_models, n_max_models)
             loop_rows = {}
-            groups = {}
-            for i, (subset, _, _) in enumerate(plan):
-                groups.setdefault(subset, []).append(i)
+            groups = _groups(plan)
             for subset, idx_all in groups.items():
                 if subset not in ensembles:
                     ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
@@ -70,14 +154,7 @@ def create_training_data_evalnet_miou_im_hela(models, h, w, c, main_input_path, 
                         lambda i: F.read_png(os.path.join(din[k], names[i]), 1), idx)), 0)).cuda()
                     bf, gt = rd("brightfield"), torch.cat([rd("alive"), rd("dead"), rd("mod_position")], 3)
                     r = ens.run(bf, 0.5, True, False, False)
-                    im = r["im"]
-                    ek = torch.tensor([plan[i][1] for i in idx], device="cuda")
-                    dk = torch.tensor([plan[i][2] for i in idx], device="cuda")
-                    for op, ks in (("erode", ek), ("dilate", dk)):     # erode first, then dilate (functions.py:3945-3953)
-                        for k in (3, 5):
-                            sel = torch.nonzero(ks == k).flatten()
-                            if sel.numel():
-                                im[sel] = _im.morph(im[sel].contiguous(), k, op)
+                    im = _random_morph(r["im"], plan, idx)     # erode first, then dilate (functions.py:3945-3953)
                     masks = r["masks"]
                     bf = bf.clone()
                     _im.block_apply(im, bf, masks)
@@ -171,42 +248,89 @@ def load_evalnet(path, device="cuda"):
     return m
 
 
-def train_evalnet_miou_model_hela(model, train_main_path, val_main_path, filepath_h5, batch_size, epochs, seed=None):
-    """functions.py:4673-4722: AdamW(LR, WD), loss ['mse', 'binary_crossentropy'], best epoch by val_loss (min), then
-    the best model evaluated on the validation generator.  Returns (total_loss, iou_loss, detection_loss, iou_mae,
-    detection_acc).  Every rank of a multi-GPU launch trains the same model from the same seed (the sets are small)."""
+def _fit_evalnet(model, train_set, val_set, filepath_h5, batch_size, epochs, evaluate, monitor, seed):
+    """model.fit(train_generator, validation_data=val_generator, steps_per_epoch=len//batch, validation_steps=len//batch,
+    callbacks=[ModelCheckpoint(save_best_only, monitor, mode='min')]) then load_model + evaluate.  `evaluate(model, set,
+    steps)` returns the metric tuple, `monitor` indexes it.  Every rank of a multi-GPU launch trains the same model from
+    the same seed (the sets are small)."""
     F = _F()
-    k = model.plan.n_out
     rng = np.random.default_rng(F.SEED if seed is None else seed)
-    tr_rows, va_rows = _read_labels(train_main_path, k), _read_labels(val_main_path, k)
-    with F._pool() as pool:
-        xa, xb, y = _load_evalnet_set(train_main_path, tr_rows, pool)
-        va, vb, vy = _load_evalnet_set(val_main_path, va_rows, pool)
-    steps, val_steps = len(tr_rows) // batch_size, len(va_rows) // batch_size
-    vperm = torch.as_tensor(rng.permutation(len(va_rows)), device="cuda")   # the validation generator shuffles too
-    va, vb, vy = va[vperm], vb[vperm], vy[vperm]
+    xa, xb, y = train_set
+    n_train, n_val = xa.shape[0], val_set[0].shape[0]
+    steps, val_steps = n_train // batch_size, n_val // batch_size
+    vperm = torch.as_tensor(rng.permutation(n_val), device="cuda")          # the validation generator shuffles too
+    val_set = tuple(t[vperm] for t in val_set)
     model.init_train_state()
     best = float("inf")
     order = []
     for ep in range(epochs):
         for _ in range(steps):
-            if not order:      # dataframe.sample(frac=1): a new shuffled pass, one short batch at its end (functions.py:4842-4850)
-                perm = torch.as_tensor(rng.permutation(len(tr_rows)), device="cuda")
+            if not order:      # dataframe.sample(frac=1): a new shuffled pass, one short batch at its end (functions.py:4794-4799)
+                perm = torch.as_tensor(rng.permutation(n_train), device="cuda")
                 pa, pb, py = xa[perm], xb[perm], y[perm]
-                order = [(i, min(i + batch_size, len(perm))) for i in range(0, len(perm), batch_size)]
+                order = [(i, min(i + batch_size, n_train)) for i in range(0, n_train, batch_size)]
             lo, hi = order.pop(0)
             model.fwd_bwd(pa[lo:hi], pb[lo:hi], py[lo:hi])
             model.adamw_step(F.LR, F.WD)
-        val_loss = _evaluate_evalnet(model, va, vb, vy, batch_size, val_steps, k)[0]
-        if val_loss < best:                       # ModelCheckpoint(monitor='val_loss', mode='min', save_best_only=True)
-            best = val_loss
+        val = evaluate(model, val_set, val_steps)[monitor]
+        if val < best:
+            best = val
             if F._rank_world()[0] == 0:
                 save_evalnet(model, filepath_h5)
     d = F._dist()
     if d:
         d.barrier()
-    best_model = load_evalnet(filepath_h5)
-    return tuple(float(v) for v in _evaluate_evalnet(best_model, va, vb, vy, batch_size, val_steps, k))
+    return tuple(float(v) for v in evaluate(load_evalnet(filepath_h5), val_set, val_steps))
+
+
+def train_evalnet_miou_model_hela(model, train_main_path, val_main_path, filepath_h5, batch_size, epochs, seed=None):
+    """functions.py:4673-4722: AdamW(LR, WD), loss ['mse', 'binary_crossentropy'], best epoch by val_loss (min), then
+    the best model evaluated on the validation generator.  Returns (total_loss, iou_loss, detection_loss, iou_mae,
+    detection_acc)."""
+    F = _F()
+    k = model.plan.n_out
+    with F._pool() as pool:
+        tr = _load_evalnet_set(train_main_path, _read_labels(train_main_path, k), pool)
+        va = _load_evalnet_set(val_main_path, _read_labels(val_main_path, k), pool)
+    ev = lambda m, st, steps: _evaluate_evalnet(m, st[0], st[1], st[2], batch_size, steps, k)
+    return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 0, seed)
+
+
+def _load_binary_evalnet_set(main_path, pool):
+    """images (RGB) [N,H,W,3], masks (grey) [N,H,W,1], labels [N,1] (functions.py:4778-4820)"""
+    F = _F()
+    rows = []
+    with open(os.path.join(main_path, "labels.csv"), encoding="utf-8", newline="") as f:
+        for r in csv.reader(f, delimiter=";"):
+            if r:
+                rows.append((r[0], float(r[1])))
+
+    def one(r):
+        mask_name = r[0]
+        image_name = mask_name.split("___")[0] + ".png" if "___" in mask_name else mask_name
+        return (F.read_png(os.path.join(main_path, "images", image_name), 3), F.read_png(os.path.join(main_path, "masks", mask_name), 1))
+
+    items = list(pool.map(one, rows))
+    return (torch.from_numpy(np.stack([i[0] for i in items], 0)).cuda(), torch.from_numpy(np.stack([i[1] for i in items], 0)).cuda(),
+            torch.tensor([[r[1]] for r in rows], dtype=torch.float32, device="cuda"))
+
+
+def train_evalnet_ISIC_2018(model, train_main_path, val_main_path, filepath_h5, batch_size, epochs, seed=None):
+    """functions.py:4464-4506: loss 'mean_squared_error', metric 'mean_absolute_error', best epoch by
+    val_mean_absolute_error (min).  Returns (mse, mae) of the best model on the validation generator."""
+    F = _F()
+    with F._pool() as pool:
+        tr, va = _load_binary_evalnet_set(train_main_path, pool), _load_binary_evalnet_set(val_main_path, pool)
+
+    def ev(m, st, steps):
+        tot = np.zeros(2)
+        for s in range(steps):
+            sl = slice(s * batch_size, (s + 1) * batch_size)
+            d = m.predict_device(st[0][sl].contiguous(), st[1][sl].contiguous()).double() - st[2][sl].double()
+            tot += np.array([float((d ** 2).mean()), float(d.abs().mean())])
+        return tuple(tot / max(steps, 1))
+
+    return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 1, seed)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -267,6 +391,46 @@ def create_augment_images_and_masks_with_evalnet_ensemble_hela(evalnets, h, w, c
                     jobs.append((os.path.join(dout["brightfield"], name), o[row, :, :, 0]))
                     for ci, key in enumerate(("alive", "dead", "mod_position")):
                         jobs.append((os.path.join(dout[key], name), om[row, :, :, ci]))
+            list(pool.map(lambda a: F.write_png(*a), jobs))
+    if F._dist():
+        F._dist().barrier()
+
+
+def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w, c, min_threshold, max_threshold,
+                                                                 main_input_path, main_output_path,
+                                                                 brightness_range_alpha=(0.6, 1.4),
+                                                                 brightness_range_beta=(-20, 20), max_blur=3, max_noise=20,
+                                                                 free_rotation=True, rgb=True):
+    """functions.py:5684-5757: 1..5 augmented copies `{stem}___{j}.png` of every pseudo-labelled pair, the number growing
+    with the IoU the EvalNet ensemble predicts for (image, mask)."""
+    F = _F()
+    if not rgb and c == 3:
+        raise NotImplementedError("rgb=False is not used by any reference script")
+    iin, min_ = os.path.join(main_input_path, "images"), os.path.join(main_input_path, "masks")
+    iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
+    os.makedirs(iout, exist_ok=True)
+    os.makedirs(mout, exist_ok=True)
+    mine = F.shard_list(os.listdir(iin))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation)
+    with F._pool() as pool:
+        for s in range(0, len(mine), F.INFER_BATCH):
+            chunk = mine[s:s + F.INFER_BATCH]
+            x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
+            m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
+            mean_iou = torch.stack([e.predict_device(x, m) for e in evalnets], 0).double().mean(0)[:, 0].cpu().numpy()
+            n_augs = torch.tensor([num_augs_from_miou(v, min_threshold, max_threshold) for v in mean_iou], device="cuda")
+            jobs = []
+            for j in range(5):
+                sel = torch.nonzero(n_augs > j).flatten()
+                if not sel.numel():
+                    break
+                o, om = augment_batch(x[sel].contiguous(), m[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                o, om = o.cpu().numpy(), om.cpu().numpy()
+                for row, i in enumerate(sel.tolist()):
+                    name = f"{chunk[i][:-4]}___{j}.png"
+                    jobs.append((os.path.join(iout, name), o[row]))
+                    jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
             list(pool.map(lambda a: F.write_png(*a), jobs))
     if F._dist():
         F._dist().barrier()

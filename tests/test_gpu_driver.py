@@ -387,3 +387,45 @@ def test_hela_aug_im_plus_plus_toy_run(tmp_path):
         assert sorted(os.listdir(unl / k)) == sorted(names)
     res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(res) == 3 and len(res[1].split(";")) == 10
+
+
+def test_isic_im_plus_plus_toy_run(tmp_path):
+    """ISIC_2018/12_ISIC_2018_IM++.py on a toy set: EvalNet training data (half of it augmented, IoU labels rounded to 4
+    decimals), 3 EvalNet candidates ranked by mae, EvalNet-weighted augmentation, one U-Net generation at n = 2."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    extra = "NUM_EPOCHS_EVALNET = 2\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 2\nNUM_LOOPS_VAL = 1\n"
+    text = CONFIG.format(base=base).replace("TOP_Ks = 2\n", "TOP_Ks = 2\n" + extra)
+    text += "FREE_ROTATION = True\nALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n"
+    cfg.write_text(text)
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1",
+           "IM_EVALNET_CANDIDATES": "0,1,2"}
+    subprocess.run([sys.executable, "-c", SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "12_ISIC_2018_IM++.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ev = base / "evalnet_im" / "run_1"
+    rows = [l.split(";") for l in (ev / "train" / "labels.csv").read_text().strip().splitlines()]
+    assert len(rows) == 32 and all(len(r) == 2 and 0.0 <= float(r[1]) <= 1.0 for r in rows)
+    assert all(len(r[1].split(".")[-1]) <= 4 for r in rows)             # round(iou, 4), functions.py:3644
+    assert np.mean([float(r[1]) for r in rows]) > 0.3                    # the toy ensemble segments the lesions
+    assert sorted(os.listdir(ev / "train" / "images")) == sorted(r[0] for r in rows) == sorted(os.listdir(ev / "train" / "masks"))
+    models = sorted(os.listdir(base / "models"))
+    assert "ISIC_2018_evalnet_im_1_topK_1.h5" in models and "ISIC_2018_evalnet_im_1_topK_2.h5" in models
+    ev_rows = (base / "csv" / "results_ISIC_2018_evalnet_im_1_2.csv").read_text().strip().splitlines()
+    assert ev_rows[0] == "modelname;mse;mae" and len(ev_rows) == 4
+    stem = "ISIC_2018_IM_plus_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    unl = base / "train_unlabeled_predictions" / "IM_plus_plus" / stem
+    tmp_imgs = os.listdir(base / "train_unlabeled_predictions" / "IM_plus_plus" / "temp" / stem / "images")
+    names = os.listdir(unl / "images")
+    per_image = {}
+    for n in names:
+        if "___" in n:
+            per_image.setdefault(n.split("___")[0], []).append(int(n.split("___")[1][:-4]))
+    assert sorted(per_image) == sorted(n[:-4] for n in tmp_imgs)         # every kept pseudo-label gets 1..5 copies
+    assert all(sorted(v) == list(range(len(v))) and 1 <= len(v) <= 5 for v in per_image.values())
+    assert len(names) == sum(len(v) for v in per_image.values()) + 16    # + the labelled pairs (12_...IM++.py:221-223)
+    assert sorted(os.listdir(unl / "masks")) == sorted(names)
+    res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(res) == 3 and len(res[1].split(";")) == 7
