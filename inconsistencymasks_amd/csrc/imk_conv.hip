@@ -232,7 +232,7 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 // Channel passes: the K dimension is walked in n_pass passes of nc8p chunks (imk_pass_chunks above), each pass staging
 // its channel slice of the tile and of the packed weights; any width up to 512 channels runs this way.
 // k order = (pass, tap, chunk in pass) -- see pack_conv_batched_kernel.
-struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds; };
+struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp; };
 
 // bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
 // (Measured and dropped for the launches that do not fill the chip -- deep layers at batch 32: staging batches of 6-12
@@ -240,7 +240,7 @@ struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp,
 template <int TH, int MT, int LM>
 __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkConvGeom &gm, int bx, int by) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, mt_total = gm.mt_total, nc8 = gm.nc8, nc8p = gm.nc8p;
-    const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp, w_in_lds = gm.w_in_lds;
+    const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp;
     constexpr int NW = 4, NT = 64 * NW;   // waves / threads per workgroup
     constexpr int P = TH / NW;            // pixel groups (tile rows) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -269,12 +269,11 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[m][p] = f32x4{0, 0, 0, 0};
-    const f16 *wp = a.wpk + (size_t)lane * 8;
     for (int pass = 0; pass < n_pass; ++pass) {
         const int c8_lo = pass * nc8p;
         const int nc8_cur = min(nc8p, nc8 - c8_lo);
         if (pass) __syncthreads();   // everyone is done with the previous pass's tile and weights
-        if (w_in_lds) {
+        {
             // One cooperative copy of this workgroup's weight fragments into LDS: the k-loop then never waits for L2
             // (deep layers have 18-72 k-steps; a global fragment load per k-step costs a full L2 latency each).
             // The copy is asynchronous (global_load_lds_dwordx4: global -> LDS without registers, one contiguous KB per
@@ -346,34 +345,56 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
 
         // ---- MFMA loop over (tap, chunk) of this pass ----------------------------------------------------------
         const int nq = T * nc8p;          // the packing pads every pass to nc8p chunks (zero weights beyond nc8_cur)
-        int q = g;
-        int tap = q / nc8p;
-        int c8 = q - tap * nc8p;
-        int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
-        for (int s = 0; s < nsp; ++s) {
-            const bool vq = (q < nq) && (c8 < nc8_cur);
-            const int off = vq ? ((ty * WT + tx) * ps + c8) * 16 : 0;
-            f16x8 af[MT];
+        int q = g;                        // this lane group's k-slot (tap, chunk) index at the next step to load
+        const int mg_q = (65536 + nc8p - 1) / nc8p;    // q / nc8p as multiply-shift (q < 9 * 4 + 4, nc8p <= IMK_PASS_CAP)
+        // Software-pipelined over the k-steps with two register sets of fragments: the LDS (or L2) reads of step s + 1
+        // are issued before the MFMAs of step s, so their latency runs under the matrix pipe instead of in front of it
+        // (one wave per SIMD and workgroup: nothing else would hide it).  The loop body has no conditional load or MFMA
+        // (see load_frag), so the compiler's wait counts leave exactly the younger set in flight.
+        auto k_loop = [&]() {
+            int sn = 0;     // next k-step to load
+            const f16 *wsrc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int ct = ct0 + m;
-                if (w_in_lds) af[m] = *reinterpret_cast<const f16x8 *>(s_w + ((size_t)(m * nsp + s) * 64 + lane) * 8);
-                else af[m] = (ct < mt_total) ? *reinterpret_cast<const f16x8 *>(wp + ((size_t)ct * ns_total + (size_t)pass * nsp + s) * 512)
-                                             : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                wsrc[m] = s_w + ((size_t)m * nsp * 64 + lane) * 8;
             }
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            auto load_frag = [&](f16x8 (&af)[MT], f16x8 (&bf)[P]) {
+                const int tap = (q * mg_q) >> 16, c8 = q - tap * nc8p;
+                const int ty = ks3 ? (tap * 11) >> 5 : 0, tx = ks3 ? tap - 3 * ty : 0;   // tap / 3 for tap < 16
+                const bool vq = (q < nq) && (c8 < nc8_cur);
+                const int off = vq ? ((ty * WT + tx) * ps + c8) * 16 : 0;     // invalid k-slots: zero weights
+                // steps past the end (the second half of the last pair when nsp is odd, and the look-ahead of the last
+                // iteration) re-read the last step and get a zero weight fragment: no branch, so all MFMAs of the loop
+                // sit in one basic block with one set of accumulators
+                const unsigned live = sn < nsp ? 0xFFFFFFFFu : 0u;
+                const int sc = min(sn, nsp - 1);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);  // invalid k-slots: zero weights
+                for (int m = 0; m < MT; ++m) {
+                    const u32x4 w = *reinterpret_cast<const u32x4 *>(wsrc[m] + (size_t)sc * 512) & live;
+                    af[m] = __builtin_bit_cast(f16x8, w);
+                }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][p], 0, 0, 0);
+                for (int p = 0; p < P; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off);
+                ++sn;
+                q += 4;
+            };
+            auto mma = [&](const f16x8 (&af)[MT], const f16x8 (&bf)[P]) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[p], acc[m][p], 0, 0, 0);
+            };
+            f16x8 a0[MT], b0[P], a1[MT], b1[P];
+            load_frag(a0, b0);
+            for (int s = 0; s < nsp; s += 2) {
+                load_frag(a1, b1);
+                mma(a0, b0);
+                load_frag(a0, b0);
+                mma(a1, b1);
             }
-            q += 4;
-            c8 += 4;
-            while (c8 >= nc8p) {
-                c8 -= nc8p;
-                if (++tx == 3) { tx = 0; ++ty; }
-            }
-        }
+        };
+        k_loop();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -1188,19 +1209,13 @@ static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
     const int n_sp = a.B * tiles_x * tiles_y;
     int mt = mt_total >= 4 ? 4 : (mt_total >= 2 ? 2 : 1);
     while (mt > 1 && n_sp * imk_cdiv(mt_total, mt) < 512) mt >>= 1;
-    // weight fragments (of one pass) through LDS when they fit next to the tile (1 KB per (channel tile, k-step))
-    int w_in_lds = 0;
-    while (true) {
-        const size_t wbytes = (size_t)mt * nsp * 1024;
-        if (wbytes <= 80 * 1024 && lds_base + wbytes <= 150 * 1024) { w_in_lds = 1; lds = lds_base + wbytes; break; }
-        if (mt > 1) { mt >>= 1; continue; }
-        break;
-    }
-    if (nsp * n_pass <= 2) { w_in_lds = 0; lds = lds_base; }   // 1-2 k-steps: nothing to hide
+    // the weight fragments of one pass sit in LDS next to the tile (1 KB per (channel tile, k-step); a pass has at most
+    // 9 k-steps, so this always fits)
+    lds = lds_base + (size_t)mt * nsp * 1024;
     const size_t out_bytes = (size_t)TH * 16 * (mt * 16 + 8) * sizeof(f16);   // the epilogue's output tile reuses the LDS
     if (lds < out_bytes) lds = out_bytes;
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
-    L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, w_in_lds};
+    L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp};
     L.th = TH; L.mt = mt; L.gx = n_sp; L.gy = imk_cdiv(mt_total, mt); L.lds = lds;
     return IMK_OK;
 }
