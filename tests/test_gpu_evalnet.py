@@ -133,3 +133,36 @@ def test_training_reduces_loss():
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5])
     out = m.predict([xa, xb])
     assert out[0].shape == (cfg["b"], cfg["k"]) and out[1].shape == (cfg["b"], cfg["k"])
+
+
+def test_full_size_hela_shape():
+    """config.ini [HELA]: 256 x 256, brightfield + 3 masks, ALPHA_EVALNET = 2, batch 32 (the 32-channel towers run at full
+    resolution on the per-tile conv kernel): finite, deterministic, the training-mode outputs match a second pass, inference is
+    batch-invariant, and a few steps reduce the loss."""
+    from inconsistencymasks_amd.evalnet import get_evalnet_miou
+    m = get_evalnet_miou(256, 256, 1, 3, alpha=2, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    xa = torch.randint(0, 256, (32, 256, 256, 1), dtype=torch.uint8, device="cuda", generator=g)
+    xb = (torch.rand((32, 256, 256, 3), device="cuda", generator=g) > 0.7).to(torch.uint8)
+    y = torch.rand((32, 6), device="cuda", generator=g)
+    y[:, 3:] = (y[:, 3:] > 0.5).float()
+    m.init_train_state()
+    for attempt in range(14):
+        out1 = m.fwd_bwd(xa, xb, y).clone()
+        if float(m.stats[1]) == 0.0:
+            break
+        m.adamw_step(3e-3, 1e-4)           # overflow: skipped, loss scale halved
+    assert float(m.stats[1]) == 0.0 and torch.isfinite(m.grads).all() and torch.isfinite(out1).all()
+    g1, l1 = m.grads.clone(), float(m.stats[0])
+    # the BN moving statistics moved, the weights did not: a second pass gives the same outputs and gradients
+    out2 = m.fwd_bwd(xa, xb, y)
+    assert torch.equal(out1, out2) and torch.equal(g1, m.grads)
+    assert abs(l1 - float(m.stats[4]) - float(m.stats[5])) < 1e-5
+    losses = []
+    for _ in range(12):
+        m.train_step(xa, xb, y, 3e-3, 1e-4)
+        losses.append(float(m.stats[0]))
+    assert np.isfinite(losses).all() and losses[-1] < l1
+    p32 = m.predict_device(xa, xb)
+    p8 = m.predict_device(xa[8:16].contiguous(), xb[8:16].contiguous())
+    assert torch.equal(p32[8:16], p8)
