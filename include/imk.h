@@ -100,11 +100,13 @@ typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory (U-Net and Ev
 /* EvalNet (evalnet.py:24-73), see the section at the end of this file */
 typedef struct imk_evalnet_cfg {
     int h, w;            /* input height / width; multiples of 64 (6 poolings)                         */
-    int ca, cb;          /* channels of input A (image) and input B (mask stack); 1..4 each            */
+    int ca, cb;          /* channels of input A (image) and input B (mask stack); 1..4 each, cb up to 64 with b_onehot */
     int n_out;           /* units per Dense head: 1 (get_evalnet) or inputB_channels (get_evalnet_miou) */
     int two_heads;       /* 0: one sigmoid head (evalnet.py:45); 1: 'iou' + 'detection' (evalnet.py:70-71) */
     int normalize_a, normalize_b;   /* the x/255 Lambda of each input block (evalnet.py:5-6)            */
     int ch[5];           /* int(16a), int(32a), int(64a), int(128a), int(256a)  (evalnet.py:28-41)      */
+    int b_onehot;        /* 1: input B is a class-id map [B,H,W] u8, expanded on the device to the one-hot stack over cb
+                            classes that the reference feeds (functions.py:4978, 5990); no x/255 on it */
 } imk_evalnet_cfg;
 
 int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out);
@@ -226,7 +228,7 @@ int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h,
  * ----------------------------------------------------------------------------------------------
  * Replaces get_evalnet / get_evalnet_miou + model.predict([A, B]) (functions.py:5837-5941 call sites) and the
  * model.fit step of train_evalnet_ISIC_2018 / train_evalnet_miou_model_hela (functions.py:4464-4506, 4673-4722).
- * Two uint8 inputs A [B,H,W,ca] (image) and B [B,H,W,cb] (mask stack); each tower is input_block + conv_block, the
+ * Two uint8 inputs A [B,H,W,ca] (image) and B [B,H,W,cb] (mask stack, or [B,H,W] class ids with b_onehot); each tower is input_block + conv_block, the
  * towers are concatenated, five conv_blocks follow, then GlobalAvgPool2D and the Dense sigmoid head(s).
  * The plan is an imk_unet_plan: imk_unet_param_count / _num_layers / _layer_info / _packed_bytes / _pack_weights /
  * _state_bytes / _state_init / _adamw_step / _plan_destroy apply unchanged.  Layer names: "a.in.c", "a.in.bn", "a.c3",

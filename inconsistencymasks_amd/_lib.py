@@ -16,7 +16,7 @@ class UnetCfg(ctypes.Structure):
 
 class EvalnetCfg(ctypes.Structure):
     _fields_ = [("h", c_int), ("w", c_int), ("ca", c_int), ("cb", c_int), ("n_out", c_int), ("two_heads", c_int),
-                ("normalize_a", c_int), ("normalize_b", c_int), ("ch", c_int * 5)]
+                ("normalize_a", c_int), ("normalize_b", c_int), ("ch", c_int * 5), ("b_onehot", c_int)]
 
 
 class AugParams(ctypes.Structure):

@@ -39,6 +39,7 @@ int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, 
 // Dense gradients) and the batch reduction of the latter
 int imk_launch_concat_pool(const f16 *za, const float *sca, const float *sha, int csa, const f16 *zb, const float *scb,
                            const float *shb, int csb, int B, int Hh, int Wh, f16 *cat, hipStream_t stream);
+int imk_launch_onehot(const uint8_t *cls, long long n_pix, int cs, f16 *out, hipStream_t stream);
 size_t imk_evalnet_head_partial_floats(int B, int n_heads, int K, int C);
 int imk_launch_evalnet_head(const f16 *z, const float *sc, const float *sh, const float *const *w, const float *const *bias,
                             int n_heads, int K, int C, int cs, int B, int H, int W, float *out, const float *y,

@@ -567,6 +567,20 @@ __global__ __launch_bounds__(256) void concat_pool_kernel(const f16 *__restrict_
     *reinterpret_cast<f16x8 *>(cat + (size_t)pix * (csa + csb) + c8 * 8) = o;
 }
 
+// class ids [n_pix] u8 -> fp16 one-hot [n_pix][cs] (what the reference's generator builds on the host, functions.py:4978)
+__global__ __launch_bounds__(256) void onehot_kernel(const uint8_t *__restrict__ cls, long long n_pix, int cs,
+                                                     f16 *__restrict__ out) {
+    const int nc8 = cs / 8;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pix * nc8) return;
+    const long long pix = i / nc8;
+    const int c0 = (int)(i - pix * nc8) * 8, k = cls[pix];
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(c0 + j == k ? 1.0f : 0.0f);
+    *reinterpret_cast<f16x8 *>(out + pix * cs + c0) = o;
+}
+
 // The tail of EvalNet for one sample per workgroup: BatchNorm + MaxPooling2D of the last block (on load), GlobalAvgPool2D,
 // the Dense head(s) with sigmoid (evalnet.py:43-45, 69-71), and in training the losses (head 0: mean squared error, head 1:
 // binary cross-entropy -- functions.py:4708), d(loss * scale)/d(pooled tensor) and the per-sample Dense gradients.
@@ -814,6 +828,13 @@ int imk_launch_concat_pool(const f16 *za, const float *sca, const float *sha, in
                            const float *shb, int csb, int B, int Hh, int Wh, f16 *cat, hipStream_t stream) {
     const long long n = (long long)B * Hh * Wh * ((csa + csb) / 8);
     concat_pool_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(za, sca, sha, csa, zb, scb, shb, csb, B, Hh, Wh, cat);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
+int imk_launch_onehot(const uint8_t *cls, long long n_pix, int cs, f16 *out, hipStream_t stream) {
+    const long long n = n_pix * (cs / 8);
+    onehot_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(cls, n_pix, cs, out);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

@@ -46,7 +46,7 @@ void build_layers(imk_unet_plan *p) {
     for (int s = 0; s < 2; ++s) {
         snprintf(nm, sizeof nm, "%c.in.c", tw[s]);
         const int ic = add_conv(p, nm, 1, cin[s], F, 0);
-        if (!norm[s]) p->layers[ic].flags |= IMK_LF_U8_RAW;
+        if (!norm[s] && !(s == 1 && e.b_onehot)) p->layers[ic].flags |= IMK_LF_U8_RAW;
         snprintf(nm, sizeof nm, "%c.in.bn", tw[s]);
         const int ib = add_bn(p, nm, F, 0, ic);
         snprintf(nm, sizeof nm, "%c.c3", tw[s]);
@@ -55,7 +55,8 @@ void build_layers(imk_unet_plan *p) {
         const int c1 = add_conv(p, nm, 1, F, F, 0);
         snprintf(nm, sizeof nm, "%c.bn", tw[s]);
         add_bn(p, nm, F, 0, c1);
-        set_src(p, ic, LM_U8, s ? IMK_SRC_XB : IMK_SRC_XA);
+        if (s == 1 && e.b_onehot) set_src(p, ic, LM_RAW, IMK_SRC_ONEHOT);   // 1x1 conv over the one-hot stack
+        else set_src(p, ic, LM_U8, s ? IMK_SRC_XB : IMK_SRC_XA);
         set_src(p, c3, LM_AFFINE, ic, ib);
         set_src(p, c1, LM_RAW, c3);
     }
@@ -89,6 +90,7 @@ Ws make_ews(const imk_unet_plan *p, int B, int mode) {
     const size_t px1 = (size_t)B * (e.h / 2) * (e.w / 2);
     const int cat_cs = 2 * imk_pad8(e.ch[0]);
     w.cat = take(px1 * cat_cs * 2);
+    if (e.b_onehot) w.onehot = take((size_t)B * e.h * e.w * imk_pad8(e.cb) * 2);
     w.probs = take((size_t)B * 2 * e.n_out * sizeof(float));   // training: the head's outputs of the batch
     if (mode == 1) {
         w.dcat = take(px1 * cat_cs * 2);
@@ -105,11 +107,14 @@ Ws make_ews(const imk_unet_plan *p, int B, int mode) {
 int run_forward(Ctx &c, const ETopo &t, float *params_rw) {
     int rc;
 #define OK(e) do { rc = (e); if (rc) return rc; } while (0)
+    const imk_evalnet_cfg &e = c.p->ecfg;
+    if (e.b_onehot)
+        OK(imk_launch_onehot(c.x_in[1], (long long)c.B * e.h * e.w, imk_pad8(e.cb), reinterpret_cast<f16 *>(c.base + c.ws.onehot),
+                             c.stream));
     for (int s = 0; s < 2; ++s) {
         OK(run_conv_fwd(c, t.in_c[s], params_rw));
         OK(run_conv_pair(c, t.t_c3[s], t.t_c1[s], params_rw));
     }
-    const imk_evalnet_cfg &e = c.p->ecfg;
     const int csF = imk_pad8(e.ch[0]);
     OK(imk_launch_concat_pool(c.act(t.t_c1[0]), c.bn_scale(t.t_bn[0]), c.bn_shift(t.t_bn[0]), csF, c.act(t.t_c1[1]),
                               c.bn_scale(t.t_bn[1]), c.bn_shift(t.t_bn[1]), csF, c.B, e.h / 2, e.w / 2,
@@ -135,7 +140,7 @@ int run_head(Ctx &c, const ETopo &t, float *out, const float *y, const ImkCtl *c
 bool ecfg_ok(const imk_evalnet_cfg *c) {
     if (!c) return false;
     if (c->h <= 0 || c->w <= 0 || (c->h % 64) || (c->w % 64)) return false;   // six 2x2 poolings without remainders
-    if (c->ca < 1 || c->ca > 4 || c->cb < 1 || c->cb > 4) return false;       // uint8 stems of the pipelined conv kernel
+    if (c->ca < 1 || c->ca > 4 || c->cb < 1 || c->cb > (c->b_onehot ? 64 : 4)) return false;   // uint8 stems of the pipelined conv kernel
     if (c->n_out < 1 || c->n_out > 32) return false;
     for (int i = 0; i < 5; ++i) if (c->ch[i] < 1 || c->ch[i] > 512) return false;
     if (c->ch[0] % 8) return false;   // the towers' channels sit side by side in the concatenated tensor

@@ -1,4 +1,4 @@
-// Internal launch API between the U-Net orchestration (imk_unet.hip) and the kernels.
+// Internal launch API between the network orchestration (imk_net.h, imk_unet.hip, imk_evalnet.hip) and the conv kernels.
 #pragma once
 #include "imk_common.h"
 

@@ -94,6 +94,7 @@ struct Ws {
     size_t probs = 0, dlogit = 0, loss_partial = 0;
     // EvalNet
     size_t cat = 0, dcat = 0;      // concatenated pooled tower outputs [B,H/2,W/2,2F] and their gradient
+    size_t onehot = 0;             // b_onehot: input B as fp16 one-hot [B,H,W,pad8(cb)]
     size_t head_partial = 0;       // train: per-sample Dense gradients and loss terms
     size_t total = 0;
 };
@@ -170,7 +171,8 @@ inline ImkInput conv_input(const Ctx &c, int conv) {
         in.u8_div = (l.flags & IMK_LF_U8_RAW) ? 1.0f : 255.0f;
         return in;
     }
-    in.in = l.src == IMK_SRC_CAT ? reinterpret_cast<const void *>(c.base + c.ws.cat) : c.act(l.src);
+    in.in = l.src == IMK_SRC_CAT ? reinterpret_cast<const void *>(c.base + c.ws.cat)
+          : l.src == IMK_SRC_ONEHOT ? reinterpret_cast<const void *>(c.base + c.ws.onehot) : c.act(l.src);
     if (l.src_bn >= 0) { in.sc = c.bn_scale(l.src_bn); in.sh = c.bn_shift(l.src_bn); }
     if (l.src2 >= 0) { in.in2 = c.act(l.src2); in.sc2 = c.bn_scale(l.src2_bn); in.sh2 = c.bn_shift(l.src2_bn); }
     return in;

@@ -21,7 +21,7 @@ struct ImkLayer {
     int64_t pk_scale;            // bn: fp32 scale[cpad], shift[cpad] for inference (folded moving stats)
     // graph, filled by the network builder
     int src = -1;                // conv: the conv whose output it reads, or IMK_SRC_XA / _XB (the uint8 network inputs) /
-                                 // IMK_SRC_CAT (EvalNet's concatenated towers)
+                                 // IMK_SRC_CAT (EvalNet's concatenated towers) / IMK_SRC_ONEHOT (its one-hot expanded input B)
     int src_bn = -1;             // conv: BatchNorm applied to `src` on load (-1: none)
     int src2 = -1, src2_bn = -1; // conv, LM_UPADD: the skip tensor and its BatchNorm
     int lmode = 0;               // conv: ImkLoadMode
@@ -29,7 +29,7 @@ struct ImkLayer {
     int producer = -1;           // bn: the conv that feeds it
     int flags = 0;               // IMK_LF_*
 };
-enum { IMK_SRC_XA = -2, IMK_SRC_XB = -3, IMK_SRC_CAT = -4 };
+enum { IMK_SRC_XA = -2, IMK_SRC_XB = -3, IMK_SRC_CAT = -4, IMK_SRC_ONEHOT = -5 };
 enum {
     IMK_LF_HEAD = 1,     // the U-Net's output conv: forward in fp32 from the flat parameters (only its dgrad operand is packed)
     IMK_LF_DENSE = 4,    // EvalNet's Dense heads: fp32 only, no packed weights, no workspace

@@ -20,11 +20,12 @@ class EvalPlan(Plan):
 
     _ws_fn = "imk_evalnet_workspace_bytes"
 
-    def __init__(self, h, w, ca, cb, n_out, alpha, two_heads, normalize_a, normalize_b):
+    def __init__(self, h, w, ca, cb, n_out, alpha, two_heads, normalize_a, normalize_b, b_onehot=False):
         ch = [int(v * alpha) for v in (16, 32, 64, 128, 256)]          # evalnet.py:28-41
-        self.cfg = EvalnetCfg(h, w, ca, cb, n_out, int(two_heads), int(normalize_a), int(normalize_b), (ctypes.c_int * 5)(*ch))
+        self.cfg = EvalnetCfg(h, w, ca, cb, n_out, int(two_heads), int(normalize_a), int(normalize_b), (ctypes.c_int * 5)(*ch),
+                              int(b_onehot))
         self.h, self.w, self.ca, self.cb, self.n_out, self.alpha = h, w, ca, cb, n_out, alpha
-        self.two_heads = bool(two_heads)
+        self.two_heads, self.b_onehot = bool(two_heads), bool(b_onehot)
         self._p = ctypes.c_void_p()
         check(lib.imk_evalnet_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._p)), "imk_evalnet_plan_create")
         self._describe()
@@ -33,8 +34,9 @@ class EvalPlan(Plan):
 class EvalNet(UNet):
     N_STATS = 8     # loss, overflow flag, loss scale, step, loss of head 0 (mse), loss of head 1 (bce), 2 spare
 
-    def __init__(self, h, w, ca, cb, n_out, alpha, two_heads, normalize_a=True, normalize_b=True, seed=None, device="cuda"):
-        self._init_from_plan(EvalPlan(h, w, ca, cb, n_out, alpha, two_heads, normalize_a, normalize_b), seed, device,
+    def __init__(self, h, w, ca, cb, n_out, alpha, two_heads, normalize_a=True, normalize_b=True, seed=None, device="cuda",
+                 b_onehot=False):
+        self._init_from_plan(EvalPlan(h, w, ca, cb, n_out, alpha, two_heads, normalize_a, normalize_b, b_onehot), seed, device,
                              dense=("dense", "iou", "detection"))
         self.n_heads = 2 if two_heads else 1
 
@@ -49,8 +51,22 @@ class EvalNet(UNet):
             raise ValueError(f"expected [B,{self.plan.h},{self.plan.w},{c}], got {tuple(t.shape)}")
         return t.to(self.device).contiguous()
 
+    def _as_input_b(self, x):
+        """input B as the kernels take it: the uint8 mask stack [B,H,W,Cb], or with b_onehot the class-id map [B,H,W,1]
+        (a one-hot stack [B,H,W,K], which is what the reference's call sites pass, is folded back to class ids)"""
+        if not self.plan.b_onehot:
+            return self._as_u8(x, self.plan.cb)
+        t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+        if t.dim() == 4 and t.shape[-1] == self.plan.cb and self.plan.cb > 1:
+            t = t.argmax(-1)
+        if t.dim() == 2:
+            t = t[None]
+        if t.dim() == 3:
+            t = t[..., None]
+        return self._as_u8(t, 1)
+
     def predict_device(self, xa_u8, xb_u8):
-        """uint8 device tensors [B,H,W,Ca], [B,H,W,Cb] -> float32 device tensor [B, n_heads*n_out]."""
+        """uint8 device tensors [B,H,W,Ca], [B,H,W,Cb] (b_onehot: class ids [B,H,W,1]) -> float32 [B, n_heads*n_out]."""
         self.ready_for_inference()
         b = xa_u8.shape[0]
         ws = self.workspace(b, 0)
@@ -62,7 +78,7 @@ class EvalNet(UNet):
 
     def predict(self, x, batch_size=32, verbose=0):
         """Keras-like: [A, B] numpy batches in; [B,1] (get_evalnet) or [iou, detection] (get_evalnet_miou) out."""
-        xa, xb = self._as_u8(x[0], self.plan.ca), self._as_u8(x[1], self.plan.cb)
+        xa, xb = self._as_u8(x[0], self.plan.ca), self._as_input_b(x[1])
         outs = [self.predict_device(xa[i:i + batch_size], xb[i:i + batch_size]) for i in range(0, xa.shape[0], batch_size)]
         o = torch.cat(outs, 0).cpu().numpy()
         k = self.plan.n_out
@@ -115,8 +131,13 @@ def get_evalnet(i_height, i_width, inputA_channels, inputB_channels, alpha=2, ac
 
 
 def get_evalnet_miou(i_height, i_width, inputA_channels, inputB_channels, alpha=2, actifu="relu", ksi=3,
-                     kernel_ini="he_normal", normalize_A=True, normalize_B=False, seed=None, device="cuda"):
-    """evalnet.py:49 -- heads 'iou' and 'detection', inputB_channels sigmoid units each."""
+                     kernel_ini="he_normal", normalize_A=True, normalize_B=False, seed=None, device="cuda", onehot_B=None):
+    """evalnet.py:49 -- heads 'iou' and 'detection', inputB_channels sigmoid units each.  onehot_B: input B is the
+    one-hot stack of a class-id map (the multiclass scripts, functions.py:4978); it is then passed as class ids and
+    expanded on the device.  Default: True when inputB_channels > 4 (SUIM: 9 classes), False for mask stacks (HeLa: 3)."""
     _check_defaults(actifu, ksi, kernel_ini)
+    onehot = inputB_channels > 4 if onehot_B is None else bool(onehot_B)
+    if onehot and normalize_B:
+        raise NotImplementedError("a one-hot input is not divided by 255 in any reference script")
     return EvalNet(i_height, i_width, inputA_channels, inputB_channels, inputB_channels, alpha, True, normalize_A,
-                   normalize_B, seed, device)
+                   normalize_B, seed, device, b_onehot=onehot)

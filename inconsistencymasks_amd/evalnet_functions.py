@@ -113,6 +113,112 @@ def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_p
 
 
 # ---------------------------------------------------------------------------------------------------
+# multiclass: label helpers (functions.py:4328-4358, 4400-4459) and training data (functions.py:3773-3877)
+# ---------------------------------------------------------------------------------------------------
+def compute_classwise_IoU(pred, gt, num_classes):
+    """functions.py:4328-4358: IoU per class present in gt, rounded to 4 decimals; class 0 scores 1 as soon as the
+    prediction has a class-0 pixel and gt has none of them (the prefill), else its IoU like the others."""
+    pred, gt = np.asarray(pred), np.asarray(gt)
+    iou_list = [0] * num_classes
+    if (pred == 0).sum() > 0:
+        iou_list[0] = 1
+    for cls in range(num_classes):
+        if cls in gt:
+            inter = np.logical_and(gt == cls, pred == cls).sum()
+            union = np.logical_or(gt == cls, pred == cls).sum()
+            if union > 0:
+                iou_list[cls] = round(inter / union, 4)
+    return iou_list
+
+
+def compute_classwise_detection(mask, num_classes):
+    """functions.py:4400-4421: class present on more than 1 % of the pixels"""
+    mask = np.asarray(mask)
+    return [1 if (mask == cls).sum() > mask.size * 0.01 else 0 for cls in range(num_classes)]
+
+
+def compute_classwise_detection_im(pred_mask, num_classes, gt_class_counts, threshold):
+    """functions.py:4424-4459: class detected if its pixel count in the IM-blocked mask is at least `threshold` of its
+    ground-truth count, or at least 10 % of the image; class 0 as soon as one pixel of it is left."""
+    pred_mask = np.asarray(pred_mask)
+    total = pred_mask.size
+    out = [0] * num_classes
+    for cls in range(num_classes):
+        n = (pred_mask == cls).sum()
+        ratio = 0 if gt_class_counts[cls] == 0 else n / gt_class_counts[cls]
+        if cls == 0 and n > 0:
+            out[cls] = 1
+        elif ratio >= threshold:
+            out[cls] = 1
+        elif n / total >= 0.1:
+            out[cls] = 1
+    return out
+
+
+def create_training_data_evalnet_miou_im_multiclass(models, h, w, c, num_classes, images_path, masks_path, main_output_path,
+                                                    num_loops, n_min_models=2, n_max_models=4, rgb=True,
+                                                    brightness_range_alpha=(0.8, 1.2), brightness_range_beta=(-10, 10),
+                                                    max_blur=1, max_noise=10, free_rotation=False, seed=None):
+    """Per loop and labelled image: a random sub-ensemble -> argmax agreement IM, randomly eroded / dilated -> blocked
+    image + label map; labels = class-wise IoU of the blocked prediction against the ground truth and class-wise
+    detection of the IM-blocked ground truth (threshold 0.3); half of the samples are written augmented."""
+    F = _F()
+    if not rgb and c == 3:
+        raise NotImplementedError("rgb=False is not used by any reference script")
+    rng = random.Random(F.SEED if seed is None else seed)
+    np_rng = np.random.default_rng(rng.getrandbits(32))
+    iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
+    os.makedirs(iout, exist_ok=True)
+    os.makedirs(mout, exist_ok=True)
+    names = sorted(os.listdir(images_path))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation, rng=rng, np_rng=np_rng)
+    rows, ensembles = [], {}
+    with F._pool() as pool:
+        for nl in range(num_loops):
+            plan = _draw_plan(rng, len(names), len(models), n_min_models, n_max_models)
+            loop_rows = {}
+            for subset, idx_all in _groups(plan).items():
+                if subset not in ensembles:
+                    ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
+                for s in range(0, len(idx_all), F.INFER_BATCH):
+                    idx = idx_all[s:s + F.INFER_BATCH]
+                    x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
+                    gts = list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1)[..., 0], idx))
+                    r = ensembles[subset].run(x, F.THRESHOLD, False, False, False)
+                    im = _random_morph(r["im"], plan, idx)
+                    masks, img = r["masks"], x.clone()
+                    _im.block_apply(im, img, masks)
+                    pred_np, im_np = masks[:, 0].cpu().numpy(), im.cpu().numpy()
+                    mk = masks.permute(0, 2, 3, 1).contiguous()
+                    sel = torch.nonzero(torch.tensor([plan[i][3] for i in idx], device="cuda")).flatten()
+                    if sel.numel():      # functions.py:3859-3860
+                        o, om = augment_batch(img[sel].contiguous(), mk[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                        img[sel], mk[sel] = o, om
+                    img_np, mk_np = img.cpu().numpy(), mk.cpu().numpy()
+                    jobs = []
+                    for row, i in enumerate(idx):
+                        gt = gts[row]
+                        ious = compute_classwise_IoU(pred_np[row], gt, num_classes)
+                        counts = np.zeros(num_classes)
+                        bins = np.bincount(gt.ravel(), minlength=num_classes)
+                        counts[:len(bins)] += bins[:num_classes] if len(bins) > num_classes else bins
+                        gt_blocked = gt.copy()
+                        gt_blocked[im_np[row] > 0] = 0
+                        det = compute_classwise_detection_im(gt_blocked, num_classes, counts, 0.3)
+                        out_name = f"{names[i][:-4]}_aug_{nl}.png"
+                        loop_rows[i] = (out_name, *ious, *det)
+                        jobs.append((os.path.join(iout, out_name), img_np[row]))
+                        jobs.append((os.path.join(mout, out_name), mk_np[row, :, :, 0]))
+                    list(pool.map(lambda a: F.write_png(*a), jobs))
+            rows += [loop_rows[i] for i in range(len(names))]
+    with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
+        wr = csv.writer(f, delimiter=";")
+        for row in rows:
+            wr.writerow(row)
+
+
+# ---------------------------------------------------------------------------------------------------
 # training data of the mIoU EvalNet from ensemble IM predictions (functions.py:3881-4006)
 # ---------------------------------------------------------------------------------------------------
 def create_training_data_evalnet_miou_im_hela(models, h, w, c, main_input_path, main_output_path, num_loops, n_min_models=2,
@@ -233,7 +339,7 @@ def save_evalnet(model, path):
     p = model.plan
     meta = {"net": "evalnet", "h": str(p.h), "w": str(p.w), "ca": str(p.ca), "cb": str(p.cb), "n_out": str(p.n_out),
             "alpha": repr(p.alpha), "two_heads": str(int(p.two_heads)), "normalize_a": str(p.cfg.normalize_a),
-            "normalize_b": str(p.cfg.normalize_b)}
+            "normalize_b": str(p.cfg.normalize_b), "b_onehot": str(int(p.b_onehot))}
     save_file({k: v.contiguous() for k, v in model.state_dict().items()}, path, metadata=meta)
 
 
@@ -243,7 +349,8 @@ def load_evalnet(path, device="cuda"):
         meta = f.metadata()
         sd = {k: f.get_tensor(k) for k in f.keys()}
     m = EvalNet(int(meta["h"]), int(meta["w"]), int(meta["ca"]), int(meta["cb"]), int(meta["n_out"]), float(meta["alpha"]),
-                bool(int(meta["two_heads"])), bool(int(meta["normalize_a"])), bool(int(meta["normalize_b"])), device=device)
+                bool(int(meta["two_heads"])), bool(int(meta["normalize_a"])), bool(int(meta["normalize_b"])), device=device,
+                b_onehot=bool(int(meta.get("b_onehot", "0"))))
     m.load_state_dict(sd)
     return m
 
@@ -333,6 +440,35 @@ def train_evalnet_ISIC_2018(model, train_main_path, val_main_path, filepath_h5, 
     return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 1, seed)
 
 
+def _load_multiclass_evalnet_set(main_path, num_classes, pool):
+    """images (RGB) [N,H,W,3], class-id masks [N,H,W,1] (one-hot on the device), labels [N,2K] (functions.py:4940-4984)"""
+    F = _F()
+    rows = _read_labels(main_path, num_classes)
+
+    def one(r):
+        mask_name = r[0]
+        image_name = mask_name.split("___")[0] + ".png" if "___" in mask_name else mask_name
+        return (F.read_png(os.path.join(main_path, "images", image_name), 3), F.read_png(os.path.join(main_path, "masks", mask_name), 1))
+
+    items = list(pool.map(one, rows))
+    return (torch.from_numpy(np.stack([i[0] for i in items], 0)).cuda(), torch.from_numpy(np.stack([i[1] for i in items], 0)).cuda(),
+            torch.from_numpy(np.stack([r[1] for r in rows], 0)).cuda())
+
+
+def train_evalnet_miou_model_multiclass(model, h, w, train_main_path, val_main_path, filepath_h5, batch_size, num_classes, epochs,
+                                        seed=None):
+    """functions.py:4726-4775: like the HeLa variant, masks are label maps fed as one-hot stacks.  Returns (total_loss,
+    iou_loss, detection_loss, iou_mae, detection_acc)."""
+    F = _F()
+    if not model.plan.b_onehot or model.plan.n_out != num_classes:
+        raise ValueError("needs a get_evalnet_miou(..., inputB_channels=num_classes) model with a one-hot input B")
+    with F._pool() as pool:
+        tr = _load_multiclass_evalnet_set(train_main_path, num_classes, pool)
+        va = _load_multiclass_evalnet_set(val_main_path, num_classes, pool)
+    ev = lambda m, st, steps: _evaluate_evalnet(m, st[0], st[1], st[2], batch_size, steps, num_classes)
+    return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 0, seed)
+
+
 # ---------------------------------------------------------------------------------------------------
 # EvalNet-weighted augmentation of the pseudo-labelled set (functions.py:5837-5941)
 # ---------------------------------------------------------------------------------------------------
@@ -420,6 +556,50 @@ def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w,
             m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
             mean_iou = torch.stack([e.predict_device(x, m) for e in evalnets], 0).double().mean(0)[:, 0].cpu().numpy()
             n_augs = torch.tensor([num_augs_from_miou(v, min_threshold, max_threshold) for v in mean_iou], device="cuda")
+            jobs = []
+            for j in range(5):
+                sel = torch.nonzero(n_augs > j).flatten()
+                if not sel.numel():
+                    break
+                o, om = augment_batch(x[sel].contiguous(), m[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                o, om = o.cpu().numpy(), om.cpu().numpy()
+                for row, i in enumerate(sel.tolist()):
+                    name = f"{chunk[i][:-4]}___{j}.png"
+                    jobs.append((os.path.join(iout, name), o[row]))
+                    jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
+            list(pool.map(lambda a: F.write_png(*a), jobs))
+    if F._dist():
+        F._dist().barrier()
+
+
+def create_augment_images_and_masks_with_evalnet_ensemble_multiclass(evalnets, h, w, c, num_classes, min_threshold,
+                                                                     max_threshold, main_input_path, main_output_path,
+                                                                     brightness_range_alpha=(0.6, 1.4),
+                                                                     brightness_range_beta=(-20, 20), max_blur=3,
+                                                                     max_noise=20, free_rotation=False, rgb=True):
+    """functions.py:5946-6035: the number of augmented copies follows the mean predicted IoU over the classes > 0 whose
+    mean detection score is at least 0.5."""
+    F = _F()
+    if not rgb and c == 3:
+        raise NotImplementedError("rgb=False is not used by any reference script")
+    iin, min_ = os.path.join(main_input_path, "images"), os.path.join(main_input_path, "masks")
+    iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
+    os.makedirs(iout, exist_ok=True)
+    os.makedirs(mout, exist_ok=True)
+    mine = F.shard_list(os.listdir(iin))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation)
+    with F._pool() as pool:
+        for s in range(0, len(mine), F.INFER_BATCH):
+            chunk = mine[s:s + F.INFER_BATCH]
+            x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
+            m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
+            outs = torch.stack([e.predict_device(x, m) for e in evalnets], 0).double().mean(0).cpu().numpy()
+            n_augs = []
+            for row in outs:
+                valid = [row[ci] for ci in range(1, num_classes) if row[num_classes + ci] >= 0.5]
+                n_augs.append(num_augs_from_miou(sum(valid) / len(valid) if valid else 0.0, min_threshold, max_threshold))
+            n_augs = torch.tensor(n_augs, device="cuda")
             jobs = []
             for j in range(5):
                 sel = torch.nonzero(n_augs > j).flatten()

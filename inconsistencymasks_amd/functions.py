@@ -907,8 +907,11 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
 # EvalNet call sites of the IM++ / AIM++ drivers (functions.py:3572-3670, 3881-4006, 4464-4506, 4673-4722, 5684-5757,
 # 5837-5941)
 # ---------------------------------------------------------------------------------------------------
-from .evalnet_functions import (create_augment_images_and_masks_with_evalnet_ensemble_binary,  # noqa: E402,F401
+from .evalnet_functions import (compute_classwise_detection, compute_classwise_detection_im,  # noqa: E402,F401
+                                compute_classwise_IoU, create_augment_images_and_masks_with_evalnet_ensemble_binary,
                                 create_augment_images_and_masks_with_evalnet_ensemble_hela,
+                                create_augment_images_and_masks_with_evalnet_ensemble_multiclass,
                                 create_training_data_evalnet_im_binary, create_training_data_evalnet_miou_im_hela,
-                                load_evalnet, num_augs_from_miou, save_evalnet, train_evalnet_ISIC_2018,
-                                train_evalnet_miou_model_hela)
+                                create_training_data_evalnet_miou_im_multiclass, load_evalnet, num_augs_from_miou,
+                                save_evalnet, train_evalnet_ISIC_2018, train_evalnet_miou_model_hela,
+                                train_evalnet_miou_model_multiclass)

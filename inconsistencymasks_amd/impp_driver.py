@@ -1,6 +1,6 @@
 """Generation loop of the IM++ / AIM++ drivers of the reference: ISIC_2018/12_ISIC_2018_IM++.py,
-ISIC_2018/14_ISIC_2018_aug_IM++.py, HeLa/12_HeLa_IM++.py, HeLa/14_HeLa_aug_IM++.py (copies of one template; the `aug`
-variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
+ISIC_2018/14_ISIC_2018_aug_IM++.py, HeLa/12_HeLa_IM++.py, HeLa/14_HeLa_aug_IM++.py, SUIM/13_SUIM_IM++.py (copies of
+one template; the `aug` variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
 on IM predictions of the labelled set (5 candidates, top-K by mean absolute error), then per generation the IM
 pseudo-labels of the unlabeled set get 1..5 augmented copies each, weighted by the IoU the EvalNets predict, and 5 U-Net
 candidates of growing width are trained on them.  Same loops, schedules, model / directory / CSV names.
@@ -14,7 +14,7 @@ import torch
 from . import functions as F
 from . import paths
 from .evalnet import get_evalnet, get_evalnet_miou
-from .im_driver import DATASETS, _ints
+from .im_driver import DATASETS, _ints, default_color_mapping
 from .unet import get_unet
 
 _HELA = dict(   # HeLa/14_HeLa_aug_IM++.py:53-57 (identical in 12_HeLa_IM++.py)
@@ -23,12 +23,16 @@ _HELA = dict(   # HeLa/14_HeLa_aug_IM++.py:53-57 (identical in 12_HeLa_IM++.py)
 _ISIC = dict(   # ISIC_2018/12_ISIC_2018_IM++.py:52-56
     alphas=[0.5, 0.75, 1, 1.25, 1.5], max_blurs=[0, 1, 1, 2, 3], max_noises=[5, 10, 15, 20, 25],
     bra=[(0.9, 1.1), (0.8, 1.2), (0.7, 1.3), (0.6, 1.4), (0.5, 1.5)], brb=[(-5, 5), (-10, 10), (-15, 15), (-20, 20), (-25, 25)])
-SCHEDULE = {"HeLa": _HELA, "ISIC_2018": _ISIC}
+SCHEDULE = {"HeLa": _HELA, "ISIC_2018": _ISIC,
+            "SUIM": dict(_ISIC, alphas=[1, 1.25, 1.5, 1.75, 2])}   # SUIM/13_SUIM_IM++.py:54-58
 
 
 def run(dataset, aug=False, train_new_evalnet=True):
-    hela = dataset == "HeLa"
-    tag = "HELA" if hela else "ISIC_2018"
+    kind = DATASETS[dataset]["kind"]            # isic | hela | multi
+    hela, multi = kind == "hela", kind == "multi"
+    if multi and aug:
+        raise NotImplementedError("SUIM/15_SUIM_aug_IBAs++.py is not built")
+    tag = {"HeLa": "HELA", "ISIC_2018": "ISIC_2018", "SUIM": "SUIM"}[dataset]
     S, D, sch = F.config[tag], F.config["DEFAULT"], SCHEDULE[dataset]
     H, W, C, K = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"]), int(S["NUM_CLASSES"])
     alpha_evalnet = float(S["ALPHA_EVALNET"])
@@ -42,7 +46,7 @@ def run(dataset, aug=False, train_new_evalnet=True):
     free_rot = S["FREE_ROTATION"].lower() == "true"
     approach = "aug_IM_plus_plus" if aug else "IM_plus_plus"
     subset_tag = f"{tag}_subset_aug" if aug else f"{tag}_subset"
-    evalnet_tag = f"{tag}_evalnet_{'miou_' if hela else ''}{'aug_' if aug else ''}im"
+    evalnet_tag = f"{tag}_evalnet_{'miou_' if (hela or multi) else ''}{'aug_' if aug else ''}im"
     P = lambda name: getattr(paths, f"{tag}_{name}")
     base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
     labeled_dir = os.path.join(base, "train_labeled_aug") if aug else P("TRAIN_LABELED_DIR")
@@ -63,6 +67,9 @@ def run(dataset, aug=False, train_new_evalnet=True):
                     if hela:
                         F.create_training_data_evalnet_miou_im_hela(subset_models, H, W, C, P(f"{split}_DIR"),
                                                                     os.path.join(ev_dir, sub), loops)
+                    elif multi:
+                        F.create_training_data_evalnet_miou_im_multiclass(subset_models, H, W, C, K, P(f"{split}_IMAGES_DIR"),
+                                                                          P(f"{split}_MASKS_DIR"), os.path.join(ev_dir, sub), loops)
                     else:
                         F.create_training_data_evalnet_im_binary(subset_models, H, W, C, P(f"{split}_IMAGES_DIR"),
                                                                  P(f"{split}_MASKS_DIR"), os.path.join(ev_dir, sub), loops)
@@ -76,6 +83,10 @@ def run(dataset, aug=False, train_new_evalnet=True):
                     evalnet = get_evalnet_miou(H, W, C, K, alpha_evalnet, seed=7000 * runid + i)
                     res = F.train_evalnet_miou_model_hela(evalnet, os.path.join(ev_dir, "train"), os.path.join(ev_dir, "val"), h5,
                                                           bs_evalnet, ep_evalnet)
+                elif multi:
+                    evalnet = get_evalnet_miou(H, W, C, K, alpha_evalnet, seed=7000 * runid + i, onehot_B=True)
+                    res = F.train_evalnet_miou_model_multiclass(evalnet, H, W, os.path.join(ev_dir, "train"),
+                                                                os.path.join(ev_dir, "val"), h5, bs_evalnet, K, ep_evalnet)
                 else:
                     evalnet = get_evalnet(H, W, C, K, alpha_evalnet, normalize_B=True, seed=7000 * runid + i)
                     res = F.train_evalnet_ISIC_2018(evalnet, os.path.join(ev_dir, "train"), os.path.join(ev_dir, "val"), h5,
@@ -83,7 +94,8 @@ def run(dataset, aug=False, train_new_evalnet=True):
                 rows.append((name,) + tuple(res))
                 del evalnet
             if rank == 0:
-                top = sorted(rows, key=lambda r: r[4 if hela else 2])[:top_k]       # iou_mae / mae, ascending
+                # ascending: HeLa by iou_mae (14_HeLa...:131), SUIM by total_loss (13_SUIM...:129), ISIC by mae (12_ISIC...:124)
+                top = sorted(rows, key=lambda r: r[4 if hela else (1 if multi else 2)])[:top_k]
                 print(top)
                 for i, row in enumerate(top, start=1):
                     os.rename(os.path.join(model_dir, f"{row[0]}.h5"), os.path.join(model_dir, f"{row[0][:-2]}_topK_{i}.h5"))
@@ -91,11 +103,12 @@ def run(dataset, aug=False, train_new_evalnet=True):
                 with open(os.path.join(csv_dir, f"results_{rows[-1][0]}.csv"), "w", encoding="utf-8", newline="") as f:
                     wr = csv.writer(f, delimiter=";")
                     wr.writerow(["modelname", "total_loss", "iou_loss", "detection_loss", "iou_mae", "detection_mae"] if hela
+                                else ["modelname", "total_loss", "iou_loss", "conf_loss", "iou_mae", "conf_mae"] if multi
                                 else ["modelname", "mse", "mae"])
                     wr.writerows(rows)
             barrier()
 
-        for n in _ints("IM_NS", [2] if (hela or aug) else [2, 3, 4]):
+        for n in _ints("IM_NS", [2] if (hela or multi or aug) else [2, 3, 4]):
             for gen in _ints("IM_GENS", [0, 1, 2, 3, 4]):
                 name_of = lambda g: f"{tag}_{approach}_{runid}_n{n}_gen{g}_e{EK}_d{DK}_bi_{BI}_bo_{BO}"
                 modelname = name_of(gen)
@@ -111,14 +124,21 @@ def run(dataset, aug=False, train_new_evalnet=True):
                     if hela:
                         means.append(F.create_pseudo_labels_im_hela(best_models, H, W, C, os.path.join(P(f"{split}_DIR"), "brightfield"),
                                                                     tmp[key], EK, DK, BI, BO))
+                    elif multi:
+                        means.append(F.create_pseudo_labels_im_multiclass(best_models, H, W, C, P(f"{split}_IMAGES_DIR"), tmp[key],
+                                                                          True, EK, DK, BI, BO))
                     else:
                         means.append(F.create_pseudo_labels_im_ISIC_2018(best_models, H, W, C, P(f"{split}_IMAGES_DIR"), tmp[key],
                                                                          True, EK, DK, BI, BO))
                 best_evalnets = [F.load_evalnet(os.path.join(model_dir, f"{evalnet_tag}_{runid}_topK_{j}.h5")) for j in range(1, n + 1)]
-                weighted = (F.create_augment_images_and_masks_with_evalnet_ensemble_hela if hela
-                            else F.create_augment_images_and_masks_with_evalnet_ensemble_binary)
-                weighted(best_evalnets, H, W, C, t_min, t_max, tmp["train_unlabeled"], unl, sch["bra"][gen], sch["brb"][gen],
-                         sch["max_blurs"][gen], sch["max_noises"][gen], free_rot)
+                aug_args = (t_min, t_max, tmp["train_unlabeled"], unl, sch["bra"][gen], sch["brb"][gen], sch["max_blurs"][gen],
+                            sch["max_noises"][gen], free_rot)
+                if hela:
+                    F.create_augment_images_and_masks_with_evalnet_ensemble_hela(best_evalnets, H, W, C, *aug_args)
+                elif multi:
+                    F.create_augment_images_and_masks_with_evalnet_ensemble_multiclass(best_evalnets, H, W, C, K, *aug_args, True)
+                else:
+                    F.create_augment_images_and_masks_with_evalnet_ensemble_binary(best_evalnets, H, W, C, *aug_args)
                 del best_evalnets
                 if rank == 0:   # aug: the plain pseudo-labels + the augmented labelled set; else the labelled set (lines 215-228)
                     for src in ([tmp["train_unlabeled"], labeled_dir] if aug else [labeled_dir]):
@@ -138,6 +158,11 @@ def run(dataset, aug=False, train_new_evalnet=True):
                     if hela:
                         res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
                                            P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
+                    elif multi:
+                        res = F.train_multiclass(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
+                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
+                                                 name_i, h5, model, "categorical_crossentropy", steps, H, W, C, K,
+                                                 default_color_mapping(K), *preds)
                     else:
                         res = F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),

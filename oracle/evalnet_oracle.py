@@ -78,9 +78,17 @@ def init_weights(ca, cb, n_out, alpha, two_heads, seed):
     return w
 
 
+def one_hot(class_ids, num_classes):
+    """functions.py:4978 / 5990: np.stack([(mask == cls) for cls in range(num_classes)], axis=-1), as uint8"""
+    ids = np.asarray(class_ids)
+    ids = ids[..., 0] if ids.ndim == 4 else ids
+    return np.stack([(ids == c) for c in range(num_classes)], axis=-1).astype(np.uint8)
+
+
 def forward(p, xa_u8, xb_u8, two_heads, normalize_a=True, normalize_b=True, training=False, emulate_fp16=False,
             stats_out=None, taps=None, override=None):
-    """xa [B,H,W,Ca], xb [B,H,W,Cb] uint8 -> (outputs [B, n_heads*K] float32, logits)."""
+    """xa [B,H,W,Ca], xb [B,H,W,Cb] uint8 (for the multiclass nets: one_hot(class ids), normalize_b False)
+    -> (outputs [B, n_heads*K] float32, logits)."""
     f16 = emulate_fp16
 
     def tap(name, t):

@@ -19,6 +19,8 @@ What is pinned (SURVEY.md §8 a'):
   writer_isic.npz    create_pseudo_labels_im_ISIC_2018, EK=DK=0           (a8)
   writer_multi.npz   create_pseudo_labels_im_multiclass, EK=DK=0          (a9)
   metrics.npz        get_IoU_binary / dice_score_numpy_binary             (eval helpers)
+  evalnet_labels.npz compute_classwise_IoU / compute_classwise_detection_im / compute_classwise_detection
+                     (functions.py:4328-4358, 4400-4459): the label arithmetic of the multiclass EvalNet training data
   augment.npz        add_noise (functions.py:1463-1478): the only numpy-only piece of the augmentation chain.  The
                      noise field the reference drew is recorded next to its output (numpy's global stream re-seeded),
                      so the add / clip / dtype arithmetic is pinned; the draw itself is not reproducible by design.
@@ -394,12 +396,44 @@ def gen_augment(F):
     print("augment:", len(cases), "cases")
 
 
+def gen_evalnet_labels(F):
+    """the numpy-only label helpers of create_training_data_evalnet_miou_im_multiclass (functions.py:3826-3838)"""
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = []
+    for i, (K, shape) in enumerate([(3, (16, 16)), (9, (32, 48)), (9, (64, 64)), (35, (40, 80)), (9, (24, 24))]):
+        gt = rng.integers(0, K, shape).astype(np.uint8)
+        gt[: shape[0] // 2, : shape[1] // 2] = rng.integers(0, K)                   # a dominant class
+        if i == 4:
+            gt[:] = 4                                                              # single-class ground truth
+        pred = np.where(rng.random(shape) > 0.35, gt, rng.integers(0, K, shape)).astype(np.uint8)
+        im = (rng.random(shape) > 0.8)
+        pred[im] = 0                                                               # blocked by the IM
+        if i == 1:
+            pred[pred == 0] = 1                                                    # no class-0 pixel in the prediction
+        counts = np.zeros(K)
+        bins = np.bincount(gt.ravel(), minlength=K)
+        counts[:len(bins)] += bins
+        gt_blocked = gt.copy()
+        gt_blocked[im] = 0
+        k = f"e{i}"
+        out[k + "_gt"], out[k + "_pred"], out[k + "_im"], out[k + "_K"] = gt, pred, im.astype(np.uint8), np.array([K])
+        out[k + "_iou"] = np.array(F.compute_classwise_IoU(pred, gt, K), np.float64)
+        out[k + "_det_im"] = np.array(F.compute_classwise_detection_im(gt_blocked, K, counts, 0.3), np.int64)
+        out[k + "_det"] = np.array(F.compute_classwise_detection(pred, K), np.int64)
+        cases.append(k)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "evalnet_labels.npz"), **out)
+    print("evalnet_labels:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     F, cv2 = import_reference()
+    only = set(sys.argv[1:])          # e.g. `make_golden.py evalnet_labels` regenerates one file
+    gens = [("binary", lambda: gen_binary(F)), ("hela", lambda: gen_hela(F)), ("multiclass", lambda: gen_multiclass(F)),
+            ("writers", lambda: gen_writers(F, cv2)), ("metrics", lambda: gen_metrics(F)), ("augment", lambda: gen_augment(F)),
+            ("evalnet_labels", lambda: gen_evalnet_labels(F))]
     with np.errstate(all="ignore"):
-        gen_binary(F)
-        gen_hela(F)
-        gen_multiclass(F)
-        gen_writers(F, cv2)
-        gen_metrics(F)
-        gen_augment(F)
+        for name, fn in gens:
+            if not only or name in only:
+                fn()

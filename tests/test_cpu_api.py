@@ -252,3 +252,22 @@ def test_evalnet_oracle_losses_and_aug_count():
     lo, hi = 0.59, 0.62                                  # config.ini:54-55
     assert [num_augs_from_miou(v, lo, hi) for v in (0.0, 0.59, 0.5901, 0.597, 0.603, 0.609, 0.615, 0.62, 0.6201, 1.0)] == \
         [1, 1, 1, 2, 3, 4, 5, 5, 5, 5]
+
+
+def test_classwise_label_helpers_golden(golden_dir):
+    """compute_classwise_IoU / compute_classwise_detection_im / compute_classwise_detection (functions.py:4328-4459): the label
+    arithmetic of the multiclass EvalNet training data, bit-identical to the reference's own outputs"""
+    from inconsistencymasks_amd import evalnet_functions as EF
+    g = np.load(os.path.join(golden_dir, "evalnet_labels.npz"))
+    assert len(g["cases"]) == 5
+    for k in g["cases"]:
+        K = int(g[k + "_K"][0])
+        gt, pred, im = g[k + "_gt"], g[k + "_pred"], g[k + "_im"] > 0
+        assert np.array_equal(np.array(EF.compute_classwise_IoU(pred, gt, K), np.float64), g[k + "_iou"]), k
+        counts = np.zeros(K)
+        bins = np.bincount(gt.ravel(), minlength=K)
+        counts[:len(bins)] += bins
+        blocked = gt.copy()
+        blocked[im] = 0
+        assert np.array_equal(np.array(EF.compute_classwise_detection_im(blocked, K, counts, 0.3)), g[k + "_det_im"]), k
+        assert np.array_equal(np.array(EF.compute_classwise_detection(pred, K)), g[k + "_det"]), k

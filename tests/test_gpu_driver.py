@@ -429,3 +429,45 @@ def test_isic_im_plus_plus_toy_run(tmp_path):
     assert sorted(os.listdir(unl / "masks")) == sorted(names)
     res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(res) == 3 and len(res[1].split(";")) == 7
+
+
+def test_suim_im_plus_plus_toy_run(tmp_path):
+    """SUIM/13_SUIM_IM++.py on a 3-class toy set: the EvalNet takes the label map as a one-hot stack; label rows = name +
+    K class-wise IoUs + K detection flags; EvalNet candidates ranked by total loss."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    extra = "NUM_EPOCHS_EVALNET = 2\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 2\nNUM_LOOPS_VAL = 1\n"
+    text = MULTI_CONFIG.format(base=base).replace("TOP_Ks = 2\n", "TOP_Ks = 2\n" + extra)
+    text += "ALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n"
+    cfg.write_text(text)
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_GENS": "0", "IM_CANDIDATES": "0,1",
+           "IM_EVALNET_CANDIDATES": "0,1,2"}
+    subprocess.run([sys.executable, "-c", MULTI_SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "SUIM", "13_SUIM_IM++.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ev = base / "evalnet_im" / "run_1"
+    rows = [l.split(";") for l in (ev / "train" / "labels.csv").read_text().strip().splitlines()]
+    assert len(rows) == 32 and all(len(r) == 1 + 2 * 3 for r in rows)
+    assert all(0.0 <= float(v) <= 1.0 for r in rows for v in r[1:4]) and all(v in ("0", "1") for r in rows for v in r[4:])
+    assert np.mean([float(r[3]) for r in rows]) > 0.3                   # the toy ensemble finds the "object" class
+    models = sorted(os.listdir(base / "models"))
+    assert "SUIM_evalnet_miou_im_1_topK_1.h5" in models and "SUIM_evalnet_miou_im_1_topK_2.h5" in models
+    ev_rows = (base / "csv" / "results_SUIM_evalnet_miou_im_1_2.csv").read_text().strip().splitlines()
+    assert ev_rows[0] == "modelname;total_loss;iou_loss;conf_loss;iou_mae;conf_mae" and len(ev_rows) == 4
+    stem = "SUIM_IM_plus_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    unl = base / "train_unlabeled_predictions" / "IM_plus_plus" / stem
+    names = os.listdir(unl / "images")
+    per_image = {}
+    for n in names:
+        if "___" in n:
+            per_image.setdefault(n.split("___")[0], []).append(int(n.split("___")[1][:-4]))
+    assert len(per_image) == 24 and all(sorted(v) == list(range(len(v))) and 1 <= len(v) <= 5 for v in per_image.values())
+    assert len(names) == sum(len(v) for v in per_image.values()) + 16
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    m = F.read_png(str(unl / "masks" / [n for n in names if "___" in n][0]), 1)
+    assert set(np.unique(m)) <= {0, 1, 2}
+    res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(res) == 3 and len(res[1].split(";")) == 7

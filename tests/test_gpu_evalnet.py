@@ -17,12 +17,15 @@ CFGS = {
     "isic": dict(h=64, w=64, ca=3, cb=1, k=1, alpha=1.0, two=False, na=True, nb=True, b=4),      # get_evalnet, config.ini:24
     "hela": dict(h=64, w=128, ca=1, cb=3, k=3, alpha=0.5, two=True, na=True, nb=False, b=3),     # get_evalnet_miou
     "alpha2": dict(h=64, w=64, ca=1, cb=3, k=3, alpha=2.0, two=True, na=True, nb=False, b=2),    # HeLa ALPHA_EVALNET = 2
+    # SUIM: input B is the one-hot stack of a 9-class label map (functions.py:4978), passed as class ids
+    "suim": dict(h=64, w=64, ca=3, cb=9, k=9, alpha=1.0, two=True, na=True, nb=False, b=3, onehot=True),
 }
 
 
 def make(cfg, seed):
     from inconsistencymasks_amd.evalnet import EvalNet
-    m = EvalNet(cfg["h"], cfg["w"], cfg["ca"], cfg["cb"], cfg["k"], cfg["alpha"], cfg["two"], cfg["na"], cfg["nb"], seed=seed)
+    m = EvalNet(cfg["h"], cfg["w"], cfg["ca"], cfg["cb"], cfg["k"], cfg["alpha"], cfg["two"], cfg["na"], cfg["nb"], seed=seed,
+                b_onehot=cfg.get("onehot", False))
     sd = randomize_bn(m.state_dict(), seed + 1)
     m.load_state_dict(sd)
     rng = np.random.default_rng(seed + 2)
@@ -30,11 +33,19 @@ def make(cfg, seed):
     yy, xx = np.mgrid[0:h, 0:w]
     xa = (127 + 80 * np.sin(xx / 7.0)[None, :, :, None] * np.cos(yy / 5.0)[None, :, :, None]
           + rng.integers(-30, 30, (b, h, w, cfg["ca"]))).clip(0, 255).astype(np.uint8)
-    xb = ((rng.random((b, h // 8, w // 8, cfg["cb"])) > 0.6).astype(np.uint8) * 255).repeat(8, 1).repeat(8, 2)
+    if cfg.get("onehot"):
+        xb = rng.integers(0, cfg["cb"], (b, h // 8, w // 8, 1)).astype(np.uint8).repeat(8, 1).repeat(8, 2)
+    else:
+        xb = ((rng.random((b, h // 8, w // 8, cfg["cb"])) > 0.6).astype(np.uint8) * 255).repeat(8, 1).repeat(8, 2)
     y = rng.random((b, (2 if cfg["two"] else 1) * cfg["k"])).astype(np.float32)
     if cfg["two"]:
         y[:, cfg["k"]:] = (y[:, cfg["k"]:] > 0.5)
     return m, sd, xa, xb, y
+
+
+def ob(cfg, xb):
+    """input B as the oracle takes it"""
+    return E.one_hot(xb, cfg["cb"]) if cfg.get("onehot") else xb
 
 
 def test_param_count_and_order():
@@ -57,11 +68,14 @@ def test_inference_parity(name):
     finally:
         lib.imk_debug_materialize(0)
     taps = {}
-    ref, _ = E.forward(sd, xa, xb, cfg["two"], cfg["na"], cfg["nb"], emulate_fp16=True, taps=taps)
+    ref, _ = E.forward(sd, xa, ob(cfg, xb), cfg["two"], cfg["na"], cfg["nb"], emulate_fp16=True, taps=taps)
     for n, t in taps.items():
         assert rel_l2(m.intermediate(n, cfg["b"], 0).numpy(), t.numpy()) <= 1e-2, n
     got = np.concatenate(out, 1) if cfg["two"] else out
     assert np.abs(got - ref.numpy()).max() <= 2e-2
+    if cfg.get("onehot"):    # the reference's call sites pass the one-hot stack itself: same result
+        oh = m.predict([xa, E.one_hot(xb, cfg["cb"])])
+        assert np.array_equal(np.concatenate(oh, 1), got)
     # batch invariance of inference
     one = m.predict([xa[:1], xb[:1]])
     one = np.concatenate(one, 1) if cfg["two"] else one
@@ -93,10 +107,10 @@ def test_train_pass_parity(name):
     dense = ("dense", "iou", "detection")
     ov = {l["name"]: m.intermediate(l["name"], cfg["b"], 1) for l in m.plan.layers if l["kind"] == 0 and l["name"] not in dense}
     taps = {}
-    E.forward(sd, xa, xb, cfg["two"], cfg["na"], cfg["nb"], training=True, emulate_fp16=True, taps=taps)
+    E.forward(sd, xa, ob(cfg, xb), cfg["two"], cfg["na"], cfg["nb"], training=True, emulate_fp16=True, taps=taps)
     for n, t in taps.items():
         assert rel_l2(ov[n].numpy(), t.numpy()) <= 3e-2, n
-    losses, out_ref, grads_ref, bstats = E.grads(sd, xa, xb, y, cfg["two"], cfg["na"], cfg["nb"], emulate_fp16=True,
+    losses, out_ref, grads_ref, bstats = E.grads(sd, xa, ob(cfg, xb), y, cfg["two"], cfg["na"], cfg["nb"], emulate_fp16=True,
                                                  loss_scale=float(stats[2]), override=ov)
     assert np.abs(out.cpu().numpy() - out_ref.numpy()).max() <= 2e-3
     assert abs(stats[0] - losses[0]) <= 1e-3 * max(1.0, abs(losses[0]))
