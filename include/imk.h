@@ -99,7 +99,7 @@ typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory (U-Net and Ev
 
 /* EvalNet (evalnet.py:24-73), see the section at the end of this file */
 typedef struct imk_evalnet_cfg {
-    int h, w;            /* input height / width; multiples of 64 (6 poolings)                         */
+    int h, w;            /* input height / width: even, >= 64 (6 poolings; odd rows / columns are dropped like Keras does) */
     int ca, cb;          /* channels of input A (image) and input B (mask stack); 1..4 each, cb up to 64 with b_onehot */
     int n_out;           /* units per Dense head: 1 (get_evalnet) or inputB_channels (get_evalnet_miou) */
     int two_heads;       /* 0: one sigmoid head (evalnet.py:45); 1: 'iou' + 'detection' (evalnet.py:70-71) */

@@ -98,7 +98,7 @@ __device__ __forceinline__ f16x8 load_chunk(const ImkInput &in, int b, int y, in
             return affine8(*(const f16x8 *)p, s_aff + c8 * 8, s_aff + cs + c8 * 8);
         }
         case LM_POOL: {
-            const int H2 = 2 * H, W2 = 2 * W;
+            const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
             const f16 *p = (const f16 *)in.in + ((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
             const f16x8 z00 = *(const f16x8 *)p, z01 = *(const f16x8 *)(p + cs);
             const f16x8 z10 = *(const f16x8 *)(p + (size_t)W2 * cs), z11 = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
@@ -165,8 +165,8 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
     if constexpr (LM == LM_RAW || LM == LM_AFFINE) {
         r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
     } else if constexpr (LM == LM_POOL) {
-        const int W2 = 2 * W;
-        const f16 *p = (const f16 *)in.in + ((size_t)(b * 2 * H + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
+        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
+        const f16 *p = (const f16 *)in.in + ((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
         r.v[0] = *(const f16x8 *)p;
         r.v[1] = *(const f16x8 *)(p + cs);
         r.v[2] = *(const f16x8 *)(p + (size_t)W2 * cs);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
         for (unsigned pix0 = blockIdx.x * slots + slot; pix0 < n_pix; pix0 += UB * pix_stride) {
             f16x8 zz[UB], d0[UB], d1[UB], w1[UB], w2[UB], w3[UB];
             unsigned xs[UB], ys[UB];
-            bool ok[UB];
+            bool ok[UB], inwin[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const unsigned pix = pix0 + u * pix_stride;
@@ -156,11 +156,15 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
                     xs[u] = x; ys[u] = y;
                     if (MODE == 1) {
                         const int Hh = a.H / 2, Wh = a.W / 2;
-                        d1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + ((size_t)(b * Hh + (y >> 1)) * Wh + (x >> 1)) * a.go_cs + c8 * 8);
+                        // an odd last row / column belongs to no window (MaxPooling2D 'valid'): its loads are clamped
+                        // into the last window and its pooled gradient dropped below (inwin)
+                        const unsigned yh = min(y >> 1, (unsigned)Hh - 1), xh = min(x >> 1, (unsigned)Wh - 1);
+                        inwin[u] = (y >> 1) < (unsigned)Hh && (x >> 1) < (unsigned)Wh;
+                        d1[u] = *reinterpret_cast<const f16x8 *>(a.g_other + ((size_t)(b * Hh + yh) * Wh + xh) * a.go_cs + c8 * 8);
                         d0[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                         if (a.g_direct) d0[u] = *reinterpret_cast<const f16x8 *>(a.g_direct + it * 8);
                         // the other three elements of the 2x2 pooling window (row-major order kept below)
-                        const size_t w00 = (((size_t)(b * a.H + (y & ~1u)) * a.W + (x & ~1u)) * nc8 + c8) * 8;
+                        const size_t w00 = (((size_t)(b * a.H + 2 * yh) * a.W + 2 * xh) * nc8 + c8) * 8;
                         const int me = (y & 1) * 2 + (x & 1);
                         const size_t o1 = (size_t)a.cs, o2 = (size_t)a.W * a.cs;
                         const int e0 = 0 < me ? 0 : 1, e1 = 1 < me ? 1 : 2, e2 = 2 < me ? 2 : 3;   // window indices != me
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
                             const int e = k < me ? k : k + 1;           // window index of the k-th "other" element
                             win = win && (e < me ? (vm > o[k]) : (vm >= o[k]));
                         }
-                        dy[j] = (f16)((float)d0[u][j] + (win ? (float)d1[u][j] : 0.f));
+                        dy[j] = (f16)((float)d0[u][j] + ((win && inwin[u]) ? (float)d1[u][j] : 0.f));
                     }
                     *reinterpret_cast<f16x8 *>(a.dy_out + it * 8) = dy;
                 } else {
@@ -652,10 +656,13 @@ __global__ __launch_bounds__(256) void evalnet_head_kernel(EvalHeadArgs a) {
     if (!train) return;
     __syncthreads();
     float *part = a.partial + (size_t)b * ((size_t)NO * (a.C + 1) + 2);
-    if (t < 64) {   // loss terms of this sample (NO <= 64 outputs sit in the first wave)
+    __shared__ float s_l[2][2];   // loss terms of this sample: NO <= 128 outputs sit in the first two waves
+    if (t < 128) {
         const float l0 = wave_sum<64>(loss_h[0]), l1 = wave_sum<64>(loss_h[1]);
-        if (t == 0) { part[(size_t)NO * (a.C + 1)] = l0; part[(size_t)NO * (a.C + 1) + 1] = l1; }
+        if ((t & 63) == 0) { s_l[t >> 6][0] = l0; s_l[t >> 6][1] = l1; }
     }
+    __syncthreads();
+    if (t == 0) { part[(size_t)NO * (a.C + 1)] = s_l[0][0] + s_l[1][0]; part[(size_t)NO * (a.C + 1) + 1] = s_l[0][1] + s_l[1][1]; }
     // per-sample Dense gradients dW[o][c] = dlogit[o] * feat[c], db[o] = dlogit[o]
     for (int i = t; i < NO * a.C; i += 256) { const int o = i / a.C, c = i - o * a.C; part[i] = s_o[o] * s_f[c]; }
     if (t < NO) part[(size_t)NO * a.C + t] = s_o[t];
@@ -844,10 +851,10 @@ size_t imk_evalnet_head_partial_floats(int B, int n_heads, int K, int C) { retur
 int imk_launch_evalnet_head(const f16 *z, const float *sc, const float *sh, const float *const *w, const float *const *bias,
                             int n_heads, int K, int C, int cs, int B, int H, int W, float *out, const float *y,
                             const ImkCtl *ctl, float *stats, f16 *dP, float *partial, hipStream_t stream) {
-    if (n_heads < 1 || n_heads > 2 || n_heads * K > 64 || (H & 1) || (W & 1)) return IMK_EUNSUPPORTED;
+    if (n_heads < 1 || n_heads > 2 || n_heads * K > 128 || H < 2 || W < 2) return IMK_EUNSUPPORTED;
     EvalHeadArgs a{z, sc, sh, {w[0], n_heads > 1 ? w[1] : nullptr}, {bias[0], n_heads > 1 ? bias[1] : nullptr},
                    n_heads, K, C, cs, B, H, W, out, y, ctl, stats, dP, partial};
-    evalnet_head_kernel<<<B, 256, (size_t)(cs + 64) * sizeof(float), stream>>>(a);
+    evalnet_head_kernel<<<B, 256, (size_t)(cs + 128) * sizeof(float), stream>>>(a);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

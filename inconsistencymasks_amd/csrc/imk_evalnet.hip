@@ -139,9 +139,11 @@ int run_head(Ctx &c, const ETopo &t, float *out, const float *y, const ImkCtl *c
 
 bool ecfg_ok(const imk_evalnet_cfg *c) {
     if (!c) return false;
-    if (c->h <= 0 || c->w <= 0 || (c->h % 64) || (c->w % 64)) return false;   // six 2x2 poolings without remainders
+    // six 2x2 poolings; sizes that are not multiples of 64 lose odd last rows / columns like Keras' 'valid' pooling
+    // (208 x 416: 13 -> 6 -> 3).  Full resolution itself must be even (the towers' pooled outputs are concatenated).
+    if (c->h < 64 || c->w < 64 || (c->h % 2) || (c->w % 2)) return false;
     if (c->ca < 1 || c->ca > 4 || c->cb < 1 || c->cb > (c->b_onehot ? 64 : 4)) return false;   // uint8 stems of the pipelined conv kernel
-    if (c->n_out < 1 || c->n_out > 32) return false;
+    if (c->n_out < 1 || c->n_out > 64) return false;
     for (int i = 0; i < 5; ++i) if (c->ch[i] < 1 || c->ch[i] > 512) return false;
     if (c->ch[0] % 8) return false;   // the towers' channels sit side by side in the concatenated tensor
     return true;

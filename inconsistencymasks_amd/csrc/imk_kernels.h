@@ -6,7 +6,7 @@
 enum ImkLoadMode {
     LM_RAW = 0,     // fp16 [B,H,W,cs] as is
     LM_AFFINE = 1,  // fp16(z*sc + sh)                                   (BN on load)
-    LM_POOL = 2,    // 2x2 max of fp16(z*sc + sh), z at [B,2H,2W,cs]     (BN + MaxPooling2D, unet.py:16-17)
+    LM_POOL = 2,    // 2x2 max of fp16(z*sc + sh), z at [B,src_h,src_w,cs] (BN + MaxPooling2D, unet.py:16-17)
     LM_UPADD = 3,   // fp16( fp16(zlo*sc+sh)[y/2,x/2] + fp16(zsk*sc2+sh2) )  (UpSampling2D + add, unet.py:32-33)
     LM_U8 = 4,      // fp16(u8/u8_div), [B,H,W,cin] bytes                (Lambda x/255, unet.py:5)
     LM_BNBWD = 5,   // (A*dy + B*z + C) * [z > 0]: BatchNorm backward + ReLU backward applied on load;
@@ -26,6 +26,8 @@ struct ImkInput {
     int lmode;
     int cin, cs_in;        // logical / padded-to-8 channel count (LM_U8: cs_in = 8)
     float u8_div;          // LM_U8: 255 (Lambda x/255, unet.py:5) or 1 (evalnet.py:5, normalize=False)
+    int src_h, src_w;      // LM_POOL: size of the tensor that is pooled (0: 2H x 2W); 2H + 1 / 2W + 1 when MaxPooling2D dropped
+                           // an odd last row / column (Keras 'valid' pooling: EvalNet at sizes that are not multiples of 64)
 };
 
 struct ImkConvArgs {

@@ -174,6 +174,7 @@ inline ImkInput conv_input(const Ctx &c, int conv) {
     in.in = l.src == IMK_SRC_CAT ? reinterpret_cast<const void *>(c.base + c.ws.cat)
           : l.src == IMK_SRC_ONEHOT ? reinterpret_cast<const void *>(c.base + c.ws.onehot) : c.act(l.src);
     if (l.src_bn >= 0) { in.sc = c.bn_scale(l.src_bn); in.sh = c.bn_shift(l.src_bn); }
+    if (l.lmode == LM_POOL) { const Dim ds = res_dim(c.p->cfg, c.p->layers[l.src].res); in.src_h = ds.h; in.src_w = ds.w; }
     if (l.src2 >= 0) { in.in2 = c.act(l.src2); in.sc2 = c.bn_scale(l.src2_bn); in.sh2 = c.bn_shift(l.src2_bn); }
     return in;
 }

@@ -86,7 +86,7 @@ def run(dataset, approach="IM"):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         torch.distributed.init_process_group("nccl")
     rank, world = F._rank_world()
-    tag = dataset if dataset != "ISIC_2018" else "ISIC_2018"
+    tag = {"HeLa": "HELA", "Cityscapes": "CITYSCAPES"}.get(dataset, dataset)   # name prefix of models / CSVs (HeLa/09_HeLa_IM.py:61)
 
     for runid in _ints("IM_RUNIDS", [1, 2, 3]):
         for n in _ints("IM_NS", [2, 3, 4]):

@@ -1,6 +1,6 @@
 """Generation loop of the IM++ / AIM++ drivers of the reference: ISIC_2018/12_ISIC_2018_IM++.py,
-ISIC_2018/14_ISIC_2018_aug_IM++.py, HeLa/12_HeLa_IM++.py, HeLa/14_HeLa_aug_IM++.py, SUIM/13_SUIM_IM++.py (copies of
-one template; the `aug` variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
+ISIC_2018/14_ISIC_2018_aug_IM++.py, HeLa/12_HeLa_IM++.py, HeLa/14_HeLa_aug_IM++.py, SUIM/13_SUIM_IM++.py,
+Cityscapes/12_Cityscapes_IM++.py (copies of one template; the `aug` variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
 on IM predictions of the labelled set (5 candidates, top-K by mean absolute error), then per generation the IM
 pseudo-labels of the unlabeled set get 1..5 augmented copies each, weighted by the IoU the EvalNets predict, and 5 U-Net
 candidates of growing width are trained on them.  Same loops, schedules, model / directory / CSV names.
@@ -24,15 +24,18 @@ _ISIC = dict(   # ISIC_2018/12_ISIC_2018_IM++.py:52-56
     alphas=[0.5, 0.75, 1, 1.25, 1.5], max_blurs=[0, 1, 1, 2, 3], max_noises=[5, 10, 15, 20, 25],
     bra=[(0.9, 1.1), (0.8, 1.2), (0.7, 1.3), (0.6, 1.4), (0.5, 1.5)], brb=[(-5, 5), (-10, 10), (-15, 15), (-20, 20), (-25, 25)])
 SCHEDULE = {"HeLa": _HELA, "ISIC_2018": _ISIC,
-            "SUIM": dict(_ISIC, alphas=[1, 1.25, 1.5, 1.75, 2])}   # SUIM/13_SUIM_IM++.py:54-58
+            "SUIM": dict(_ISIC, alphas=[1, 1.25, 1.5, 1.75, 2]),   # SUIM/13_SUIM_IM++.py:54-58
+            "Cityscapes": dict(alphas=[1, 1.25, 1.5, 1.75, 2], max_blurs=[0, 0, 0, 0, 1], max_noises=[3, 6, 9, 12, 15],   # 12_...:54-58
+                               bra=[(0.95, 1.05), (0.9, 1.1), (0.8, 1.2), (0.7, 1.3), (0.6, 1.4)],
+                               brb=[(-3, 3), (-6, 6), (-9, 9), (-12, 12), (-15, 15)])}
 
 
 def run(dataset, aug=False, train_new_evalnet=True):
     kind = DATASETS[dataset]["kind"]            # isic | hela | multi
     hela, multi = kind == "hela", kind == "multi"
     if multi and aug:
-        raise NotImplementedError("SUIM/15_SUIM_aug_IBAs++.py is not built")
-    tag = {"HeLa": "HELA", "ISIC_2018": "ISIC_2018", "SUIM": "SUIM"}[dataset]
+        raise NotImplementedError("SUIM/15_SUIM_aug_IBAs++.py and Cityscapes/14_Cityscapes_aug_IM++.py are not built")
+    tag = {"HeLa": "HELA", "ISIC_2018": "ISIC_2018", "SUIM": "SUIM", "Cityscapes": "CITYSCAPES"}[dataset]
     S, D, sch = F.config[tag], F.config["DEFAULT"], SCHEDULE[dataset]
     H, W, C, K = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"]), int(S["NUM_CLASSES"])
     alpha_evalnet = float(S["ALPHA_EVALNET"])

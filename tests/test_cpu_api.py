@@ -228,9 +228,13 @@ def test_evalnet_plan_rejects_bad_config(built_lib):
     from inconsistencymasks_amd._lib import ImkError
     from inconsistencymasks_amd.evalnet import EvalPlan
     with pytest.raises(ImkError):
-        EvalPlan(208, 416, 3, 1, 1, 1.0, False, True, True)      # six poolings need multiples of 64
+        EvalPlan(255, 256, 3, 1, 1, 1.0, False, True, True)      # the towers' pooled outputs are concatenated: even sizes
     with pytest.raises(ImkError):
-        EvalPlan(256, 256, 3, 9, 9, 1.0, True, True, False)      # more than 4 mask channels: not built
+        EvalPlan(48, 256, 3, 1, 1, 1.0, False, True, True)       # six poolings need at least 64 rows
+    with pytest.raises(ImkError):
+        EvalPlan(256, 256, 3, 9, 9, 1.0, True, True, False)      # a 9-channel uint8 mask stack (not one-hot): not built
+    p = EvalPlan(208, 416, 3, 35, 35, 2.0, True, True, False, True)   # Cityscapes: floor pooling 13 -> 6 -> 3, 35 classes
+    assert p.n_total > 0 and p.workspace_bytes(4, 1) > 0
 
 
 def test_evalnet_oracle_losses_and_aug_count():

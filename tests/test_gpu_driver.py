@@ -295,7 +295,7 @@ for j in (1, 2):
     for it in range(700):
         m.train_step(x, y, 0, 3e-3 if it < 200 else 0.0, 1e-4 if it < 200 else 0.0)
     m.repack()
-    F.save_model(m, os.path.join(paths.HELA_MODEL_DIR, f"HeLa_subset_1_topK_{{j}}.h5"))
+    F.save_model(m, os.path.join(paths.HELA_MODEL_DIR, f"HELA_subset_1_topK_{{j}}.h5"))
 """
 
 
@@ -310,7 +310,7 @@ def test_hela_driver_toy_run(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "HeLa", "09_HeLa_IM.py")], env=env, cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    stem = "HeLa_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    stem = "HELA_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
     models = sorted(os.listdir(base / "models"))
     assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
     rows = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
@@ -334,7 +334,7 @@ def test_hela_driver_toy_run(tmp_path):
 HELA_PP_SETUP_EXTRA = """
 import shutil
 for j in (1, 2):   # the IM++ drivers start from the `HELA_subset_aug_{{runid}}` ensemble (HeLa/14_HeLa_aug_IM++.py:75,180)
-    shutil.copy(os.path.join(paths.HELA_MODEL_DIR, f"HeLa_subset_1_topK_{{j}}.h5"),
+    shutil.copy(os.path.join(paths.HELA_MODEL_DIR, f"HELA_subset_1_topK_{{j}}.h5"),
                 os.path.join(paths.HELA_MODEL_DIR, f"HELA_subset_aug_1_topK_{{j}}.h5"))
 sample(8, os.path.join(paths.HELA_BASE_DIR, "train_labeled_aug"), "laug")
 """

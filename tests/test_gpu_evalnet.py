@@ -19,6 +19,9 @@ CFGS = {
     "alpha2": dict(h=64, w=64, ca=1, cb=3, k=3, alpha=2.0, two=True, na=True, nb=False, b=2),    # HeLa ALPHA_EVALNET = 2
     # SUIM: input B is the one-hot stack of a 9-class label map (functions.py:4978), passed as class ids
     "suim": dict(h=64, w=64, ca=3, cb=9, k=9, alpha=1.0, two=True, na=True, nb=False, b=3, onehot=True),
+    # Cityscapes-like: 35 classes, sizes that are not multiples of 64 (104 -> 52 -> 26 -> 13 -> 6 -> 3 -> 1: MaxPooling2D drops
+    # the odd last row / column twice per axis)
+    "city": dict(h=104, w=208, ca=3, cb=35, k=35, alpha=0.5, two=True, na=True, nb=False, b=2, onehot=True),
 }
 
 
