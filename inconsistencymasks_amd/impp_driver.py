@@ -1,6 +1,6 @@
 """Generation loop of the IM++ / AIM++ drivers of the reference: ISIC_2018/12_ISIC_2018_IM++.py,
 ISIC_2018/14_ISIC_2018_aug_IM++.py, HeLa/12_HeLa_IM++.py, HeLa/14_HeLa_aug_IM++.py, SUIM/13_SUIM_IM++.py,
-Cityscapes/12_Cityscapes_IM++.py (copies of one template; the `aug` variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
+SUIM/15_SUIM_aug_IBAs++.py, Cityscapes/12_Cityscapes_IM++.py, Cityscapes/14_Cityscapes_aug_IM++.py (copies of one template; the `aug` variants differ in names and in which sets join the training directory).  Per run an ensemble of EvalNets is trained
 on IM predictions of the labelled set (5 candidates, top-K by mean absolute error), then per generation the IM
 pseudo-labels of the unlabeled set get 1..5 augmented copies each, weighted by the IoU the EvalNets predict, and 5 U-Net
 candidates of growing width are trained on them.  Same loops, schedules, model / directory / CSV names.
@@ -33,8 +33,6 @@ SCHEDULE = {"HeLa": _HELA, "ISIC_2018": _ISIC,
 def run(dataset, aug=False, train_new_evalnet=True):
     kind = DATASETS[dataset]["kind"]            # isic | hela | multi
     hela, multi = kind == "hela", kind == "multi"
-    if multi and aug:
-        raise NotImplementedError("SUIM/15_SUIM_aug_IBAs++.py and Cityscapes/14_Cityscapes_aug_IM++.py are not built")
     tag = {"HeLa": "HELA", "ISIC_2018": "ISIC_2018", "SUIM": "SUIM", "Cityscapes": "CITYSCAPES"}[dataset]
     S, D, sch = F.config[tag], F.config["DEFAULT"], SCHEDULE[dataset]
     H, W, C, K = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"]), int(S["NUM_CLASSES"])
