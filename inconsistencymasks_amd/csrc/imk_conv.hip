@@ -153,11 +153,20 @@ __device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_
         for (int i = threadIdx.x; i < cs; i += 256) { s_aff[2 * cs + i] = in.sc2[i]; s_aff[3 * cs + i] = in.sh2[i]; }
     if (in.lmode == LM_BNBWD)
         for (int i = threadIdx.x; i < 3 * cs; i += 256) s_aff[i] = in.sc[i];
+    if (in.lmode == LM_STEM) {   // [sc | sh | W[0] | W[1] | W[2] | W[3] | bias], cs floats each; weights as the fp16 values the stem kernel uses
+        for (int i = threadIdx.x; i < cs; i += 256) {
+            const bool real = i < in.cin;
+            s_aff[i] = in.sc[i]; s_aff[cs + i] = in.sh[i];
+            for (int c = 0; c < 4; ++c) s_aff[(2 + c) * cs + i] = (real && c < in.u8_c) ? (float)(f16)in.sc2[c * in.cin + i] : 0.f;
+            s_aff[6 * cs + i] = real ? in.sh2[i] : 0.f;
+        }
+    }
 }
 
 // ---- two-phase input staging: raw global loads into registers, transform later ------------------------------------
 template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 2 : 1)]; };
 template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
+template <> struct RawChunk<LM_STEM> { uint32_t b[4]; };
 
 template <int LM>
 __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x, int H, int W, int c8, RawChunk<LM> &r) {
@@ -179,9 +188,10 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
         r.v[0] = *(const f16x8 *)((const f16 *)in.in + o);
         r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + o);
     } else {
-        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
+        const int nb = LM == LM_STEM ? in.u8_c : in.cin;     // bytes per pixel
+        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * nb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < in.cin) ? p[j] : 0;
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < nb) ? p[j] : 0;
     }
 }
 
@@ -216,6 +226,22 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
         for (int j = 0; j < 8; ++j) {
             const float zf = (float)r.v[1][j];
             o[j] = zf > 0.f ? (f16)(A[j] * (float)r.v[0][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
+        }
+        return o;
+    } else if constexpr (LM == LM_STEM) {
+        // x * (1/255) rounds to the same fp16 as x / 255 for all 256 byte values (checked exhaustively)
+        float xin[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xin[c] = (float)(f16)((float)r.b[c] * (1.0f / 255.0f));
+        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8, *bias = s_aff + 6 * cs + c8 * 8;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = fmaf(s_aff[(2 + c) * cs + c8 * 8 + j], xin[c], acc);   // absent channels: zero weights
+            const f16 z = (f16)fmaxf(acc + bias[j], 0.f);                                            // the stem's stored output
+            o[j] = (f16)((float)z * sc[j] + sh[j]);
         }
         return o;
     } else {
@@ -555,7 +581,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int nq = (ks3 ? 9 : 1) * NC8, ns = PAIR ? (nq + 1) / 2 : (nq + 3) / 4;
     uint8_t *s_tile = smem;
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);
-    float *s_red = s_aff + 4 * 16;              // [4 waves][2][16]
+    float *s_red = s_aff + 8 * 16;              // [4 waves][2][16] (the affine table has up to 7 rows of 16: LM_STEM)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int set = PAIR ? (g >> 1) : 0;        // PAIR: which of the block's two tile rows this lane feeds and owns
@@ -1159,6 +1185,7 @@ double conv_algorithmic_bytes(const ImkConvArgs &a) {
         case LM_UPADD: in_b = px * a.x.cs_in * 2 + 0.25 * px * a.x.cs_in * 2; break;  // skip + low-res tensor
         case LM_BNBWD: in_b = 2.0 * px * a.x.cs_in * 2; break;                        // dy and z
         case LM_U8: in_b = px * a.x.cin; break;
+        case LM_STEM: in_b = px * a.x.u8_c; break;
         default: in_b = px * a.x.cs_in * 2;
     }
     double out_b = (a.wpk2 && !a.out) ? 0.0 : px * a.cs_out * 2;
@@ -1272,7 +1299,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 16 + 4 * 2 * 16) * sizeof(float) + 1024;   // tile, affine table, statistics, u8 rows
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024;   // tile, affine table, statistics, u8 rows
     auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL>;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -1317,6 +1344,8 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
             case LM_POOL: return IMK_PIPE_FWD(LM_POOL);
             case LM_UPADD: return IMK_PIPE_FWD(LM_UPADD);
             case LM_U8: return IMK_PIPE_FWD(LM_U8);
+            case LM_STEM:   // inference chains only (Conv3x3 -> Conv1x1 without the intermediate)
+                return chain == 2 ? launch_conv_pipe_k<LM_STEM, NC8, 2, PAIR, EP_RELU, false, FULL>(a, stream) : IMK_EUNSUPPORTED;
             default: return IMK_EUNSUPPORTED;
         }
 #undef IMK_PIPE_FWD
@@ -1361,6 +1390,11 @@ bool imk_conv_pair_layout(int k_in, int m_out, bool u8_input) {
     return pair_enabled() && imk_pad8(k_in) <= 16 && m_out <= 8 && (!u8_input || k_in <= 4);
 }
 
+bool imk_conv_stem_fusable(int u8_c, int ch0, int cout_next) {
+    static const bool off = []() { const char *e = getenv("IMK_STEM_FUSE"); return e && e[0] == '0'; }();
+    return !off && pipe_enabled() && u8_c <= 4 && ch0 <= 16 && cout_next <= 16;
+}
+
 bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     static const bool off = []() { const char *e = getenv("IMK_CONV_CHAIN"); return e && e[0] == '0'; }();
     if (off || !pipe_enabled()) return false;
@@ -1387,6 +1421,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
         return launch_conv_pipe_any(a, stream);
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
+    if (a.x.lmode == LM_STEM) return IMK_EUNSUPPORTED;
     return launch_conv_mfma(a, stream);
 }
 

@@ -11,6 +11,10 @@ enum ImkLoadMode {
     LM_U8 = 4,      // fp16(u8/u8_div), [B,H,W,cin] bytes                (Lambda x/255, unet.py:5)
     LM_BNBWD = 5,   // (A*dy + B*z + C) * [z > 0]: BatchNorm backward + ReLU backward applied on load;
                     // in = dy, in2 = z (the BN's input), sc = per-channel coefficients [A | B | C] (3*cs floats)
+    LM_STEM = 6,    // inference: the whole input block on load (unet.py:4-9: x/255 -> Conv1x1+ReLU -> BatchNorm):
+                    // in = uint8 image [B,H,W,u8_c], sc2 / sh2 = the stem's fp32 kernel [u8_c][cin] / bias [cin],
+                    // sc / sh = its folded BatchNorm; fp16(fp16(relu(W . fp16(x/255) + b)) * sc + sh), i.e. what
+                    // LM_AFFINE reads from the stored stem output.  Pipelined kernel only (<= 16 channels).
 };
 enum ImkEpilogue {
     EP_RELU = 0,   // fp16(max(acc + bias, 0)); optional per-channel sum / sum-of-squares partials
@@ -26,6 +30,7 @@ struct ImkInput {
     int lmode;
     int cin, cs_in;        // logical / padded-to-8 channel count (LM_U8: cs_in = 8)
     float u8_div;          // LM_U8: 255 (Lambda x/255, unet.py:5) or 1 (evalnet.py:5, normalize=False)
+    int u8_c;              // LM_STEM: bytes per pixel of the uint8 image (<= 4)
     int src_h, src_w;      // LM_POOL: size of the tensor that is pooled (0: 2H x 2W); 2H + 1 / 2W + 1 when MaxPooling2D dropped
                            // an odd last row / column (Keras 'valid' pooling: EvalNet at sizes that are not multiples of 64)
 };
@@ -72,6 +77,8 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
 bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
+// inference: can the input block (u8_c image channels -> ch0) be computed on load by the conv that follows it (LM_STEM)?
+bool imk_conv_stem_fusable(int u8_c, int ch0, int cout_next);
 // "Pair" fragment layout (see conv_pipe_kernel): used by every conv operand with <= 8 output channels that the
 // pipelined kernel runs (<= 16 input channels, u8 input with <= 4 channels).  k_in / m_out are the operand's own input /
 // output channel counts (forward: cin / cout, dgrad: cout / cin; chain: both must be <= 8).

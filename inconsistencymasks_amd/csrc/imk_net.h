@@ -181,11 +181,14 @@ inline ImkInput conv_input(const Ctx &c, int conv) {
 
 // conv2 >= 0: fuse the 1x1 conv `conv2` (whose only input is conv's output) into the same kernel when possible.
 // Returns 1 in *fused if it did.
-inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool *fused = nullptr) {
+// x_override: another description of the same input (LM_STEM: the input block computed on load); only valid together with
+// a successful chain, otherwise nothing is launched and IMK_EUNSUPPORTED comes back (the caller runs the plain path).
+inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool *fused = nullptr,
+                        const ImkInput *x_override = nullptr) {
     const ImkLayer &l = c.p->layers[conv];
     const Dim d = res_dim(c.p->cfg, l.res);
     ImkConvArgs a{};
-    a.x = conv_input(c, conv);
+    a.x = x_override ? *x_override : conv_input(c, conv);
     a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
     a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
     a.wpk = c.wfwd(conv);
@@ -206,6 +209,7 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
             if (fused) *fused = true;
         }
     }
+    if (x_override && !(a.wpk2 && !a.out)) return IMK_EUNSUPPORTED;
     const int bn = c.p->layers[stat_conv].bn_after;
     int rows = 0;
     if (c.train && bn >= 0) {

@@ -120,8 +120,24 @@ int run_forward(Ctx &c, const Topo &t, float *probs, float *params_rw) {
 #define RUN(conv) do { rc = run_conv_fwd(c, (conv), params_rw); if (rc) return rc; } while (0)
     // Conv3x3+ReLU -> Conv1x1+ReLU pairs run as one kernel where the channel counts allow it
 #define RUN_PAIR(c3, c1) do { rc = run_conv_pair(c, (c3), (c1), params_rw); if (rc) return rc; } while (0)
-    RUN(t.in_c);
-    for (int i = 0; i < 4; ++i) RUN_PAIR(t.e_c3[i], t.e_c1[i]);
+    // Inference: the input block (x/255 -> Conv1x1+ReLU -> BN, unet.py:4-9) is computed by the first encoder conv while it
+    // stages its tile (LM_STEM), so the full-resolution stem tensor is neither written nor read.
+    bool stem_fused = false;
+    {
+        const ImkLayer &st = c.p->layers[t.in_c], &c3 = c.p->layers[t.e_c3[0]];
+        if (!c.train && !g_imk_materialize && imk_conv_stem_fusable(st.cin, st.cout, c3.cout)) {
+            ImkInput x{};
+            x.in = c.x_in[0]; x.lmode = LM_STEM; x.cin = c3.cin; x.cs_in = imk_pad8(c3.cin); x.u8_c = st.cin;
+            x.sc = c.bn_scale(t.in_bn); x.sh = c.bn_shift(t.in_bn);
+            x.sc2 = c.params + st.off_w; x.sh2 = c.params + st.off_b;
+            bool f = false;
+            rc = run_conv_fwd(c, t.e_c3[0], params_rw, t.e_c1[0], &f, &x);
+            if (rc == IMK_OK) stem_fused = true;
+            else if (rc != IMK_EUNSUPPORTED) return rc;
+        }
+    }
+    if (!stem_fused) { RUN(t.in_c); RUN_PAIR(t.e_c3[0], t.e_c1[0]); }
+    for (int i = 1; i < 4; ++i) RUN_PAIR(t.e_c3[i], t.e_c1[i]);
     RUN_PAIR(t.b_c3, t.b_c1);
     for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN_PAIR(t.d_c3[j], t.d_c1[j]); }
 #undef RUN_PAIR

@@ -295,3 +295,23 @@ def test_baseline_shapes_full_size(UNet, name):
     st = m.stats.cpu().numpy()
     assert st[1] == 0.0 and np.isfinite(st[0]), st
     assert not torch.equal(before, m.params) and bool(torch.isfinite(m.params).all())
+
+
+@pytest.mark.parametrize("name", ["isic", "hela"])
+def test_fused_input_block_matches_stored_one(UNet, name):
+    """Inference computes the input block (x/255 -> Conv1x1+ReLU -> BN) inside the first encoder conv's load (LM_STEM) instead of
+    storing its output; imk_debug_materialize(1) runs the stored path.  Same fp16 roundings, fp32 sums of <= 4 products in a
+    different order: probabilities agree to 2e-3."""
+    from inconsistencymasks_amd._lib import lib
+    cfg = CFGS[name]
+    m = UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=5)
+    m.load_state_dict(randomize_bn(m.state_dict(), 6))
+    x, _, _ = make_input(cfg, 7)
+    fused = m.predict(x)
+    lib.imk_debug_materialize(1)
+    try:
+        stored = m.predict(x)
+    finally:
+        lib.imk_debug_materialize(0)
+    assert np.abs(fused - stored).max() <= 2e-3
+    assert (np.abs(fused - stored) > 0).mean() < 0.5 or np.abs(fused - stored).max() <= 1e-3
