@@ -56,6 +56,22 @@ def default_color_mapping(n_classes):
     return {((37 * k) % 256, (91 * k) % 256, (173 * k) % 256): k for k in range(n_classes)}
 
 
+class _Timer:
+    """wall-clock stage timer of the drivers, printed when IM_TIMING is set"""
+
+    def __init__(self, prefix):
+        import time
+        self.prefix, self.clock, self.t = prefix, time.perf_counter, time.perf_counter()
+        self.on = bool(os.environ.get("IM_TIMING"))
+
+    def __call__(self, what):
+        if self.on:
+            torch.cuda.synchronize()
+            now = self.clock()
+            print(f"[timing] {self.prefix}{what}: {now - self.t:.2f} s", flush=True)
+            self.t = now
+
+
 def _ints(name, default):
     v = os.environ.get(name)
     return [int(x) for x in v.split(",")] if v else default
@@ -101,6 +117,7 @@ def run(dataset, approach="IM"):
                 else:
                     files = [os.path.join(model_dir, f"{name_of(gen - 1)}_topK_{j}.h5") for j in range(1, n + 1)]
                 best_models = [F.load_model(f) for f in files]
+                tick = _Timer(f"{modelname}: ")     # IM_TIMING=1 prints the wall time of every stage
 
                 means = []
                 for split, key in (("VAL", "val"), ("TEST", "test"), ("TRAIN_UNLABELED", "train_unlabeled")):
@@ -113,6 +130,7 @@ def run(dataset, approach="IM"):
                     else:
                         means.append(F.create_pseudo_labels_im_hela(best_models, H, W, C, os.path.join(P(f"{split}_DIR"), "brightfield"),
                                                                     out[key], EK, DK, BI, BO))
+                tick("pseudo-labels (val, test, unlabeled): ensemble inference + IM + PNG I/O")
                 unl = out["train_unlabeled"]
                 if plus:     # augmented copies only (copy_org False) form the training set
                     src, unl = unl, os.path.join(base, "train_unlabeled_predictions", approach, modelname)
@@ -161,6 +179,7 @@ def run(dataset, approach="IM"):
                         res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
                                            P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
                     rows.append((name_i,) + tuple(res))
+                    tick(f"candidate {i}: training + 3 benchmarks")
                     del model
 
                 if rank == 0:
