@@ -503,19 +503,25 @@ def load_model(path, custom_objects=None, device="cuda"):
     return m
 
 
+_VAL_CACHE = {}   # (directories, file list) -> decoded validation set on the device: the monitor runs once per epoch
+
+
 def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
     """Keras BinaryIoU(target_class_ids=[1], threshold=0.5) accumulated over the whole directory (the
     val_binary_io_u monitor of functions.py:216-217); pixel counts from imk_eval_binary."""
     files = sorted(glob.glob(os.path.join(images_dir, "*.png")))
+    key = (images_dir, masks_dir, c, tuple(files))
+    if key not in _VAL_CACHE:
+        _VAL_CACHE.clear()
+        with _pool() as pool:
+            items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), files))
+        _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                           torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda())
+    xs, ys = _VAL_CACHE[key]
     inter = union = 0
-    with _pool() as pool:
-        for i in range(0, len(files), batch):
-            chunk = files[i:i + batch]
-            items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), chunk))
-            x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
-            y = torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda()
-            _, cnt = _ev.eval_binary(model.predict_device(x), y, 0.5, True, want_pred=False)
-            inter += int(cnt[:, 0].sum()); union += int(cnt[:, 1].sum())
+    for i in range(0, len(files), batch):
+        _, cnt = _ev.eval_binary(model.predict_device(xs[i:i + batch]), ys[i:i + batch], 0.5, True, want_pred=False)
+        inter += int(cnt[:, 0].sum()); union += int(cnt[:, 1].sum())
     return inter / max(union, 1)
 
 
