@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
 // z and four skip-gradient chunks of the window and its pooled gradient are 9 loads for 4 pixels (the per-pixel
 // form above needs 6 per pixel: itself, the pooled gradient, the skip gradient and the three other window elements),
 // the first-maximum decision is taken once per window, and the index arithmetic runs per window instead of per pixel.
+// DIRECT = false: no skip gradient (EvalNet's blocks: max-pool scatter only, 5 loads per window; the pooled gradient may
+// be a channel slice of a wider tensor, go_cs).
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
     const int nc8 = a.cs / 8;
     int sh = 0;
@@ -248,14 +251,13 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
             const unsigned xh = w % Wh, r = w / Wh, yh = r % Hh, b = r / Hh;
             const size_t w00 = (((size_t)(b * a.H + 2 * yh) * a.W + 2 * xh) * nc8 + c8) * 8;
             const size_t off[4] = {w00, w00 + o1, w00 + o2, w00 + o2 + o1};   // row-major window order
-            // all nine loads of the window go out together (no branch between them: the skip gradient always exists
-            // for the encoder outputs this kernel serves; the launcher sends a null g_direct to the per-pixel kernel)
+            // all loads of the window go out together (no branch between them: DIRECT is a compile-time property)
             f16x8 z[4], g[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = *reinterpret_cast<const f16x8 *>(a.z + off[e]);
-            const f16x8 dp = *reinterpret_cast<const f16x8 *>(a.g_other + ((size_t)w * nc8 + c8) * 8);
+            const f16x8 dp = *reinterpret_cast<const f16x8 *>(a.g_other + (size_t)w * a.go_cs + c8 * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = *reinterpret_cast<const f16x8 *>(a.g_direct + off[e]);
+            for (int e = 0; e < 4; ++e) g[e] = DIRECT ? *reinterpret_cast<const f16x8 *>(a.g_direct + off[e]) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             f16x8 dy[4];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -746,7 +748,8 @@ int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, co
     if (a.go_cs != cs && (mode != 1 || g_direct)) return IMK_EUNSUPPORTED;
     const int nb = imk_bn_prep_blocks(B, H, W, cs);
     if (mode == 0) bn_bwd_prep_kernel<0><<<nb, 256, 0, stream>>>(a);
-    else if (mode == 1 && H % 2 == 0 && W % 2 == 0 && g_direct) bn_bwd_prep_pool_kernel<<<nb, 256, 0, stream>>>(a);
+    else if (mode == 1 && H % 2 == 0 && W % 2 == 0 && g_direct) bn_bwd_prep_pool_kernel<true><<<nb, 256, 0, stream>>>(a);
+    else if (mode == 1 && H % 2 == 0 && W % 2 == 0) bn_bwd_prep_pool_kernel<false><<<nb, 256, 0, stream>>>(a);
     else if (mode == 1) bn_bwd_prep_kernel<1><<<nb, 256, 0, stream>>>(a);
     else bn_bwd_prep_kernel<2><<<nb, 256, 0, stream>>>(a);
     IMK_LAUNCH_CHECK();
