@@ -129,7 +129,7 @@ def png_io_rate(images):
     import io
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    threads = int(os.environ.get("IMK_IO_THREADS", 8))
+    threads = int(os.environ.get("IMK_IO_THREADS", min(16, os.cpu_count() or 8)))
     def enc(a):
         b = io.BytesIO()
         Image.fromarray(a).save(b, format="PNG", compress_level=1)

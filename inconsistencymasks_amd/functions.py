@@ -38,7 +38,9 @@ NUM_EPOCHS = int(_D.get("NUM_EPOCHS", 50))
 NUM_EPOCHS_CS = int(_D.get("NUM_EPOCHS_CS", 100))
 
 INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 256))
-_IO_THREADS = int(os.environ.get("IMK_IO_THREADS", 8))
+# PNG decode / encode threads (Pillow releases the GIL inside the codecs; measured on the MI355X host, 256 x 256 x 3 images:
+# 8 / 16 / 32 / 64 threads -> encode 1.5 / 2.3 / 3.2 / 1.4 k images/s, decode 2.8 / 4.4 / 2.7 / 2.8 k images/s)
+_IO_THREADS = int(os.environ.get("IMK_IO_THREADS", min(16, os.cpu_count() or 8)))
 
 
 # ---------------------------------------------------------------------------------------------------
