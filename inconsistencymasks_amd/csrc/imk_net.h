@@ -334,6 +334,7 @@ struct Bwd {
     struct Pending { int conv; const f16 *dA_override; };
     Pending pending[8];
     int n_pending = 0;
+    bool defer_finalize = false;
     int launch_wgrad(int conv, const f16 *dA_override, hipStream_t ws) {
         ImkWgradArgs a{};
         wgrad_args(conv, dA_override, a);
@@ -367,7 +368,11 @@ struct Bwd {
             if (rc) return rc;
         }
         n_pending = 0;
-        // ... and their split reductions right behind them, so that only the last layers' are left for the end of the step
+        // ... and their split reductions right behind them, so that only the last layers' are left for the end of the step.
+        // Those last layers (defer_finalize: the final block of the backward pass) skip it: their reductions would sit between
+        // their weight-gradient kernels on the side stream, which the end of the step waits for; finish_wgrads does all of
+        // them in one pair of launches instead.
+        if (defer_finalize) return IMK_OK;
         int rc = imk_launch_wgrad_finalize_jobs(jobs, &ctl->inv_loss_scale, found_inf, ws);
         jobs = ImkWgFinalJobs{};
         return rc;

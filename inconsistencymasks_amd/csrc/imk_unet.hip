@@ -391,6 +391,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     OK(b.flush_wgrads());
     // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
     for (int i = 3; i >= 0; --i) {
+        if (i == 0) b.defer_finalize = true;   // last block: nothing left to hide its split reductions behind
         OK(b.bn_bwd(t.e_bn[i], 1, reinterpret_cast<f16 *>(c.base + c.ws.dU[3 - i]),
                     reinterpret_cast<f16 *>(c.base + c.ws.dP[i])));
         OK(b.wgrad_dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
