@@ -6,7 +6,8 @@ rows = []
 for r in csv.DictReader(open(f)):
     name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
     name = re.sub(r"^void ", "", name).split("(")[0]
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?"),
+                 r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
 stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4")]          # uint8 stem: start of a forward
 folds = [i for i, r in enumerate(rows) if r[2].startswith("pack_conv_batched_kernel")]   # end of an optimizer step
@@ -19,12 +20,18 @@ def show(seg, title):
     agg = defaultdict(lambda: [0, 0.0])
     for s, e, n, *_ in seg:
         agg[n][0] += 1; agg[n][1] += (e - s) / 1e3
+    busy_main = sum(e - s for s, e, n, gx, wx, q in seg if q == seg[0][5]) / 1e3
+    print(f"   first kernel's stream: busy {busy_main:.1f} us of the span")
     for n, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"   {n:42s} n={c:3d} us={us:8.1f}")
-    for s, e, n, gx, wx in seg:
+    main = seg[0][5]                     # the stream of the step's first kernel; "gap" = idle time of that stream before a kernel
+    last_end = {}
+    for s, e, n, gx, wx, q in seg:
         try: g = int(gx) // max(int(wx), 1)
         except ValueError: g = gx
-        print(f"  {(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f} {n:42s} {g}")
+        gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+        last_end[q] = e
+        print(f"  {(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f} {'M' if q == main else 's'} gap {gap:6.1f} {n:42s} {g}")
 train = [(st, min(f for f in folds if f > st)) for st in stems if any(f > st for f in folds)
          and not any(h > st and h < min(f for f in folds if f > st) for h in heads)]
 if len(train) >= 2:
