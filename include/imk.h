@@ -12,7 +12,9 @@
  *     (a hipStream_t passed as void*; NULL = the null stream) and the caller owns every buffer until
  *     it has synchronised that stream;
  *   - all pointers are DEVICE pointers unless a parameter says "host";
- *   - re-entrant and thread-safe: no global state besides read-only code objects.
+ *   - compute entry points keep no global state; a PLAN owns one set of side streams / events, so one plan must not be
+ *     driven from two host threads at the same time (use one plan per thread; plans are cheap).  The debug and measurement
+ *     hooks at the end of this file (imk_debug_*, imk_prof_*) are process-global switches and are not thread-safe.
  *   - images and masks are uint8, NHWC; probabilities float32 NHWC; sizes int64.
  */
 #ifndef IMK_H
@@ -27,6 +29,9 @@ extern "C" {
 
 #define IMK_VERSION 100 /* 0.1.0 */
 
+/* libimk.so is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#define IMK_API __attribute__((visibility("default")))
+
 enum {
     IMK_OK = 0,
     IMK_EINVAL = -1,      /* null pointer / non-positive size / unsupported combination */
@@ -34,8 +39,8 @@ enum {
     IMK_EWORKSPACE = -3,  /* workspace too small */
 };
 
-int imk_version(void);
-const char *imk_error_string(int code);
+IMK_API int imk_version(void);
+IMK_API const char *imk_error_string(int code);
 
 /* ------------------------------------------------------------------------------------------------
  * Inconsistency-mask kernels
@@ -52,7 +57,7 @@ const char *imk_error_string(int code);
  *   im_out     [B,H,W]   uint8 {0,255}  (max over the Kb channel IMs)
  *   im_size    [B,Kb] int64, pred_size [B,Kb] int64   -- counted BEFORE blocking, like the reference
  * NaN votes 0 under both comparison operators.                                                        */
-int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int kb,
+IMK_API int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int kb,
                   float thr, int cmp_ge,
                   const uint8_t *img, int c, int block_in, int block_out,
                   uint8_t *img_out, uint8_t *masks_out, uint8_t *im_out,
@@ -68,19 +73,19 @@ int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int
  *   im_size    [B] int64
  *   presence   [N,B,K] uint8 or NULL: 1 where model n predicts class k somewhere in image b (the
  *              `np.unique` sets of functions.py:3226, for the unique-set filter of :3231-3234)        */
-int imk_im_multiclass(const float *probs, int n_models, int batch, int h, int w, int k,
+IMK_API int imk_im_multiclass(const float *probs, int n_models, int batch, int h, int w, int k,
                       const uint8_t *img, int c, int block_in, int block_out,
                       uint8_t *img_out, uint8_t *final_out, uint8_t *im_out,
                       int64_t *im_size, uint8_t *presence, void *stream);
 
 /* k x k all-ones erosion (op = 0) / dilation (op = 1) of [B,H,W] uint8 masks, out-of-image taps ignored.
  * Replaces cv2.erode / cv2.dilate at functions.py:2858-2864 (dead in every shipped config: EK = DK = 0). */
-int imk_morph(const uint8_t *src, uint8_t *dst, int batch, int h, int w, int ksize, int op, void *stream);
+IMK_API int imk_morph(const uint8_t *src, uint8_t *dst, int batch, int h, int w, int ksize, int op, void *stream);
 
 /* image[im>0] = 0 (all C channels) and mask[im>0] = 0 for n_masks [B,H,W] masks packed as [B,n_masks,H,W]:
  * the blocking step of functions.py:2867-2874 when it has to run AFTER morphology changed the IM.
  * In place.  img or masks may be NULL.                                                                */
-int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *masks, int n_masks,
+IMK_API int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *masks, int n_masks,
                     int batch, int h, int w, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -109,13 +114,13 @@ typedef struct imk_evalnet_cfg {
                             classes that the reference feeds (functions.py:4978, 5990); no x/255 on it */
 } imk_evalnet_cfg;
 
-int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out);
-void imk_unet_plan_destroy(imk_unet_plan *plan);
+IMK_API int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out);
+IMK_API void imk_unet_plan_destroy(imk_unet_plan *plan);
 
 /* Flat fp32 parameter vector.  Trainable section first (what AdamW and the gradient all-reduce see),
  * in unet.py creation order: per Conv2D kernel [kh][kw][cin][cout] (Keras HWIO) then bias [cout]; per
  * BatchNormalization gamma then beta.  Then the non-trainable section: per BN moving_mean, moving_var. */
-int imk_unet_param_count(const imk_unet_plan *plan, int64_t *total, int64_t *trainable);
+IMK_API int imk_unet_param_count(const imk_unet_plan *plan, int64_t *total, int64_t *trainable);
 
 typedef struct imk_layer_info {
     char name[16];   /* "in.c", "e1.c3", "e1.c1", "e1.bn", "b.c3", ..., "d6.ca", "d6.bna", ..., "out" */
@@ -124,39 +129,39 @@ typedef struct imk_layer_info {
     int64_t off_w, off_b;         /* conv: kernel, bias;   bn: gamma, beta   (offsets in floats) */
     int64_t off_mean, off_var;    /* bn only */
 } imk_layer_info;
-int imk_unet_num_layers(const imk_unet_plan *plan);
-int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer_info *out);
+IMK_API int imk_unet_num_layers(const imk_unet_plan *plan);
+IMK_API int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer_info *out);
 
 /* fp16 copies of the conv kernels in MFMA-fragment order (forward and transposed/flipped for dgrad),
  * folded BN scale/shift.  Re-run after every change of `params`.  train = 0 folds the moving statistics
  * into scale/shift (inference); in training the batch statistics are produced by the step itself. */
-int64_t imk_unet_packed_bytes(const imk_unet_plan *plan);
-int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream);
+IMK_API int64_t imk_unet_packed_bytes(const imk_unet_plan *plan);
+IMK_API int imk_unet_pack_weights(const imk_unet_plan *plan, const float *params, void *packed, void *stream);
 
 /* Workspace (activations, gradients, reduction scratch).  mode 0 = inference, 1 = training. */
-int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode);
+IMK_API int64_t imk_unet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode);
 
 /* Batched inference: replaces model.predict at functions.py:3157, 3184, 3224 (and the batch-64 form at
  * :1120).  x [B,H,W,c_in] uint8 (the model divides by 255 itself, unet.py:5) -> probs [B,H,W,n_out] f32. */
-int imk_unet_forward(const imk_unet_plan *plan, const float *params, const void *packed,
+IMK_API int imk_unet_forward(const imk_unet_plan *plan, const float *params, const void *packed,
                      const uint8_t *x, int batch, float *probs, void *workspace, int64_t workspace_bytes,
                      void *stream);
 
 /* Debug/parity: after imk_unet_forward or a training step, byte offset/shape of a stored intermediate
  * inside the workspace (fp16, NHWC with the channel count padded to a multiple of 8).
  * which: 0 = conv output of layer `layer_idx` (post-ReLU, pre-BN).  Returns IMK_EINVAL if not stored. */
-int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
+IMK_API int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
                          int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
 /* Ensemble inference fused with the IM chain: N models' forward passes, then head -> threshold/argmax ->
- * agreement -> IM -> blocking without writing the probability stack.  One call = functions.py:2844-2887
+ * agreement -> IM -> blocking.  One call = functions.py:2844-2887
  * minus file I/O, for a batch.  `params`/`packed` are arrays (host) of n_models device pointers.
  * binary heads (act_out = 0): outputs as imk_im_binary;  softmax heads: as imk_im_multiclass
  * (masks_out = final_out [B,H,W], pred_size unused, presence optional).
  * workspace: n_models * align256(B*H*W*n_out*4) for the probability stack + k * imk_unet_workspace_bytes(plan, B, 0),
  * 1 <= k <= min(n_models, 3): with k > 1 the models run on k streams side by side (forked from and joined to
  * `stream` with events; the call stays asynchronous), with k = 1 back to back.                          */
-int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
+IMK_API int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
                         const float *const *params, const void *const *packed,
                         const uint8_t *x, int batch, float thr, int cmp_ge,
                         const uint8_t *img, int block_in, int block_out,
@@ -172,9 +177,9 @@ int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
  *   stats     device float[4]: {loss, found_inf (0/1), loss_scale used, reserved}
  *   state     device buffer of imk_unet_state_bytes(): Adam m, v, step counter, dynamic loss scale
  * imk_unet_fwd_bwd also updates the BN moving statistics in `params` (momentum 0.99).                  */
-int64_t imk_unet_state_bytes(const imk_unet_plan *plan);
-int imk_unet_state_init(const imk_unet_plan *plan, void *state, void *stream);
-int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state,
+IMK_API int64_t imk_unet_state_bytes(const imk_unet_plan *plan);
+IMK_API int imk_unet_state_init(const imk_unet_plan *plan, void *state, void *stream);
+IMK_API int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state,
                      const uint8_t *x, const uint8_t *y, int batch, int loss_kind,
                      float *grads, float *stats, void *workspace, int64_t workspace_bytes, void *stream);
 
@@ -183,7 +188,7 @@ int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, voi
  * training step.  It does NOT refresh the folded inference BatchNorm statistics (training never reads them):
  * call imk_unet_pack_weights before the next imk_unet_forward / imk_unet_forward_im.
  * grad_scale multiplies grads first (1/world_size after a sum all-reduce).                            */
-int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, void *state,
+IMK_API int imk_unet_adamw_step(const imk_unet_plan *plan, float *params, void *packed, void *state,
                         const float *grads, const float *stats, float grad_scale,
                         float lr, float wd, float beta1, float beta2, float eps, void *stream);
 
@@ -203,7 +208,7 @@ typedef struct imk_aug_params {   /* one per image, device array */
 /* Replaces augment_image_and_mask (functions.py:2779-2826) + add_noise_and_blur (:1481-1506) for a batch.
  *   img  [B,H,W,C] u8 -> img_out;  mask [B,H,W,Cm] u8 (or NULL) -> mask_out (geometric part only).
  * 90-degree turns need h == w (set any_quarter_turn if any params[i].rot is 1 or 3).  Not in place. */
-int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w, int c, int cm,
+IMK_API int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w, int c, int cm,
                 const imk_aug_params *params, uint8_t *img_out, uint8_t *mask_out, int any_quarter_turn, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -213,14 +218,14 @@ int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w
  * get_IoU_binary (:1767-1788) and dice_score_numpy_binary (:1837-1861):
  *   probs [B,H,W] f32, gt [B,H,W] u8 -> pred_out [B,H,W] u8 in {0,255} (may be NULL), counts [B,5] int64 =
  *   { #(gt!=0 & pred), #(gt!=0 | pred), #(gt>=128), #pred, #(gt>=128 & pred) };  pred = p > thr (cmp_ge: >=). */
-int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt, int batch, int h, int w,
+IMK_API int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt, int batch, int h, int w,
                     uint8_t *pred_out, int64_t *counts, void *stream);
 
 /* Replaces argmax + pixel_accuracy (functions.py:1820-1834) + get_IoU_multi_unique (:1791-1816) of
  * benchmark_multiclass (:1308-1330):  probs [B,H,W,K] f32, gt [B,H,W] u8 class ids -> pred_out [B,H,W] u8 (may be
  * NULL), counts [B,4,256] int64: [0][v] = #(gt==v), [1][v] = #(pred==v), [2][v] = #(gt==v & pred==v),
  * [3][0] = #(pred==gt).  k <= 256. */
-int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
+IMK_API int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
                         int64_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -234,11 +239,11 @@ int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h,
  * _state_bytes / _state_init / _adamw_step / _plan_destroy apply unchanged.  Layer names: "a.in.c", "a.in.bn", "a.c3",
  * "a.c1", "a.bn", the same with "b.", "m1.c3", "m1.c1", "m1.bn" ... "m5.bn", then "dense" or "iou", "detection"
  * (Dense kernels [C, n_out] + bias, reported as 1x1 convs); parameter order = Keras creation order. */
-int imk_evalnet_plan_create(const imk_evalnet_cfg *cfg, imk_unet_plan **out);
-int64_t imk_evalnet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode /* 0 inference, 1 training */);
+IMK_API int imk_evalnet_plan_create(const imk_evalnet_cfg *cfg, imk_unet_plan **out);
+IMK_API int64_t imk_evalnet_workspace_bytes(const imk_unet_plan *plan, int batch, int mode /* 0 inference, 1 training */);
 
 /* out [B, n_heads*n_out] f32 sigmoid outputs (two heads: iou units first, then detection units); inference-mode BN */
-int imk_evalnet_forward(const imk_unet_plan *plan, const float *params, const void *packed, const uint8_t *xa,
+IMK_API int imk_evalnet_forward(const imk_unet_plan *plan, const float *params, const void *packed, const uint8_t *xa,
                         const uint8_t *xb, int batch, float *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Training pass: forward with batch statistics (moving statistics updated in params), losses, backward.
@@ -247,34 +252,38 @@ int imk_evalnet_forward(const imk_unet_plan *plan, const float *params, const vo
  *   out (may be NULL): the training-mode outputs;  grads [n_trainable] f32 (unscaled);
  *   stats [8] f32: {total loss, overflow flag, loss scale, step, loss of head 0, loss of head 1, -, -}.
  * Follow with imk_unet_adamw_step. */
-int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state, const uint8_t *xa,
+IMK_API int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, void *packed, void *state, const uint8_t *xa,
                         const uint8_t *xb, const float *y, int batch, float *out, float *grads, float *stats,
                         void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Debug/parity: like imk_unet_tensor_info, for EvalNet plans */
-int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
+IMK_API int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
                             int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
 /* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
  * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on
  * every layer.  Global flag; training always stores them (the backward pass needs them). */
-int imk_debug_materialize(int on);
+IMK_API int imk_debug_materialize(int on);
 
 /* Measurement: with on = 1 every kernel runs on the caller's stream (no side stream for the weight gradients, the
  * ensemble's models back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
-int imk_debug_single_stream(int on);
+IMK_API int imk_debug_single_stream(int on);
 
 /* ------------------------------------------------------------------------------------------------
- * Measurement hook (bench.py): per-launch HIP-event timing of the convolution kernel, on the stream the
- * kernel is launched on.  imk_prof_enable(k) makes every k-th conv launch record an event pair (0 = off);
- * imk_prof_collect synchronises those events and returns, per kernel variant v (0..IMK_PROF_VARIANTS-1:
- * v = 3*(tile_h==8) + log2(MT) for conv_mfma_kernel, v = 6 for conv_pipe_kernel), the launch count, the summed duration in ms and the summed ALGORITHMIC
- * bytes (input tensor(s) read once + output tensor written once + mask read once), then resets.
- * Not thread-safe; for benchmarking only (costs two hipEventRecord per launch while enabled).
+ * Measurement hook (bench.py): per-launch HIP-event timing of every kernel family of the path, on the stream the
+ * kernel is launched on.  imk_prof_enable(k) makes every k-th hooked launch record an event pair (0 = off);
+ * imk_prof_collect synchronises those events and returns, per family v (0..IMK_PROF_VARIANTS-1), the number of sampled
+ * launches, their summed duration in ms and their summed ALGORITHMIC bytes (every input tensor read once + every
+ * output tensor written once), then resets.  Families:
+ *   0..5  conv_mfma_kernel<TH,MT>: v = 3*(TH==8) + log2(MT)      6  conv_pipe_kernel
+ *   7  wgrad_mfma_kernel      8  bn_bwd_prep(_pool)_kernel       9  bn_bwd_coef_kernel     10  bn_finalize_kernel
+ *   11 wgf_stage1 + wgf_stage2 (one bracket)                     12 head_kernel            13  head_loss_kernel
+ *   14 loss_finalize / adamw / pack_conv_batched / bn_fold_batched                         15  im_binary_* / im_multi_kernel
+ * Process-global and not thread-safe; for benchmarking only (two hipEventRecord per sampled launch while enabled).
  * ---------------------------------------------------------------------------------------------- */
-#define IMK_PROF_VARIANTS 7
-int imk_prof_enable(int on);
-int imk_prof_collect(int64_t *count, double *ms, double *bytes);
+#define IMK_PROF_VARIANTS 16
+IMK_API int imk_prof_enable(int on);
+IMK_API int imk_prof_collect(int64_t *count, double *ms, double *bytes);
 
 #ifdef __cplusplus
 }

@@ -25,3 +25,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- measurement hook (imk_prof_enable / imk_prof_collect, include/imk.h) --------------------------------------------
+// Kernel families whose launches can be bracketed with HIP events on the stream they are launched on.
+enum ImkProfFamily {
+    PF_CONV_MFMA = 0,    // 0..5: conv_mfma_kernel<TH,MT>: 3 * (TH == 8) + log2(MT)
+    PF_CONV_PIPE = 6,    // conv_pipe_kernel (every template variant)
+    PF_WGRAD = 7,        // wgrad_mfma_kernel
+    PF_BN_PREP = 8,      // bn_bwd_prep_kernel / bn_bwd_prep_pool_kernel (assemble dy + reduce)
+    PF_BN_COEF = 9,      // bn_bwd_coef_kernel
+    PF_BN_FINALIZE = 10, // bn_finalize_kernel
+    PF_WGF = 11,         // wgf_stage1_kernel + wgf_stage2_kernel (one bracket around the pair)
+    PF_HEAD = 12,        // head_kernel (inference)
+    PF_HEAD_LOSS = 13,   // head_loss_kernel
+    PF_STEP_TAIL = 14,   // loss_finalize_kernel, adamw_kernel, pack_conv_batched_kernel, bn_fold_batched_kernel
+    PF_IM = 15,          // im_binary_vec / im_binary_generic / im_multi_kernel
+    PF_COUNT = 16
+};
+// Returns a slot >= 0 when this launch is sampled (an event was recorded on `stream`), else -1.
+int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream);
+void imk_prof_end(int slot, hipStream_t stream);
+struct ImkProfScope {
+    int slot;
+    hipStream_t stream;
+    ImkProfScope(int family, double bytes, hipStream_t s) : slot(imk_prof_begin(family, bytes, s)), stream(s) {}
+    ~ImkProfScope() { if (slot >= 0) imk_prof_end(slot, stream); }
+    ImkProfScope(const ImkProfScope &) = delete;
+    ImkProfScope &operator=(const ImkProfScope &) = delete;
+};

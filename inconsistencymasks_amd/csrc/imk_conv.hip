@@ -1133,6 +1133,10 @@ int imk_wgf_add_job(ImkWgFinalJobs &jobs, float *partial, int n_split, int ksize
 
 int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_scale_ptr, float *found_inf, hipStream_t stream) {
     if (jobs.n <= 0) return IMK_OK;
+    double wgf_bytes = 0;
+    for (int i = 0; i < jobs.n; ++i)   // partials read once, chunk sums written and read once, gradients written
+        wgf_bytes += ((double)jobs.j[i].n_split + 2.0 * jobs.j[i].n_chunks + 1.0) * jobs.j[i].n_tiles * 256 * 4;
+    ImkProfScope prof(PF_WGF, wgf_bytes, stream);
     wgf_stage1_kernel<<<jobs.total_work1, 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     wgf_stage2_kernel<<<jobs.total_tiles, 1024, 0, stream>>>(jobs, inv_scale_ptr, found_inf);
@@ -1142,6 +1146,9 @@ int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_
 
 int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
     if (jobs.n <= 0) return IMK_OK;
+    double pk_bytes = 0;
+    for (int i = 0; i < jobs.n; ++i) pk_bytes += (double)jobs.j[i].ksize * jobs.j[i].ksize * jobs.j[i].cin * jobs.j[i].cout * 6;
+    ImkProfScope prof(PF_STEP_TAIL, pk_bytes, stream);
     pack_conv_batched_kernel<<<dim3(16, jobs.n), 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
@@ -1165,7 +1172,7 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int variant; double bytes; };
-int g_prof_period = 0;   // 0 = off, k = time every k-th conv launch
+int g_prof_period = 0;   // 0 = off, k = time every k-th hooked launch
 long g_prof_counter = 0;
 std::vector<ProfRec> g_prof;       // recorded launches since the last collect
 std::vector<hipEvent_t> g_ev_pool; // recycled events
@@ -1197,16 +1204,27 @@ double conv_algorithmic_bytes(const ImkConvArgs &a) {
 }  // namespace
 
 extern "C" int imk_prof_enable(int on) { g_prof_period = on < 0 ? 0 : on; return IMK_OK; }
-static inline bool prof_sample() { return g_prof_period > 0 && (g_prof_counter++ % g_prof_period) == 0; }
+
+int imk_prof_begin(int family, double bytes, hipStream_t stream) {
+    if (g_prof_period <= 0 || (g_prof_counter++ % g_prof_period) != 0) return -1;
+    ProfRec pr{prof_event(), prof_event(), family, bytes};
+    if (hipEventRecord(pr.e0, stream) != hipSuccess) { g_ev_pool.push_back(pr.e0); g_ev_pool.push_back(pr.e1); return -1; }
+    g_prof.push_back(pr);
+    return (int)g_prof.size() - 1;
+}
+void imk_prof_end(int slot, hipStream_t stream) {
+    if (slot >= 0 && slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
+}
 
 extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
     IMK_CHECK_ARG(count && ms && bytes);
+    static_assert(IMK_PROF_VARIANTS == PF_COUNT, "include/imk.h and imk_common.h disagree");
     for (int v = 0; v < IMK_PROF_VARIANTS; ++v) { count[v] = 0; ms[v] = 0; bytes[v] = 0; }
     for (auto &r : g_prof) {
-        IMK_HIP(hipEventSynchronize(r.e1));
         float t = 0.f;
-        IMK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-        count[r.variant] += 1; ms[r.variant] += t; bytes[r.variant] += r.bytes;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            count[r.variant] += 1; ms[r.variant] += t; bytes[r.variant] += r.bytes;
+        }
         g_ev_pool.push_back(r.e0); g_ev_pool.push_back(r.e1);
     }
     g_prof.clear();
@@ -1265,14 +1283,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         kern<<<grid, 256, L.lds, stream>>>(a, L.gm);
         return IMK_OK;
     };
-    ProfRec pr{};
-    const bool prof = prof_sample();
-    if (prof) {
-        pr.e0 = prof_event(); pr.e1 = prof_event();
-        pr.variant = (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0));
-        pr.bytes = conv_algorithmic_bytes(a);
-        IMK_HIP(hipEventRecord(pr.e0, stream));
-    }
+    ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), conv_algorithmic_bytes(a), stream);
 #define IMK_MFMA_MT(TH, LM) \
     (L.mt == 4 ? launch(conv_mfma_kernel<TH, 4, LM>) : (L.mt == 2 ? launch(conv_mfma_kernel<TH, 2, LM>) : launch(conv_mfma_kernel<TH, 1, LM>)))
 #define IMK_MFMA_TH(LM) (L.th == 16 ? IMK_MFMA_MT(16, LM) : IMK_MFMA_MT(8, LM))
@@ -1288,10 +1299,6 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_MFMA_MT
     if (rc) return rc;
     if (a.stats_rows) *a.stats_rows = L.gx;
-    if (prof) {
-        IMK_HIP(hipEventRecord(pr.e1, stream));
-        g_prof.push_back(pr);
-    }
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -1310,21 +1317,10 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    ProfRec pr{};
-    const bool prof = prof_sample();
-    if (prof) {
-        pr.e0 = prof_event(); pr.e1 = prof_event();
-        pr.variant = 6;
-        pr.bytes = conv_algorithmic_bytes(a);
-        IMK_HIP(hipEventRecord(pr.e0, stream));
-    }
+    ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x, 1.0f / (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
-    if (prof) {
-        IMK_HIP(hipEventRecord(pr.e1, stream));
-        g_prof.push_back(pr);
-    }
     return IMK_OK;
 }
 
@@ -1460,11 +1456,26 @@ static int plan_wgrad(const ImkWgradArgs &a, WgradLaunch &L) {
     return IMK_OK;
 }
 
+// forward input read once (per its load mode) + gradient operand(s) read once + the fp32 partials written
+static double wgrad_algorithmic_bytes(const ImkWgradArgs &a, const WgradLaunch &L) {
+    const double px = (double)a.B * a.H * a.W;
+    double in_b;
+    switch (a.x.lmode) {
+        case LM_POOL: in_b = 4.0 * px * a.x.cs_in * 2; break;
+        case LM_UPADD: in_b = 1.25 * px * a.x.cs_in * 2; break;
+        case LM_U8: in_b = px * a.x.cin; break;
+        default: in_b = px * a.x.cs_in * 2;
+    }
+    const int T = a.ksize == 3 ? 9 : 1;
+    return in_b + px * a.cs_out * 2 * (a.dA_z ? 2 : 1) + (double)L.gx * L.gy * (T + 1) * 256 * 4;
+}
+
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     WgradLaunch L{};
     int rc = plan_wgrad(a, L);
     if (rc) return rc;
     const dim3 grid(L.gx, L.gy);
+    ImkProfScope prof(PF_WGRAD, wgrad_algorithmic_bytes(a, L), stream);
     switch (a.x.lmode) {
 #define IMK_WG(LM) do { if (a.dA_z) wgrad_mfma_kernel<LM, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
                         else wgrad_mfma_kernel<LM, false><<<grid, 256, L.lds, stream>>>(a, L.gm); } while (0)

@@ -714,6 +714,7 @@ __global__ __launch_bounds__(256) void evalnet_head_reduce_kernel(const float *_
 int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *beta, float *mov_mean, float *mov_var, float *scale, float *shift,
                            float *save_mean, float *save_invstd, hipStream_t stream) {
+    ImkProfScope prof(PF_BN_FINALIZE, (double)n_part * 2 * cs * 4 + 8.0 * cs * 4, stream);
     bn_finalize_kernel<<<cs, 256, 0, stream>>>(partial, n_part, c, cs, count, gamma, beta, mov_mean, mov_var, scale, shift,
                                                save_mean, save_invstd);
     IMK_LAUNCH_CHECK();
@@ -722,6 +723,7 @@ int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, doub
 
 int imk_launch_bn_fold_jobs(const ImkFoldJobs &jobs, hipStream_t stream) {
     if (jobs.n <= 0) return IMK_OK;
+    ImkProfScope prof(PF_STEP_TAIL, 0.0, stream);
     bn_fold_batched_kernel<<<dim3(2, jobs.n), 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
@@ -747,6 +749,12 @@ int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, co
     BnPrepArgs a{mode, g_direct, g_other, z, sc, sh, dy_out, partial, B, H, W, cs, g_other_cs > 0 ? g_other_cs : cs};
     if (a.go_cs != cs && (mode != 1 || g_direct)) return IMK_EUNSUPPORTED;
     const int nb = imk_bn_prep_blocks(B, H, W, cs);
+    // mode 0: dy and z read;  mode 1: skip gradient (optional), pooled gradient at quarter size, z read, dy written;
+    // mode 2: the 2H x 2W upsampled-branch gradient and z read, dy written;  + the partial rows
+    const double px = (double)B * H * W, t = px * cs * 2;
+    const double prep_bytes = (mode == 0 ? 2 * t : mode == 1 ? (g_direct ? 3 * t : 2 * t) + 0.25 * px * a.go_cs * 2 : 6 * t)
+                            + (double)nb * 2 * cs * 4;
+    ImkProfScope prof(PF_BN_PREP, prep_bytes, stream);
     if (mode == 0) bn_bwd_prep_kernel<0><<<nb, 256, 0, stream>>>(a);
     else if (mode == 1 && H % 2 == 0 && W % 2 == 0 && g_direct) bn_bwd_prep_pool_kernel<true><<<nb, 256, 0, stream>>>(a);
     else if (mode == 1 && H % 2 == 0 && W % 2 == 0) bn_bwd_prep_pool_kernel<false><<<nb, 256, 0, stream>>>(a);
@@ -759,6 +767,7 @@ int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, co
 int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *save_mean, const float *save_invstd, const float *inv_scale_ptr, float *coef,
                            float *dgamma, float *dbeta, float *found_inf, hipStream_t stream) {
+    ImkProfScope prof(PF_BN_COEF, (double)n_part * 2 * cs * 4 + 8.0 * cs * 4, stream);
     bn_bwd_coef_kernel<<<cs, 256, 0, stream>>>(partial, n_part, c, cs, count, gamma, save_mean, save_invstd, inv_scale_ptr,
                                                coef, dgamma, dbeta, found_inf);
     IMK_LAUNCH_CHECK();
@@ -771,6 +780,7 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
     if (K > 64) return IMK_EUNSUPPORTED;
     const int nb = (int)((n_pix + 255) / 256);
     const size_t lds = ((size_t)K * cs + K + 2 * cs + 256 * (size_t)(K | 1)) * sizeof(float);
+    ImkProfScope prof(PF_HEAD, (double)n_pix * (cs * 2 + K * 4), stream);
 #define IMK_HEAD(CS)                                                                                                     \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
@@ -799,6 +809,7 @@ int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const f
     const int nb = imk_loss_blocks(n_pix);
     const size_t lds = ((size_t)K * cs + K + 2 * cs + (softmax ? 256 * (size_t)(K | 1) : 0)) * sizeof(float);
     const int cs_out = imk_pad8(K);
+    ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + (softmax ? 1 : K) + cs_out * 2), stream);
 #define IMK_HL(CS) if (lds > 64 * 1024) IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_loss_kernel<CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     head_loss_kernel<CS><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, K, softmax, n_pix, y, ctl, stats, cs_out, dlogit, loss_partial)
     switch (cs) {
@@ -816,6 +827,7 @@ int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const f
 
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, float *stats, hipStream_t stream) {
     const double denom = kind == 0 ? (double)n_pix * K : (double)n_pix;
+    ImkProfScope prof(PF_STEP_TAIL, (double)imk_loss_blocks(n_pix) * 4, stream);
     loss_finalize_kernel<<<1, 256, 0, stream>>>(loss_partial, imk_loss_blocks(n_pix), denom, stats);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
@@ -829,6 +841,7 @@ int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream) {
 
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,
                      float grad_scale, float lr, float wd, float b1, float b2, float eps, hipStream_t stream) {
+    ImkProfScope prof(PF_STEP_TAIL, (double)n * 28, stream);   // p, m, v read + written, g read
     adamw_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(p, m, v, g, n, ctl, stats, grad_scale, lr, wd, b1, b2, eps);
     IMK_LAUNCH_CHECK();
     return IMK_OK;   // the step counter / loss scale update rides on the re-packing launch that follows (imk_ctl_end_step)

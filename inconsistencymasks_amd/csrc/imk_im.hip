@@ -317,6 +317,8 @@ extern "C" int imk_im_binary(const float *preds, int n_models, int batch, int h,
     auto *ims = reinterpret_cast<unsigned long long *>(im_size);
     auto *pss = reinterpret_cast<unsigned long long *>(pred_size);
     const bool vec_ok = (hw % 4 == 0) && aligned16(preds) && (kb == 1 || kb == 3);
+    // probability stack + image read, image + masks + IM written
+    ImkProfScope prof(PF_IM, (double)batch * hw * ((double)n_models * kb * 4 + (img ? 2.0 * c : 0.0) + kb + 1), stream);
     if (vec_ok) {
         const int vec_out = (hw % 16 == 0) && aligned16(masks_out) && aligned16(im_out);
         const int vec_img = img && ((int64_t)hw * c % 16 == 0) && aligned16(img) && aligned16(img_out);
@@ -356,6 +358,7 @@ extern "C" int imk_im_multiclass(const float *probs, int n_models, int batch, in
     const uint32_t magic = (uint32_t)((1ull << 32) / (uint32_t)k) + 1u;
     const size_t lds = (size_t)MC_CHUNK * (k | 1) * sizeof(float);
     dim3 grid(imk_cdiv(hw, MC_CHUNK), batch);
+    ImkProfScope prof(PF_IM, (double)batch * hw * ((double)n_models * k * 4 + (img ? 2.0 * c : 0.0) + 2), stream);
     im_multi_kernel<<<grid, 256, lds, stream>>>(probs, n_models, batch, hw, k, magic, img, c, block_in, block_out,
                                                 img_out, final_out, im_out, reinterpret_cast<unsigned long long *>(im_size),
                                                 presence, vec_in, vec_out, vec_img);

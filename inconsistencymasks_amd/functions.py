@@ -209,16 +209,66 @@ class EnsembleIM:
                 "presence": presence}
 
 
+class StackIM:
+    """The same `.run()` as EnsembleIM for duck-typed models (anything with `.predict(x)` like a Keras model, called once
+    per image with a [1,H,W,C] batch exactly as functions.py:3157 / :3224 do): the probability stack goes through
+    imk_im_binary / imk_im_multiclass.  Native UNet models take the fused EnsembleIM path instead."""
+
+    def __init__(self, models, binary):
+        self.models, self.binary = list(models), binary
+
+    def run(self, x_u8, thr=0.5, cmp_ge=False, block_in=True, block_out=True, want_presence=False):
+        outs = []
+        for m in self.models:
+            if hasattr(m, "predict_device"):
+                outs.append(m.predict_device(x_u8))
+            else:
+                xs = x_u8.cpu().numpy()
+                p = np.concatenate([np.asarray(m.predict(xs[i:i + 1]), dtype=np.float32) for i in range(len(xs))], 0)
+                outs.append(torch.from_numpy(p).cuda())
+        preds = torch.stack(outs, 0).contiguous()
+        if self.binary:
+            r = _im.im_binary(preds, thr, cmp_ge, x_u8, block_in, block_out)
+            r["presence"] = None
+            return r
+        r = _im.im_multiclass(preds, x_u8, block_in, block_out, want_presence=want_presence)
+        b = x_u8.shape[0]
+        return {"img_out": r["img_out"], "masks": r["final"][:, None], "im": r["im"], "im_size": r["im_size"][:, None],
+                "pred_size": torch.zeros((b, 1), dtype=torch.int64, device=x_u8.device), "presence": r["presence"]}
+
+
+def _ensemble(models, binary):
+    return EnsembleIM(models) if _is_native(models) else StackIM(models, binary)
+
+
+def dilate_mask(mask, kernel_size=3, iterations=1):
+    """functions.py:3075-3100: every non-zero class dilated separately in ascending order, later classes overwriting
+    earlier ones -- i.e. the grey-level dilation (neighbourhood maximum, out-of-image taps ignored) of the class-id map,
+    which is what imk_morph computes.  Accepts [H,W] / [B,H,W] uint8 (numpy or device tensor)."""
+    t = torch.as_tensor(mask)
+    squeeze = t.dim() == 2
+    d = (t[None] if squeeze else t).to(torch.uint8).cuda().contiguous()
+    for _ in range(iterations):
+        d = _im.morph(d, kernel_size, "dilate")
+    d = d[0] if squeeze else d
+    return d if isinstance(mask, torch.Tensor) else d.cpu().numpy()
+
+
 def _morph_then_block(r, erode_kernel, dilate_kernel, block_input, block_output, x_u8, dilate_masks=False):
-    """Cold path (EK/DK > 0, dead in every shipped config): morphology on the IM, then blocking with the
-    modified IM (functions.py:2858-2874 order)."""
+    """EK / DK > 0 (the reference's DEFAULT arguments; 0 in every shipped config): morphology on the IM, with
+    erode_kernel > 0 also dilate_mask on the label maps where the reference does it (multiclass functions.py:3041-3047,
+    HeLa alive / dead :2940-2946), then blocking with the modified IM (functions.py:2858-2874, 3049-3062 order)."""
     im = r["im"]
     masks = r["masks"]
     if erode_kernel > 0:
         im = _im.morph(im, erode_kernel, "erode")
+        if dilate_masks:
+            b, m, h, w = masks.shape
+            masks = _im.morph(masks.reshape(b * m, h, w), 3, "dilate").reshape(b, m, h, w)
     if dilate_kernel > 0:
         im = _im.morph(im, dilate_kernel, "dilate")
     img = x_u8.clone()
+    masks = masks.clone() if masks is r["masks"] else masks
     _im.block_apply(im, img if block_input else None, masks if block_output else None)
     return img, masks, im
 
@@ -234,10 +284,10 @@ def _all_reduce_sum(vals):
 
 def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dilate_kernel, block_input, block_output,
                 flag):
-    """Shared body of the three writers.  kind in {'isic', 'multi'}."""
+    """Shared body of the ISIC and multiclass writers.  kind in {'isic', 'multi'}."""
     names = os.listdir(images_path)
     mine = shard_list(names)
-    ens = EnsembleIM(models)
+    ens = _ensemble(models, kind == "isic")
     fused_block = (erode_kernel <= 0 and dilate_kernel <= 0)
     sum_im, count = 0, 0
     with _pool() as pool:
@@ -250,7 +300,8 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
             if fused_block:
                 img_out, masks, im = r["img_out"], r["masks"], r["im"]
             else:
-                img_out, masks, im = _morph_then_block(r, erode_kernel, dilate_kernel, block_input, block_output, x)
+                img_out, masks, im = _morph_then_block(r, erode_kernel, dilate_kernel, block_input, block_output, x,
+                                                       dilate_masks=(kind == "multi"))
             img_np, m_np, im_np = img_out.cpu().numpy(), masks.cpu().numpy(), im.cpu().numpy()
             ims = r["im_size"].sum(1).cpu().numpy()
             pss = r["pred_size"].sum(1).cpu().numpy()
@@ -288,10 +339,8 @@ def create_pseudo_labels_im_ISIC_2018(models, h, w, c, images_path, main_output_
 def create_pseudo_labels_im_multiclass(models, h, w, c, images_path, main_output_path, rgb=True, erode_kernel=5,
                                        dilate_kernel=5, block_input=True, block_output=True,
                                        filter_unequal_class_pred=False):
-    """functions.py:2988-3070.  With erode_kernel > 0 the reference also dilates the label map per class
-    (functions.py:3047, dilate_mask) -- not implemented on the GPU path (EK = 0 in every shipped config)."""
-    if erode_kernel > 0:
-        raise NotImplementedError("per-class dilate_mask (erode_kernel > 0) is dead in the shipped configs")
+    """functions.py:2988-3070.  With erode_kernel > 0 the label map is also dilated per class (functions.py:3047,
+    dilate_mask) before blocking."""
     out = {k: os.path.join(main_output_path, k) for k in ("images", "masks", "im")}
     for d in out.values():
         os.makedirs(d, exist_ok=True)
@@ -457,6 +506,43 @@ class _EpochLoader:
         return self._px[lo:hi], self._py[lo:hi]
 
 
+def _train_shard(files):
+    """This rank's block of the training file list; with fewer files than ranks every rank keeps the whole list (the
+    averaged gradient is then the single-GPU gradient) instead of an empty shard."""
+    files = sorted(files)
+    _, world = _rank_world()
+    return files if len(files) < world else shard_list(files)
+
+
+def _sync_moving_stats(model):
+    """Data-parallel replicas normalise with their own batch statistics, so their BatchNorm moving
+    statistics drift apart; before a checkpoint decision they are averaged, so that every rank evaluates -- and rank 0
+    saves -- the same model."""
+    d = _dist()
+    if not d:
+        return
+    tail = model.params[model.plan.n_trainable:]
+    d.all_reduce(tail)
+    tail.mul_(1.0 / d.get_world_size())
+    model._fold_ok = False
+
+
+def _gather_lists(*lists):
+    """Per-image metric lists of a sharded benchmark -> the complete lists on every rank (rank order = sorted file order)."""
+    d = _dist()
+    if not d:
+        return lists
+    out = [None] * d.get_world_size()
+    d.all_gather_object(out, lists)
+    return tuple(sum((o[i] for o in out), []) for i in range(len(lists)))
+
+
+def _bench_names(directory):
+    """os.listdir order on one GPU (as the reference); this rank's contiguous block of the sorted list otherwise"""
+    names = os.listdir(directory)
+    return shard_list(names) if _dist() else names
+
+
 def _grad_allreduce(model):
     d = _dist()
     if not d:
@@ -480,6 +566,7 @@ def fit(model, loader, steps_per_epoch, epochs, loss_kind, on_epoch_end=None, lr
             model.adamw_step(lr, wd, grad_scale=scale)
             loss_acc += model.stats[0] * scale
         history.append(float(loss_acc.item()) / max(steps_per_epoch, 1))
+        _sync_moving_stats(model)
         if on_epoch_end:
             on_epoch_end(ep, history[-1])
     return history
@@ -533,7 +620,7 @@ def benchmark_ISIC2018(model, images_dir, masks_dir, pred_path, h, w, c, batch_s
     means rounded to 3.  Threshold + per-image pixel counts run in imk_eval_binary; the ratios are formed on the
     host with the reference's float expressions (evaluate.iou_dice_from_counts)."""
     os.makedirs(pred_path, exist_ok=True)
-    names = os.listdir(images_dir)
+    names = _bench_names(images_dir)
     ious, dices = [], []
     with _pool() as pool:
         for i in range(0, len(names), batch_size):
@@ -553,6 +640,7 @@ def benchmark_ISIC2018(model, images_dir, masks_dir, pred_path, h, w, c, batch_s
                 dices.append(d); ious.append(u)
                 if print_results:
                     print(f"{n} IoU: {u}    DS: {d}")
+    ious, dices = _gather_lists(ious, dices)
     mIoU = round(float(np.sum(ious) / len(ious)), 3)
     mdice = round(float(np.sum(dices) / len(dices)), 3)
     print(f"------------------------------------------------------------  mIoU: {mIoU}    mdice score: {mdice}  "
@@ -566,7 +654,7 @@ def train_ISIC_2018(train_images_dir, val_images_dir, val_masks_dir, test_images
     """functions.py:189-228.  loss_func must be 'mse' (what every ISIC script passes)."""
     if loss_func != "mse":
         raise NotImplementedError("the ISIC scripts train with 'mse'")
-    files = shard_list(glob.glob(os.path.join(train_images_dir, "*.png")))
+    files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
     loader = _EpochLoader(files, lambda p: parse_image_ISIC_2018(p, c), BATCH_SIZE, SEED)
     best = {"iou": -1.0}
 
@@ -646,7 +734,7 @@ def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_t
     """functions.py:1265-1339: batch-64 predict, argmax, PNG dumps, per-image PA / IoU rounded to 4, means to 3.
     argmax + per-image class histograms run in imk_eval_multiclass (evaluate.pa_iou_from_counts forms the ratios)."""
     os.makedirs(pred_path, exist_ok=True)
-    names = os.listdir(image_path)
+    names = _bench_names(image_path)
     ious, pas = [], []
     with _pool() as pool:
         for i in range(0, len(names), batch_size):
@@ -666,6 +754,7 @@ def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_t
                 pas.append(pa); ious.append(iou)
                 if print_results:
                     print(f"{n} IoU: {iou}    PA: {pa}")
+    ious, pas = _gather_lists(ious, pas)
     mPA = round(float(np.sum(pas) / len(pas)), 3)
     mIoU = round(float(np.sum(ious) / len(ious)), 3)
     print(f"------------------------------------------------------------   mPA: {mPA}      mIoU: {mIoU}  "
@@ -679,7 +768,7 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
                      print_results=False):
     """functions.py:275-316.  loss_func: anything (the SUIM / Cityscapes scripts pass CategoricalCrossentropy());
     the fused loss kernel implements exactly that loss on class-id masks."""
-    files = shard_list(glob.glob(os.path.join(train_images_dir, "*.png")))
+    files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
     loader = _EpochLoader(files, lambda p: parse_image_multiclass(p, n_classes, c), BATCH_SIZE, SEED)
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
     best = {"miou": -1.0}
@@ -803,13 +892,11 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
                                  block_input=True, block_output=True, max_pos_circle_size=8, min_pos_circle_size=3):
     """functions.py:2895-2984: three binary IMs (>=), combined IM = max; position mask re-drawn as discs on the host;
     brightfield / alive / dead / mod_position / im written."""
-    if erode_kernel > 0:
-        raise NotImplementedError("dilate_mask of the alive/dead masks (erode_kernel > 0) is dead in the shipped configs")
     out = {k: os.path.join(main_output_path, k) for k in ("brightfield", "alive", "dead", "mod_position", "im")}
     for d in out.values():
         os.makedirs(d, exist_ok=True)
     mine = shard_list(os.listdir(images_path))
-    ens = EnsembleIM(models)
+    ens = _ensemble(models, True)
     sum_im = count = 0
     with _pool() as pool:
         for i in range(0, len(mine), INFER_BATCH):
@@ -817,10 +904,14 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
             imgs = list(pool.map(lambda n: read_png(os.path.join(images_path, n), c), chunk))
             x = torch.from_numpy(np.stack(imgs, 0)).cuda()
             r = ens.run(x, 0.5, True, False, False)          # blocking happens after the host-side position step
-            im = r["im"]
+            im, masks = r["im"], r["masks"]
+            if erode_kernel > 0:       # functions.py:2940-2946: erode the combined IM, dilate_mask on alive and dead
+                im = _im.morph(im, erode_kernel, "erode")
+                ad = _im.morph(masks[:, :2].reshape(-1, h, w).contiguous(), 3, "dilate").reshape(-1, 2, h, w)
+                masks = torch.cat([ad, masks[:, 2:]], 1)     # contours come from the RAW position mask (:2952)
             if dilate_kernel > 0:
                 im = _im.morph(im, dilate_kernel, "dilate")
-            masks_np, im_np = r["masks"].cpu().numpy(), im.cpu().numpy()
+            masks_np, im_np = masks.cpu().numpy(), im.cpu().numpy()
             ims = r["im_size"].sum(1).cpu().numpy()
             jobs = []
             for j, name in enumerate(chunk):
@@ -851,7 +942,7 @@ def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_s
     sub = "mod_position" if mod_position else "position"
     for k in ("alive", "dead", sub):
         os.makedirs(os.path.join(pred_dir, k), exist_ok=True)
-    names = os.listdir(os.path.join(gt_main_dir, "brightfield"))
+    names = _bench_names(os.path.join(gt_main_dir, "brightfield"))
     mious, mious_ad, delta = [], [], 0
     rd = lambda k, n: read_png(os.path.join(gt_main_dir, k, n), 1)[..., 0]
     for i in range(0, len(names), batch_size):
@@ -873,6 +964,8 @@ def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_s
                 write_png(os.path.join(pred_dir, "alive", n), a_u)
                 write_png(os.path.join(pred_dir, "dead", n), d_u)
                 write_png(os.path.join(pred_dir, sub, n), p_u)
+    mious, mious_ad, deltas = _gather_lists(mious, mious_ad, [delta])
+    delta = sum(deltas)
     return (round(float(np.sum(mious) / len(mious)), 3), round(float(np.sum(mious_ad) / len(mious_ad)), 3),
             round(delta / len(mious), 3))
 
@@ -882,7 +975,7 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
     """functions.py:232-269: 'mse' on (alive, dead, 3 x position) targets, best epoch by val_loss (min)."""
     if loss_func != "mse":
         raise NotImplementedError("the HeLa scripts train with 'mse'")
-    files = shard_list(glob.glob(os.path.join(train_images_dir, "*.png")))
+    files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
     loader = _EpochLoader(files, lambda p: parse_image_hela(p, c), BATCH_SIZE, SEED)
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
     best = {"loss": float("inf")}

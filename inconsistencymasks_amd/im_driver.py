@@ -52,8 +52,34 @@ IM_PLUS = {   # per-generation schedules of the IM+ scripts (lines 46-50 / 47-51
 
 
 def default_color_mapping(n_classes):
-    """colour -> class id, deterministic palette (the reference's per-dataset colour tables are cosmetic)."""
+    """colour -> class id, deterministic palette for datasets the reference has no table for"""
     return {((37 * k) % 256, (91 * k) % 256, (173 * k) % 256): k for k in range(n_classes)}
+
+
+def color_mapping(dataset, n_classes):
+    """RGB colour -> class id tables of the `*_color.png` dumps (SUIM/SUIM_class_mapping.py:4-14 COLOR_TO_CLASS_MAPPING_SUIM,
+    Cityscapes/Cityscapes_class_mapping.py:43-80 COLOR_TO_CLASS_MAPPING_CITYSCAPES), generated from the rules the two
+    public palettes follow: SUIM = the dataset's 3-bit RGB codes shifted by one behind the light-grey IM class 0;
+    Cityscapes = the PASCAL-VOC bit-interleaved colour map with blue carrying bit 0, plus the licence-plate colour."""
+    if dataset == "SUIM" and n_classes == 9:
+        m = {(211, 211, 211): 0}
+        for k in range(8):
+            m[(255 * (k >> 2 & 1), 255 * (k >> 1 & 1), 255 * (k & 1))] = k + 1
+        return m
+    if dataset == "Cityscapes" and n_classes == 35:
+        m = {}
+        for k in range(35):
+            r = g = b = 0
+            c = k
+            for j in range(8):
+                b |= (c & 1) << (7 - j)
+                g |= (c >> 1 & 1) << (7 - j)
+                r |= (c >> 2 & 1) << (7 - j)
+                c >>= 3
+            m[(r, g, b)] = k
+        m[(192, 192, 192)] = -1
+        return m
+    return default_color_mapping(n_classes)
 
 
 class _Timer:
@@ -174,7 +200,7 @@ def run(dataset, approach="IM"):
                         res = F.train_multiclass(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                  P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
                                                  name_i, h5, model, "categorical_crossentropy", steps, H, W, C, K,
-                                                 default_color_mapping(K), *preds)
+                                                 color_mapping(dataset, K), *preds)
                     else:
                         res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
                                            P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)

@@ -14,7 +14,7 @@ import torch
 from . import functions as F
 from . import paths
 from .evalnet import get_evalnet, get_evalnet_miou
-from .im_driver import DATASETS, _ints, default_color_mapping
+from .im_driver import DATASETS, _ints, color_mapping
 from .unet import get_unet
 
 _HELA = dict(   # HeLa/14_HeLa_aug_IM++.py:53-57 (identical in 12_HeLa_IM++.py)
@@ -163,7 +163,7 @@ def run(dataset, aug=False, train_new_evalnet=True):
                         res = F.train_multiclass(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                  P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
                                                  name_i, h5, model, "categorical_crossentropy", steps, H, W, C, K,
-                                                 default_color_mapping(K), *preds)
+                                                 color_mapping(dataset, K), *preds)
                     else:
                         res = F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),

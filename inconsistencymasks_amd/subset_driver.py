@@ -1,0 +1,77 @@
+"""The labelled-subset baseline that seeds generation 0 of every IM driver: counterpart of the reference's
+ISIC_2018/03_ISIC_2018_subset.py:41-104, HeLa/03_HeLa_subset.py:41-104, SUIM/04_SUIM_subset.py:41-107 and
+Cityscapes/03_Cityscapes_subset.py (copies of one template).  Ten candidates per run id are trained on the labelled
+subset only, ranked (ISIC: mIoU_val; SUIM / Cityscapes: mIoU_val; HeLa: tuple index 6 ascending, as in the reference),
+and the best TOP_Ks are renamed `{TAG}_subset_{runid}_topK_{j}.h5` -- the files `im_driver.run` loads for gen 0.
+Environment overrides for short runs: IM_RUNIDS, IM_CANDIDATES (comma-separated)."""
+import csv
+import os
+
+import torch
+
+from . import functions as F
+from . import paths
+from .im_driver import DATASETS, _ints, color_mapping
+from .unet import get_unet
+
+# (index of the ranking value in the row, descending?) -- ISIC_2018/03_ISIC_2018_subset.py:82, SUIM/04_SUIM_subset.py:84,
+# HeLa/03_HeLa_subset.py:82 (`key=lambda x: x[6], reverse=False`)
+_RANK = {"isic": (1, True), "multi": (4, True), "hela": (6, False)}
+
+
+def train_candidate(ds, dataset, train_dir, name_i, h5, model, steps, H, W, C, K, preds):
+    """One `train_*` call with the directory arguments of the reference's scripts."""
+    P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
+    if ds["kind"] == "isic":
+        return F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
+                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
+                                 name_i, h5, model, "mse", steps, H, W, C, *preds)
+    if ds["kind"] == "multi":
+        return F.train_multiclass(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
+                                  P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
+                                  name_i, h5, model, "categorical_crossentropy", steps, H, W, C, K,
+                                  color_mapping(dataset, K), *preds)
+    return F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
+                        P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
+
+
+def run(dataset):
+    ds = DATASETS[dataset]
+    S = F.config[ds["section"]]
+    H, W, C = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"])
+    K, alpha = int(S["NUM_CLASSES"]), float(S["ALPHA"])
+    batch, top_k = int(F.config["DEFAULT"]["BATCH_SIZE"]), int(F.config["DEFAULT"]["TOP_Ks"])
+    P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
+    base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        torch.distributed.init_process_group("nccl")
+    rank, world = F._rank_world()
+    tag = {"HeLa": "HELA", "Cityscapes": "CITYSCAPES"}.get(dataset, dataset)
+    approach = "subset"
+    train_dir = os.path.join(P("TRAIN_LABELED_DIR"), "brightfield") if ds["kind"] == "hela" else P("TRAIN_LABELED_IMAGES_DIR")
+    steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+    os.makedirs(model_dir, exist_ok=True)
+    idx, desc = _RANK[ds["kind"]]
+    for runid in _ints("IM_RUNIDS", [1, 2, 3]):
+        modelname = f"{tag}_{approach}_{runid}"
+        rows = []
+        for i in _ints("IM_CANDIDATES", list(range(10))):
+            name_i = f"{modelname}_{i}"
+            h5 = os.path.join(model_dir, name_i + ".h5")
+            preds = [os.path.join(base, f"{k}_predictions", approach, name_i) for k in ("val", "test", "train_unlabeled")]
+            model = get_unet(H, W, C, K, alpha, S["ACTIFU"], S["ACTIFU_OUTPUT"], seed=7000 * runid + i)
+            rows.append((name_i,) + tuple(train_candidate(ds, dataset, train_dir, name_i, h5, model, steps, H, W, C, K, preds)))
+            del model
+        if rank == 0:
+            top = sorted(rows, key=lambda r: r[idx], reverse=desc)[:top_k]
+            print(top)
+            for j, row in enumerate(top, start=1):
+                os.rename(os.path.join(model_dir, f"{row[0]}.h5"), os.path.join(model_dir, f"{row[0][:-2]}_topK_{j}.h5"))
+            os.makedirs(csv_dir, exist_ok=True)
+            with open(os.path.join(csv_dir, f"results_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
+                wr = csv.writer(f, delimiter=";")
+                wr.writerow(ds["header"])
+                wr.writerows(rows)
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()

@@ -90,8 +90,13 @@ class UNet:
         self.plan = plan
         self.device = torch.device(device)
         gen = torch.Generator()
-        if seed is not None:
-            gen.manual_seed(int(seed))
+        if seed is None:
+            # Keras draws a fresh initialisation per get_unet() call (unet.py:46 he_normal, unseeded): a default
+            # torch.Generator() would start from the same constant seed every time and every "candidate" would be the
+            # same model.  Draw the seed from torch's global stream, so torch.manual_seed() still makes a run repeatable.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        gen.manual_seed(int(seed))
+        self.seed = int(seed)
         flat = torch.zeros(self.plan.n_total, dtype=torch.float32)
         for l in self.plan.layers:
             if l["kind"] == 0 and l["name"] in dense:      # Keras Dense default: glorot_uniform

@@ -275,3 +275,61 @@ def test_classwise_label_helpers_golden(golden_dir):
         blocked[im] = 0
         assert np.array_equal(np.array(EF.compute_classwise_detection_im(blocked, K, counts, 0.3)), g[k + "_det_im"]), k
         assert np.array_equal(np.array(EF.compute_classwise_detection(pred, K)), g[k + "_det"]), k
+
+
+def test_unseeded_models_differ(built_lib):
+    """ADVICE r1: get_unet() without a seed must give a fresh initialisation per call, like Keras (unet.py:46);
+    torch.manual_seed() makes the sequence repeatable."""
+    import torch
+    from inconsistencymasks_amd.unet import get_unet
+    a = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", device="cpu")
+    b = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", device="cpu")
+    assert not torch.equal(a.params, b.params)
+    torch.manual_seed(5)
+    c = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", device="cpu")
+    torch.manual_seed(5)
+    d = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", device="cpu")
+    assert torch.equal(c.params, d.params)
+    e = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", seed=3, device="cpu")
+    f = get_unet(64, 64, 3, 1, 0.5, "relu", "sigmoid", seed=3, device="cpu")
+    assert torch.equal(e.params, f.params)
+
+
+def test_reference_module_names_resolve(built_lib):
+    """`from functions import ...`, `from unet import get_unet`, `import paths`, and the five TensorFlow names
+    the reference's scripts touch (inconsistencymasks_amd/compat) resolve to this implementation, with the reference's
+    positional signatures (ISIC_2018/09_ISIC_2018_IM.py:5-16, 75-78, 90-120)."""
+    import inspect
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from functions import train_ISIC_2018, create_pseudo_labels_im_ISIC_2018, dice_loss, train_multiclass, train_hela\n"
+            "from functions import create_pseudo_labels_im_multiclass, create_pseudo_labels_im_hela, BATCH_SIZE, dilate_mask\n"
+            "from unet import get_unet\nfrom evalnet import get_evalnet, get_evalnet_miou\nimport paths\n"
+            "import tensorflow as tf\nfrom tensorflow.keras import mixed_precision\n"
+            "mixed_precision.set_global_policy('mixed_float16')\n"
+            "with tf.device('/gpu:0'):\n    pass\n"
+            "assert callable(tf.keras.models.load_model) and callable(tf.keras.backend.clear_session)\n"
+            "tf.keras.losses.CategoricalCrossentropy()\n"
+            "print(paths.ISIC_2018_TRAIN_UNLABELED_IMAGES_DIR, paths.HELA_VAL_BRIGHTFIELD_DIR, paths.CITYSCAPES_MODEL_DIR)\n"
+            % (ROOT, os.path.join(ROOT, "inconsistencymasks_amd", "compat")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "train_unlabeled" in r.stdout and "brightfield" in r.stdout
+    from inconsistencymasks_amd import functions as F
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(F.create_pseudo_labels_im_ISIC_2018) == ["models", "h", "w", "c", "images_path", "main_output_path", "rgb",
+                                                        "erode_kernel", "dilate_kernel", "block_input", "block_output",
+                                                        "filter_bad_predictions"]
+    d = inspect.signature(F.create_pseudo_labels_im_multiclass).parameters
+    assert d["erode_kernel"].default == 5 and d["dilate_kernel"].default == 5      # the reference's defaults
+
+
+def test_color_tables_follow_the_public_palettes():
+    """SUIM/SUIM_class_mapping.py:4-14 and Cityscapes/Cityscapes_class_mapping.py:43-80, generated by rule."""
+    from inconsistencymasks_amd.im_driver import color_mapping
+    s = color_mapping("SUIM", 9)
+    assert s[(211, 211, 211)] == 0 and s[(0, 0, 0)] == 1 and s[(0, 0, 255)] == 2 and s[(255, 0, 0)] == 5 and s[(255, 255, 255)] == 8
+    assert len(s) == 9
+    c = color_mapping("Cityscapes", 35)
+    assert c[(0, 0, 0)] == 0 and c[(0, 0, 128)] == 1 and c[(128, 128, 128)] == 7 and c[(0, 0, 64)] == 8
+    assert c[(64, 0, 0)] == 32 and c[(64, 128, 0)] == 34 and c[(192, 192, 192)] == -1 and len(c) == 36
+    assert len(color_mapping("SUIM", 3)) == 3          # toy configurations fall back to a generated palette

@@ -24,8 +24,18 @@ WORKER = textwrap.dedent("""
                                    torch.tensor([float(dist.get_rank()), 0.0, 1.0, 0.0])])   # gradients | step statistics
     m.grads, m.stats = m.grads_and_stats[:5], m.grads_and_stats[5:]
     scale = F._grad_allreduce(m)
+    # sharded benchmark: per-image metric lists of the ranks -> the complete list, in sorted file order, on every rank
+    part = [float(int(n[4:8])) for n in mine]
+    whole, = F._gather_lists(part)
+    # BatchNorm moving statistics: averaged over the replicas before a checkpoint decision
+    class P: n_trainable = 3
+    m.params = torch.tensor([9.0, 9.0, 9.0, float(dist.get_rank()), 2.0 + 2 * dist.get_rank()])
+    m.plan = P()
+    F._sync_moving_stats(m)
+    # fewer training files than ranks: every rank keeps the whole list
+    few = F._train_shard(["only.png"])
     print(json.dumps({"rank": dist.get_rank(), "n": len(mine), "mean": mean, "g": (m.grads * scale).tolist(),
-                      "stats": m.stats.tolist()}))
+                      "stats": m.stats.tolist(), "whole": whole, "params": m.params.tolist(), "few": few}))
     dist.destroy_process_group()
 """)
 
@@ -50,3 +60,6 @@ def test_gloo_world2(tmp_path):
         assert o["mean"] == expect
         assert o["g"] == [1.5] * 5                      # mean of rank gradients 1 and 2
         assert o["stats"][0] == 1.0                     # summed ride-along stats
+        assert o["whole"] == [float(int(n[4:8])) for n in sorted(names)]
+        assert o["params"] == [9.0, 9.0, 9.0, 0.5, 3.0]  # trainable part untouched, moving statistics averaged
+        assert o["few"] == ["only.png"]
