@@ -471,3 +471,130 @@ def test_suim_im_plus_plus_toy_run(tmp_path):
     assert set(np.unique(m)) <= {0, 1, 2}
     res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(res) == 3 and len(res[1].split(";")) == 7
+
+
+CITY_CONFIG = MULTI_CONFIG.replace("[SUIM]", "[CITYSCAPES]").replace("IMAGE_HEIGHT = 64", "IMAGE_HEIGHT = 48") \
+    .replace("IMAGE_WIDTH = 64", "IMAGE_WIDTH = 96").replace("NUM_CLASSES = 3", "NUM_CLASSES = 5").replace("ALPHA = 0.5", "ALPHA = 1")
+
+CITY_SETUP = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd import functions as F, paths
+from inconsistencymasks_amd.unet import get_unet
+rng = np.random.default_rng(0)
+H, W = 48, 96
+def sample(n, d_img, d_mask):
+    os.makedirs(d_img, exist_ok=True); os.makedirs(d_mask, exist_ok=True)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(n):
+        horizon, cx = rng.integers(16, 30), rng.integers(20, 76)
+        cls = np.full((H, W), 1, np.uint8)                       # "sky"
+        cls[yy > horizon] = 2                                     # "road"
+        cls[(yy > horizon - 8) & (abs(xx - cx) < 9) & (yy < horizon + 6)] = 3      # "car"
+        cls[(xx < 6) & (yy > 8)] = 4                              # "pole"
+        img = np.stack([40 * cls + 20, 250 - 45 * cls, 30 + 50 * (cls == 3) + 20 * cls], -1)
+        img = (img + rng.integers(-10, 10, (H, W, 3))).clip(0, 255).astype(np.uint8)
+        F.write_png(os.path.join(d_img, f"c_{{i:04d}}.png"), img)
+        F.write_png(os.path.join(d_mask, f"c_{{i:04d}}.png"), cls)
+sample(16, paths.CITYSCAPES_TRAIN_LABELED_IMAGES_DIR, paths.CITYSCAPES_TRAIN_LABELED_MASKS_DIR)
+sample(24, paths.CITYSCAPES_TRAIN_UNLABELED_IMAGES_DIR, paths.CITYSCAPES_TRAIN_UNLABELED_MASKS_DIR)
+sample(8, paths.CITYSCAPES_VAL_IMAGES_DIR, paths.CITYSCAPES_VAL_MASKS_DIR)
+sample(8, paths.CITYSCAPES_TEST_IMAGES_DIR, paths.CITYSCAPES_TEST_MASKS_DIR)
+"""
+
+
+@pytest.mark.parametrize("script,approach", [("09_Cityscapes_IM.py", "IM"), ("11_Cityscapes_IM+.py", "IM_plus")])
+def test_cityscapes_driver_toy_run(tmp_path, script, approach):
+    """Cityscapes/03_Cityscapes_subset.py (the labelled-subset baseline that seeds generation 0) followed by
+    Cityscapes/09_Cityscapes_IM.py / 11_Cityscapes_IM+.py on a 5-class 48 x 96 toy set: non-square images, the CITYSCAPES
+    model / CSV prefix, and for IM+ the width schedule alpha = 1 -> 1.25 over two generations."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CITY_CONFIG.format(base=base))
+    gens = "0,1" if approach == "IM_plus" else "0"
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": gens, "IM_CANDIDATES": "0,1,2"}
+    subprocess.run([sys.executable, "-c", CITY_SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "Cityscapes", "03_Cityscapes_subset.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    models = sorted(os.listdir(base / "models"))
+    # 3 candidates, TOP_Ks = 2: two renamed, the third keeps its candidate name (03_Cityscapes_subset.py top-K rename)
+    assert [m for m in models if "topK" in m] == ["CITYSCAPES_subset_1_topK_1.h5", "CITYSCAPES_subset_1_topK_2.h5"]
+    assert len(models) == 3
+    rows = (base / "csv" / "results_CITYSCAPES_subset_1.csv").read_text().strip().splitlines()
+    assert rows[0] == "modelname;mPA_val;mPA_test;mPA_train_unlabeled;mIoU_val;mIoU_test;mIoU_train_unlabeled" and len(rows) == 4
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "Cityscapes", script)], env=env, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    models = sorted(os.listdir(base / "models"))
+    for g in gens.split(","):
+        stem = f"CITYSCAPES_{approach}_1_n2_gen{g}_e0_d0_bi_True_bo_True"
+        assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+        res = (base / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+        assert len(res) == 4 and all(0.0 <= float(v) <= 1.0 for v in res[1].split(";")[1:])
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    stem0 = f"CITYSCAPES_{approach}_1_n2_gen0_e0_d0_bi_True_bo_True"
+    sub = ("temp",) if approach == "IM_plus" else ()
+    unl = base.joinpath("train_unlabeled_predictions", approach, *sub, stem0)
+    assert len(os.listdir(unl / "im")) == 24
+    m = F.read_png(str(unl / "masks" / sorted(os.listdir(unl / "masks"))[0]), 1)
+    assert m.shape[:2] == (48, 96) and set(np.unique(m)) <= {0, 1, 2, 3, 4}
+    if approach == "IM_plus":
+        m0 = F.load_model(str(base / "models" / (stem0 + "_topK_1.h5")))
+        m1 = F.load_model(str(base / "models" / (stem0.replace("gen0", "gen1") + "_topK_1.h5")))
+        assert (m0.plan.alpha, m1.plan.alpha) == (1.0, 1.25)
+
+
+REF_STYLE_SCRIPT = """
+# a per-dataset script written the way the reference's are (ISIC_2018/09_ISIC_2018_IM.py:1-153): top-level module names,
+# TensorFlow touched through tf.device / load_model / clear_session / set_global_policy only, positional calls
+import sys, os, gc
+from functions import train_ISIC_2018, create_pseudo_labels_im_ISIC_2018, dice_loss
+from unet import get_unet
+import tensorflow as tf
+from tensorflow.keras import mixed_precision
+import paths
+mixed_precision.set_global_policy('mixed_float16')
+H = W = 64
+with tf.device('/gpu:0'):
+    files = [os.path.join(paths.ISIC_2018_MODEL_DIR, f'ISIC_2018_subset_1_topK_{j}.h5') for j in (1, 2)]
+    best_models = [tf.keras.models.load_model(f, custom_objects={'dice_loss': dice_loss}) for f in files]
+    out = os.path.join(paths.ISIC_2018_BASE_DIR, 'train_unlabeled_predictions', 'IM', 'ref_style')
+    mean_im = create_pseudo_labels_im_ISIC_2018(best_models, H, W, 3, paths.ISIC_2018_TRAIN_UNLABELED_IMAGES_DIR, out, True, 0, 0, True, True, False)
+    model = get_unet(H, W, 3, 1, 0.5, 'relu', 'sigmoid')
+    res = train_ISIC_2018(os.path.join(out, 'images'), paths.ISIC_2018_VAL_IMAGES_DIR, paths.ISIC_2018_VAL_MASKS_DIR,
+                          paths.ISIC_2018_TEST_IMAGES_DIR, paths.ISIC_2018_TEST_MASKS_DIR,
+                          paths.ISIC_2018_TRAIN_UNLABELED_IMAGES_DIR, paths.ISIC_2018_TRAIN_UNLABELED_MASKS_DIR,
+                          'ref_style_0', os.path.join(paths.ISIC_2018_MODEL_DIR, 'ref_style_0.h5'), model, 'mse',
+                          max(len(os.listdir(os.path.join(out, 'images'))) // 8, 1), H, W, 3,
+                          os.path.join(out, 'val_pred'), os.path.join(out, 'test_pred'), os.path.join(out, 'unl_pred'))
+    del model
+    tf.keras.backend.clear_session()
+    gc.collect()
+print('RESULT', mean_im, len(res))
+"""
+
+
+def test_reference_style_script_with_compat_namespace(tmp_path):
+    """ISIC_2018/03_ISIC_2018_subset.py produces the gen-0 ensemble from the labelled subset; then a script in the
+    reference's own style (`from functions import ...`, `import tensorflow as tf`) runs against the top-level shims and
+    inconsistencymasks_amd/compat."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CONFIG.format(base=base))
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_CANDIDATES": "0,1,2",
+           "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "inconsistencymasks_amd", "compat")])}
+    setup = SETUP.format(root=ROOT).split("import torch\nx = torch.from_numpy")[0]      # the data only, no fabricated models
+    subprocess.run([sys.executable, "-c", setup], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "03_ISIC_2018_subset.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert {"ISIC_2018_subset_1_topK_1.h5", "ISIC_2018_subset_1_topK_2.h5"} <= set(os.listdir(base / "models"))
+    script = tmp_path / "ref_style.py"
+    script.write_text(REF_STYLE_SCRIPT)
+    r = subprocess.run([sys.executable, str(script)], env=env, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) >= 0 and int(line[2]) == 6
+    assert os.path.exists(base / "models" / "ref_style_0.h5")

@@ -81,16 +81,34 @@ def test_inference_parity(UNet, name):
     m.load_state_dict(sd)
     x, _, _ = make_input(cfg)
     from inconsistencymasks_amd._lib import lib
-    lib.imk_debug_materialize(1)            # keep the on-chip intermediates of fused kernels for the per-layer check
-    probs = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
-    lib.imk_debug_materialize(0)
-    assert np.array_equal(probs, m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy())   # same result without
+    xd = torch.from_numpy(x).cuda()
     taps = {}
     ref = U.forward(sd, x, cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], emulate_fp16=True, taps=taps).numpy()
+    # (1) the stored path: imk_debug_materialize(1) keeps the on-chip intermediates of fused kernels (and the input block's
+    #     output), so every layer can be compared
+    lib.imk_debug_materialize(1)
+    try:
+        probs_stored = m.predict_device(xd).cpu().numpy()
+        for l in m.plan.layers:
+            if l["kind"] == 0 and l["name"] != "out":
+                got = m.intermediate(l["name"], cfg["b"], 0).numpy()
+                assert rel_l2(got, taps[l["name"]].numpy()) <= 1e-2, l["name"]
+    finally:
+        lib.imk_debug_materialize(0)
+    # (2) the default path -- what bench.py and the writers run: the input block is computed on load by the first encoder
+    #     conv (LM_STEM) where the widths allow it, Conv3x3 -> Conv1x1 pairs are chained.  Every tensor this path still
+    #     stores (the block outputs *.c1 and the decoder's *.ca) is compared layer by layer, too.
+    probs = m.predict_device(xd).cpu().numpy()
     for l in m.plan.layers:
-        if l["kind"] == 0 and l["name"] != "out":
+        if l["kind"] == 0 and (l["name"].endswith(".c1") or l["name"].endswith(".ca")):
             got = m.intermediate(l["name"], cfg["b"], 0).numpy()
-            assert rel_l2(got, taps[l["name"]].numpy()) <= 1e-2, l["name"]
+            assert rel_l2(got, taps[l["name"]].numpy()) <= 1e-2, "default path: " + l["name"]
+    stem_on_load = cfg["c"] <= 4 and int(16 * cfg["alpha"]) <= 16       # imk_conv_stem_fusable
+    if stem_on_load:    # same fp16 roundings, fp32 sums of <= 4 products in another order (test_fused_input_block_...)
+        assert np.abs(probs - probs_stored).max() <= 2e-3
+    else:               # only the chaining differs: the intermediate's fp16 rounding happens on chip, bit-identical
+        assert np.array_equal(probs, probs_stored)
+    assert np.abs(probs_stored - ref).max() <= 3e-2 and rel_l2(probs_stored, ref) <= 1e-2
     assert np.abs(probs - ref).max() <= 3e-2
     assert rel_l2(probs, ref) <= 1e-2
     if cfg["act"] == "softmax":
@@ -269,6 +287,11 @@ BASELINE_SHAPES = {   # BASELINE.json configs at their real sizes (config.ini:18
     "hela_256": dict(h=256, w=256, c=1, k=3, alpha=1.0, act="sigmoid", loss="mse", b=2),
     "suim_256": dict(h=256, w=256, c=3, k=9, alpha=1.0, act="softmax", loss="cce", b=2),
     "cityscapes_208x416": dict(h=208, w=416, c=3, k=35, alpha=1.0, act="softmax", loss="cce", b=2),
+    # BASELINE configs[3]: the Cityscapes IM+ width schedule alpha = 1 ... 2 (Cityscapes/11_Cityscapes_IM+.py:48), and the
+    # literal 512 x 256 of the config's name
+    "cityscapes_implus_a1.25": dict(h=208, w=416, c=3, k=35, alpha=1.25, act="softmax", loss="cce", b=2),
+    "cityscapes_implus_a2": dict(h=208, w=416, c=3, k=35, alpha=2.0, act="softmax", loss="cce", b=2),
+    "cityscapes_256x512": dict(h=256, w=512, c=3, k=35, alpha=1.0, act="softmax", loss="cce", b=2),
 }
 
 
@@ -295,6 +318,34 @@ def test_baseline_shapes_full_size(UNet, name):
     st = m.stats.cpu().numpy()
     assert st[1] == 0.0 and np.isfinite(st[0]), st
     assert not torch.equal(before, m.params) and bool(torch.isfinite(m.params).all())
+
+
+@pytest.mark.parametrize("alpha", [1.25, 1.5, 1.75, 2.0])
+def test_cityscapes_im_plus_schedule_batch32(UNet, alpha):
+    """The IM+ generations of BASELINE configs[3] at the reference's real size and batch: 208 x 416 x 3 -> 35 classes,
+    alpha growing per generation (Cityscapes/11_Cityscapes_IM+.py:48 ALPHAS), batch 32 (config.ini:8): the workspace fits,
+    a batch-32 forward is invariant to the batch composition, and training steps are finite and move the loss."""
+    h, w, k, b = 208, 416, 35, 32
+    m = UNet(h, w, 3, k, alpha, "softmax", seed=int(alpha * 100))
+    ws_train, ws_inf = m.plan.workspace_bytes(b, 1), m.plan.workspace_bytes(b, 0)
+    assert 0 < ws_inf < ws_train < 48 * 2 ** 30, (ws_inf, ws_train)       # a sixth of one MI355X's 288 GB at most
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = ((yy // 26) * 5 + xx // 84).astype(np.uint8) % k                     # a coarse class layout
+    y = np.broadcast_to(y, (b, h, w)).copy()
+    x = (y[..., None] * 7 + rng.integers(0, 30, (b, h, w, 3))).clip(0, 255).astype(np.uint8)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    full = m.predict_device(xd)
+    assert bool(torch.isfinite(full).all()) and torch.allclose(full.sum(-1), torch.ones_like(full[..., 0]), atol=1e-5)
+    assert torch.equal(m.predict_device(xd[5:9].contiguous()), full[5:9])
+    losses = []
+    for _ in range(12):
+        m.train_step(xd, yd, 1, 3e-3, 1e-4)
+        st = m.stats.cpu().numpy()
+        if st[1] == 0.0:
+            losses.append(float(st[0]))
+    assert len(losses) >= 8 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(m.params).all())
 
 
 @pytest.mark.parametrize("name", ["isic", "hela"])
