@@ -486,7 +486,8 @@ def main():
                                    "(configs[1])", "unlabeled_images": n_images, "unlabeled_images_per_gpu": U,
                        "labeled_images": U_LABELED if strong else U_LABELED * world,
                        "n_models": N_MODELS, "infer_batch": args.infer_batch, "train_batch_per_gpu": BATCH,
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", **info},
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                       **{k: v for k, v in info.items() if k != "n_train"}},
             "stage_ms": {"ensemble_infer_plus_im": round(t_inf, 2), "train_epoch": round(t_ep, 2)},
             "roofline": roofline,
             "im_kernel": im_kernel,
