@@ -154,13 +154,18 @@ IMK_API int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode,
                          int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
 /* Ensemble inference fused with the IM chain: N models' forward passes, then head -> threshold/argmax ->
- * agreement -> IM -> blocking.  One call = functions.py:2844-2887
- * minus file I/O, for a batch.  `params`/`packed` are arrays (host) of n_models device pointers.
+ * agreement -> IM -> blocking in ONE kernel that reads the N last decoder activations (fp16) and never writes the
+ * probability stack: the head's fp32 arithmetic is the same code as imk_unet_forward's, so the outputs are bit-identical
+ * to imk_unet_forward + imk_im_binary / imk_im_multiclass.  One call = functions.py:2844-2887 minus file I/O, for a batch.
+ * `params`/`packed` are arrays (host) of n_models device pointers.
  * binary heads (act_out = 0): outputs as imk_im_binary;  softmax heads: as imk_im_multiclass
  * (masks_out = final_out [B,H,W], pred_size unused, presence optional).
- * workspace: n_models * align256(B*H*W*n_out*4) for the probability stack + k * imk_unet_workspace_bytes(plan, B, 0),
- * 1 <= k <= min(n_models, 3): with k > 1 the models run on k streams side by side (forked from and joined to
- * `stream` with events; the call stays asynchronous), with k = 1 back to back.                          */
+ * workspace: imk_unet_forward_im_workspace_bytes(plan, n_models, B, k), 1 <= k <= min(n_models, 3): with k > 1 the models
+ * run on k streams side by side (forked from and joined to `stream` with events; the call stays asynchronous), with
+ * k = 1 back to back.  Shapes the fused kernel does not cover (sigmoid heads with more than 4 maps, H*W not a multiple
+ * of 16, more than 8 models) and imk_debug_materialize(1) take the unfused route through the fp32 probability stack
+ * (n_models * align256(B*H*W*n_out*4) + k * imk_unet_workspace_bytes(plan, B, 0) bytes are enough for that one).      */
+IMK_API int64_t imk_unet_forward_im_workspace_bytes(const imk_unet_plan *plan, int n_models, int batch, int n_streams);
 IMK_API int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
                         const float *const *params, const void *const *packed,
                         const uint8_t *x, int batch, float thr, int cmp_ge,

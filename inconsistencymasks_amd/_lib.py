@@ -53,6 +53,7 @@ SIGNATURES = {
     "imk_unet_tensor_info": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64),
                                      ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                      ctypes.POINTER(c_int)]),
+    "imk_unet_forward_im_workspace_bytes": (c_int64, [c_void_p, c_int, c_int, c_int]),
     "imk_unet_forward_im": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                     c_void_p, c_int, c_float, c_int, c_void_p, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // =====================================================================================================
 // wgrad
 // =====================================================================================================
-constexpr int WG_STRIDE_H = 24;  // halfs per pixel in the wgrad LDS slices (16 channels + 8 pad = 48 B; a 32-byte pitch measured the same)
+constexpr int WG_STRIDE_H = 16;  // halfs per pixel in the wgrad LDS slices: 16 channels = 32 B, unpadded on purpose -- a 32-lane half
+                                 // of a transposed read covers 8 CONSECUTIVE pixels = one contiguous 256-B bank row (conflict-free)
 
 // LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
 // tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
@@ -936,11 +937,16 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
         for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 2 * (wave + 4 * kk);          // tile rows r0, r0+1 form this k-step's 32 pixels
             const int row = r0 + (g >> 1);
-            const int xx = 8 * (g & 1) + qq;             // +4h
+            // k-slot <-> pixel map (any bijection works as long as both operands use it): lane group g's elements 0-3 are
+            // pixels x = 4(g&1) + 0..3 and elements 4-7 the pixels 8 further right.  The two groups of a 32-lane half then
+            // read 8 consecutive pixels of one row = 256 contiguous bytes = every LDS bank once (the previous map,
+            // x = 8(g&1) + 0..3 at a 48-byte pitch, put two pixels of a half on the same banks: SQ_LDS_BANK_CONFLICT equal to
+            // SQ_ACTIVE_INST_LDS in profiles/r01_sq_counters.csv).
+            const int xx = 4 * (g & 1) + qq;             // +8 for the second read
             // B operand: dA[pixel][co]
             const f16 *pb = s_d + (row * 16 + xx) * WG_STRIDE_H + 4 * pp;
             const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
-            const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 4 * WG_STRIDE_H));
+            const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 8 * WG_STRIDE_H));
             f16x8 bf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { bf[e] = (f16)b0[e]; bf[4 + e] = (f16)b1[e]; }
@@ -951,7 +957,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
                     const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap % 3 : 0;
                     const f16 *p = pa + (ty * WT + tx) * WG_STRIDE_H;
                     const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p));
-                    const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p + 4 * WG_STRIDE_H));
+                    const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p + 8 * WG_STRIDE_H));
                     f16x8 af;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { af[e] = (f16)a0[e]; af[4 + e] = (f16)a1[e]; }

@@ -6,6 +6,7 @@
 // (ISIC_2018/09_ISIC_2018_IM.py:110, SUIM/10_SUIM_IM.py:114); tfa AdamW functions.py:215;
 // Keras LossScaleOptimizer (dynamic loss scaling under mixed_float16).
 #include "imk_elem.h"
+#include "imk_head.h"
 
 namespace {
 
@@ -343,47 +344,21 @@ __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, co
                                                    const float *__restrict__ sh, const float *__restrict__ w /*[cin][K]*/,
                                                    const float *__restrict__ bias, int cin, int K, int softmax,
                                                    long long n_pix, float *__restrict__ probs) {
-    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS], then out[256][K | 1]
-    float *s_b = s_w + K * CS, *s_sc = s_b + K, *s_sh = s_sc + CS, *s_out = s_sh + CS;
+    extern __shared__ float s_w[];  // [K][CS] transposed, then bias[K], sc[CS], sh[CS] (imk_head.h), then out[256][K | 1]
+    float *s_out = s_w + head_lds_floats<CS>(K);
     const int pitch = K | 1;
-    for (int i = threadIdx.x; i < K * CS; i += 256) {
-        const int k = i / CS, c = i - k * CS;
-        s_w[i] = (c < cin) ? w[(size_t)c * K + k] : 0.f;
-    }
-    for (int i = threadIdx.x; i < K; i += 256) s_b[i] = bias[i];
-    for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
+    head_stage<CS>(w, bias, sc, sh, cin, K, s_w);
     __syncthreads();
     const long long p0 = (long long)blockIdx.x * 256;
     const long long p = p0 + threadIdx.x;
     float *row = s_out + threadIdx.x * pitch;
     if (p < n_pix) {
         float xin[CS];
-#pragma unroll
-        for (int q = 0; q < CS / 8; ++q) {
-            const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
-        }
+        head_input<CS>(z, p, s_w, K, xin);
         if (!softmax) {
-            for (int k = 0; k < K; ++k) {
-                float acc = s_b[k];
-#pragma unroll
-                for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
-                row[k] = 1.0f / (1.0f + expf(-acc));
-            }
+            for (int k = 0; k < K; ++k) row[k] = head_sigmoid(head_logit<CS>(xin, s_w, K, k));
         } else {
-            float mx = -INFINITY;
-            for (int k = 0; k < K; ++k) {
-                float acc = s_b[k];
-#pragma unroll
-                for (int c = 0; c < CS; ++c) acc += xin[c] * s_w[k * CS + c];
-                row[k] = acc;
-                mx = fmaxf(mx, acc);
-            }
-            float sum = 0.f;
-            for (int k = 0; k < K; ++k) { const float e = expf(row[k] - mx); row[k] = e; sum += e; }
-            const float inv = 1.0f / sum;
-            for (int k = 0; k < K; ++k) row[k] *= inv;
+            head_softmax_row<CS>(xin, s_w, K, row);
         }
     }
     __syncthreads();
@@ -395,7 +370,6 @@ __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ z, co
     }
 }
 
-// ---- training: head + loss + gradient w.r.t. the logits in one pass ---------------------------------------------
 // Same arithmetic as head_kernel followed by loss_grad_kernel (same expressions in the same order, so the values are
 // bit-identical), without the [n_pix, K] fp32 probability tensor in between: the logits are recomputed per pass
 // (K * CS FMAs) instead of being parked in HBM.

@@ -11,6 +11,7 @@
 // (3-channel images, 1-byte masks) still leave the CU as full 16-byte stores; one workgroup never
 // straddles two images so the per-image sizes need one integer atomic per workgroup and channel.
 #include "imk_common.h"
+#include "imk_head.h"
 
 namespace {
 
@@ -262,6 +263,185 @@ __global__ __launch_bounds__(256) void im_multi_kernel(
     }
 }
 
+// ---- head + IM in one pass (ensemble inference: imk_unet_forward_im) ------------------------------------------------
+// The probability stack [N,B,H,W,K] fp32 never exists: every model's output layer (BatchNorm on load, fp32 1x1 conv,
+// sigmoid / softmax -- the arithmetic of head_kernel, imk_head.h) is evaluated per pixel in registers / LDS and goes
+// straight into the vote.  Per pixel it reads N x cs fp16 + the image and writes image + label map(s) + IM:
+// ISIC 2 x 16 + 3 B in, 5 B out (SURVEY 8d's fused figure) instead of 8 + 3 in / 5 out behind 2 x (16 in, 4 out).
+// A workgroup never straddles two images.  Sigmoid heads: 4 consecutive pixels per thread (1024 per workgroup), all
+// N x 4 activation loads of a thread issued before the first use; softmax heads: one pixel per thread (the K
+// probabilities of a pixel live in an LDS row).
+template <int NF>
+__device__ __forceinline__ void head_im_finish(const ImkHeadImArgs &a, const uint8_t (*s_final)[BIN_CHUNK], const uint8_t *s_im,
+                                               int *s_cnt, const int *cnt_a, const int *cnt_m, bool count_fg, int b, int p_base,
+                                               int n_px, int vec_out, int vec_img) {
+    const int t = threadIdx.x, hw = a.hw;
+    // per-image sizes: wave reduction, one LDS atomic per wave, one global atomic per workgroup
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        int fa = cnt_a[k], fm = cnt_m[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fa += __shfl_xor(fa, o, 64); fm += __shfl_xor(fm, o, 64); }
+        if ((t & 63) == 0) { if (fa) atomicAdd(&s_cnt[2 * k], fa); if (fm) atomicAdd(&s_cnt[2 * k + 1], fm); }
+    }
+    __syncthreads();
+    if (t < NF) {
+        auto *ims = reinterpret_cast<unsigned long long *>(a.im_size), *pss = reinterpret_cast<unsigned long long *>(a.pred_size);
+        if (count_fg && s_cnt[2 * t]) atomicAdd(&pss[(size_t)b * NF + t], (unsigned long long)s_cnt[2 * t]);
+        if (s_cnt[2 * t + 1]) atomicAdd(&ims[(size_t)b * NF + t], (unsigned long long)s_cnt[2 * t + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+        store_bytes<BIN_CHUNK>(a.masks_out + ((size_t)b * NF + k) * hw + p_base, s_final[k], n_px, vec_out);
+    store_bytes<BIN_CHUNK>(a.im_out + (size_t)b * hw + p_base, s_im, n_px, vec_out);
+    if (a.img) {
+        const size_t off = ((size_t)b * hw + p_base) * a.c;
+        block_image(a.img + off, a.img_out + off, s_im, n_px, a.c, a.block_in, vec_img);
+    }
+}
+
+template <int CS, int KB, int NM /* models, compile-time (0: run-time) */>
+__global__ __launch_bounds__(256) void head_im_sigmoid_kernel(ImkHeadImArgs a, int vec_out, int vec_img) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // N x head image (imk_head.h)
+    __shared__ __attribute__((aligned(16))) uint8_t s_final[KB][BIN_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_im[BIN_CHUNK];
+    __shared__ int s_cnt[2 * KB];
+    const int K = a.K, hw = a.hw;
+    const int n_models = NM > 0 ? NM : a.n_models;
+    const int per_model = head_lds_floats<CS>(K);
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int p_base = blockIdx.x * BIN_CHUNK;
+    const int n_px = min(BIN_CHUNK, hw - p_base);
+    for (int n = 0; n < n_models; ++n) head_stage<CS>(a.w[n], a.bias[n], a.sc[n], a.sh[n], a.cin, K, s_dyn + n * per_model);
+    if (t < 2 * KB) s_cnt[t] = 0;
+    int cnt_a[KB], cnt_m[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) cnt_a[k] = cnt_m[k] = 0;
+    const int p0 = 4 * t;                                   // hw % 16 == 0: a thread's 4 pixels are all in or all out
+    const long long p = (long long)b * hw + p_base + p0;
+    constexpr int NMR = NM > 0 ? NM : 1;
+    f16x8 raw[NMR][4][CS / 8];
+    if (NM > 0 && p0 < n_px) {                               // every activation load of this thread goes out first
+#pragma unroll
+        for (int n = 0; n < NMR; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < CS / 8; ++q) raw[n][j][q] = *reinterpret_cast<const f16x8 *>(a.z[n] + (p + j) * CS + q * 8);
+    }
+    __syncthreads();                                         // head images staged
+    if (p0 < n_px) {
+        int votes[4][KB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) votes[j][k] = 0;
+        auto vote = [&](const float *hw_n, const f16x8 (&r)[CS / 8], int j) {
+            const float *s_sc = hw_n + K * CS + K, *s_sh = s_sc + CS;
+            float xin[CS];
+#pragma unroll
+            for (int q = 0; q < CS / 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xin[q * 8 + e] = (float)(f16)((float)r[q][e] * s_sc[q * 8 + e] + s_sh[q * 8 + e]);   // = head_input
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const float v = head_sigmoid(head_logit<CS>(xin, hw_n, K, k));
+                votes[j][k] += (a.cmp_ge ? (v >= a.thr) : (v > a.thr)) ? 1 : 0;      // NaN compares false
+            }
+        };
+        if constexpr (NM > 0) {
+#pragma unroll
+            for (int n = 0; n < NMR; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vote(s_dyn + n * per_model, raw[n][j], j);
+        } else {
+            for (int n = 0; n < n_models; ++n) {
+                f16x8 r[4][CS / 8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < CS / 8; ++q) r[j][q] = *reinterpret_cast<const f16x8 *>(a.z[n] + (p + j) * CS + q * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vote(s_dyn + n * per_model, r[j], j);
+            }
+        }
+        uint32_t fin[KB], im4 = 0;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) fin[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool any = false, fg[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                fg[k] = votes[j][k] == n_models;
+                const bool mx = votes[j][k] != 0 && !fg[k];
+                cnt_a[k] += fg[k]; cnt_m[k] += mx;
+                any |= mx;
+            }
+            if (any) im4 |= 0xffu << (8 * j);
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (fg[k] && !(a.block_out && any)) fin[k] |= 0xffu << (8 * j);
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) *reinterpret_cast<uint32_t *>(&s_final[k][p0]) = fin[k];
+        *reinterpret_cast<uint32_t *>(&s_im[p0]) = im4;
+    }
+    __syncthreads();
+    head_im_finish<KB>(a, s_final, s_im, s_cnt, cnt_a, cnt_m, true, b, p_base, n_px, vec_out, vec_img);
+}
+
+template <int CS>
+__global__ __launch_bounds__(256) void head_im_softmax_kernel(ImkHeadImArgs a, int vec_out, int vec_img) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // N x head image (imk_head.h), then rows [256][K | 1]
+    __shared__ __attribute__((aligned(16))) uint8_t s_final[1][BIN_CHUNK];   // MC_CHUNK bytes used
+    __shared__ __attribute__((aligned(16))) uint8_t s_im[BIN_CHUNK];
+    __shared__ uint32_t s_pres[64];
+    __shared__ int s_cnt[2];
+    const int K = a.K, hw = a.hw;
+    const int per_model = head_lds_floats<CS>(K);
+    float *s_rows = s_dyn + a.n_models * per_model;
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int p_base = blockIdx.x * MC_CHUNK;
+    const int n_px = min(MC_CHUNK, hw - p_base);
+    for (int n = 0; n < a.n_models; ++n) head_stage<CS>(a.w[n], a.bias[n], a.sc[n], a.sh[n], a.cin, K, s_dyn + n * per_model);
+    if (t < 2) s_cnt[t] = 0;
+    const long long p = (long long)b * hw + p_base + t;
+    const bool live = t < n_px;
+    int cnt_a[1] = {0}, cnt_m[1] = {0};
+    int label0 = 0;
+    bool agree = true;
+    float *row = s_rows + t * (K | 1);
+    for (int n = 0; n < a.n_models; ++n) {
+        if (t < 64) s_pres[t] = 0;
+        __syncthreads();                 // (first pass: the head images are staged, too)
+        if (live) {
+            float xin[CS];
+            const float *hw_n = s_dyn + n * per_model;
+            head_input<CS>(a.z[n], p, hw_n, K, xin);
+            head_softmax_row<CS>(xin, hw_n, K, row);
+            int best = 0;
+            float bv = row[0];
+            for (int k = 1; k < K; ++k) {        // strict >: the lowest index wins ties, like numpy's argmax
+                const float v = row[k];
+                if (v > bv) { bv = v; best = k; }
+            }
+            s_pres[best] = 1;
+            if (n == 0) label0 = best; else agree = agree && (best == label0);
+        }
+        __syncthreads();
+        if (a.presence && t < K && s_pres[t]) a.presence[((size_t)n * a.batch + b) * K + t] = 1;
+    }
+    if (live) {
+        const uint8_t im = agree ? 0 : 255;
+        s_im[t] = im;
+        s_final[0][t] = (agree && !(a.block_out && im)) ? (uint8_t)label0 : 0;
+        cnt_m[0] = agree ? 0 : 1;
+    }
+    __syncthreads();
+    head_im_finish<1>(a, s_final, s_im, s_cnt, cnt_a, cnt_m, false, b, p_base, n_px, vec_out, vec_img);
+}
+
 // ---- morphology + late blocking (cold path: EK = DK = 0 in every shipped config) ------------------
 __global__ __launch_bounds__(256) void morph_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                     int h, int w, int ksize, int op) {
@@ -300,6 +480,75 @@ __global__ __launch_bounds__(256) void block_apply_kernel(const uint8_t *__restr
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+static size_t head_im_lds(const ImkHeadImArgs &a) {
+    return ((size_t)a.n_models * (a.K * a.cs + a.K + 2 * a.cs) + (a.softmax ? (size_t)MC_CHUNK * (a.K | 1) : 0)) * sizeof(float);
+}
+
+bool imk_head_im_supported(const ImkHeadImArgs &a) {
+    if (a.n_models < 1 || a.n_models > IMK_HEAD_IM_MAX_MODELS) return false;
+    if (a.softmax ? a.K > 64 : a.K > 4) return false;
+    if (a.cs != 8 && a.cs != 16 && a.cs != 24 && a.cs != 32) return false;
+    if (a.hw % 16 != 0 || !aligned16(a.masks_out) || !aligned16(a.im_out)) return false;   // odd sizes: unfused path
+    return head_im_lds(a) <= 150 * 1024;
+}
+
+int imk_launch_head_im(const ImkHeadImArgs &a, hipStream_t stream) {
+    IMK_CHECK_ARG(a.n_models > 0 && a.batch > 0 && a.hw > 0 && a.K > 0);
+    IMK_CHECK_ARG(a.masks_out && a.im_out && a.im_size && (a.softmax || a.pred_size));
+    IMK_CHECK_ARG(!a.img || (a.img_out && a.c > 0));
+    if (!imk_head_im_supported(a)) return IMK_EUNSUPPORTED;
+    const int nf = a.softmax ? 1 : a.K;
+    IMK_HIP(hipMemsetAsync(a.im_size, 0, sizeof(int64_t) * a.batch * nf, stream));
+    if (a.pred_size) IMK_HIP(hipMemsetAsync(a.pred_size, 0, sizeof(int64_t) * a.batch * nf, stream));
+    if (a.softmax && a.presence) IMK_HIP(hipMemsetAsync(a.presence, 0, (size_t)a.n_models * a.batch * a.K, stream));
+    const size_t lds = head_im_lds(a);
+    const int chunk = a.softmax ? MC_CHUNK : BIN_CHUNK;
+    const int vec_img2 = a.img && ((int64_t)a.hw * a.c % 16 == 0) && (chunk * a.c % 16 == 0) && aligned16(a.img) && aligned16(a.img_out);
+    const dim3 grid(imk_cdiv(a.hw, chunk), a.batch);
+    // algorithmic bytes: N last activations + image read, image + label map(s) + IM written
+    ImkProfScope prof(PF_IM, (double)a.batch * a.hw * ((double)a.n_models * a.cs * 2 + (a.img ? 2.0 * a.c : 0.0) + nf + 1), stream);
+#define IMK_HIM_LAUNCH(KERN)                                                                                                \
+    do {                                                                                                                    \
+        if (lds > 64 * 1024)                                                                                                \
+            IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        KERN<<<grid, 256, lds, stream>>>(a, 1, vec_img2);                                                                   \
+    } while (0)
+    if (a.softmax) {
+        switch (a.cs) {
+            case 8: IMK_HIM_LAUNCH(head_im_softmax_kernel<8>); break;
+            case 16: IMK_HIM_LAUNCH(head_im_softmax_kernel<16>); break;
+            case 24: IMK_HIM_LAUNCH(head_im_softmax_kernel<24>); break;
+            default: IMK_HIM_LAUNCH(head_im_softmax_kernel<32>); break;
+        }
+    } else {
+        // the reference's ensembles have 2-4 members: 2 and 3 get all their loads hoisted (compile-time N)
+#define IMK_HIM_SIG(CSV, KBV)                                                                                               \
+        do {                                                                                                                \
+            if (a.n_models == 2 && CSV <= 16) IMK_HIM_LAUNCH((head_im_sigmoid_kernel<CSV, KBV, 2>));                        \
+            else if (a.n_models == 3 && CSV <= 8) IMK_HIM_LAUNCH((head_im_sigmoid_kernel<CSV, KBV, 3>));                    \
+            else IMK_HIM_LAUNCH((head_im_sigmoid_kernel<CSV, KBV, 0>));                                                     \
+        } while (0)
+#define IMK_HIM_KB(CSV)                                                                                                     \
+        switch (a.K) {                                                                                                      \
+            case 1: IMK_HIM_SIG(CSV, 1); break;                                                                             \
+            case 2: IMK_HIM_SIG(CSV, 2); break;                                                                             \
+            case 3: IMK_HIM_SIG(CSV, 3); break;                                                                             \
+            default: IMK_HIM_SIG(CSV, 4); break;                                                                            \
+        }
+        switch (a.cs) {
+            case 8: IMK_HIM_KB(8); break;
+            case 16: IMK_HIM_KB(16); break;
+            case 24: IMK_HIM_KB(24); break;
+            default: IMK_HIM_KB(32); break;
+        }
+#undef IMK_HIM_KB
+#undef IMK_HIM_SIG
+    }
+#undef IMK_HIM_LAUNCH
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
 
 extern "C" int imk_im_binary(const float *preds, int n_models, int batch, int h, int w, int kb,
                              float thr, int cmp_ge, const uint8_t *img, int c, int block_in, int block_out,

@@ -146,7 +146,9 @@ struct Ctx {
     bool train;
     hipStream_t stream;
     const uint8_t *x_in[2] = {nullptr, nullptr};   // the uint8 network inputs (U-Net: [0] only)
-    f16 *act(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].out); }
+    int ovr_conv = -1;    // ensemble inference: this conv's output lives outside the (shared) activation workspace ...
+    f16 *ovr_out = nullptr;   // ... here, so that it survives until the fused head + IM kernel has read every model's
+    f16 *act(int conv) const { return conv == ovr_conv ? ovr_out : reinterpret_cast<f16 *>(base + ws.L[conv].out); }
     f16 *dA(int conv) const { return reinterpret_cast<f16 *>(base + ws.L[conv].dA); }
     f16 *dy(int bn) const { return reinterpret_cast<f16 *>(base + ws.L[bn].dy); }
     const float *bn_scale(int bn) const {

@@ -3,6 +3,7 @@
 // (forward with batch statistics, loss, backward, AdamW).  The layer-level helpers are shared with EvalNet (imk_net.h).
 // Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
 #include "imk_net.h"
+#include "imk_head.h"
 
 bool g_imk_materialize = false;
 bool g_imk_single_stream = false;
@@ -250,7 +251,21 @@ extern "C" int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mo
     return IMK_OK;
 }
 
-// Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
+// Ensemble inference + IM.  Workspace: n_models head slabs, then one activation workspace per concurrent stream.  A head
+// slab holds what the IM stage reads of one model: its last decoder activation [B,H,W,cs] fp16 (fused head + IM kernel,
+// the default) or its fp32 probabilities [B,H,W,K] (unfused: head_kernel per model + imk_im_*; taken for shapes the fused
+// kernel does not cover, under imk_debug_materialize(1), and when the caller sized the slabs for probabilities only).
+static size_t head_slab_bytes(const imk_unet_plan *plan, int batch, bool fused) {
+    const imk_unet_cfg &cf = plan->cfg;
+    const size_t px = (size_t)batch * cf.h * cf.w;
+    const size_t probs = px * cf.n_out * sizeof(float), zlast = px * imk_pad8(cf.ch[0]) * sizeof(f16);
+    return up(fused && zlast > probs ? zlast : probs);
+}
+
+extern "C" int64_t imk_unet_forward_im_workspace_bytes(const imk_unet_plan *plan, int n_models, int batch, int n_streams) {
+    if (!plan || plan->net != 0 || n_models <= 0 || batch <= 0 || n_streams <= 0) return IMK_EINVAL;
+    return (int64_t)(head_slab_bytes(plan, batch, true) * n_models + make_ws(plan, batch, 0).total * n_streams);
+}
 
 extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, const float *const *params,
                                    const void *const *packed, const uint8_t *x, int batch, float thr, int cmp_ge,
@@ -259,17 +274,27 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
                                    void *workspace, int64_t workspace_bytes, void *stream_) {
     IMK_CHECK_ARG(plan && params && packed && x && workspace && batch > 0 && n_models > 0);
     const imk_unet_cfg &cf = plan->cfg;
-    const size_t probs_one = up((size_t)batch * cf.h * cf.w * cf.n_out * sizeof(float));
     const Ws ws = make_ws(plan, batch, 0);
-    if ((int64_t)(probs_one * n_models + ws.total) > workspace_bytes) return IMK_EWORKSPACE;
-    // the probability stack must be contiguous [N,B,H,W,K]: only the last slab may be padded
+    const Topo topo = make_topo(plan);
+    // fused head + IM?  (the kernel's shape limits, and room for the activation slabs)
+    ImkHeadImArgs ha{};
+    ha.n_models = n_models; ha.cin = cf.ch[0]; ha.cs = imk_pad8(cf.ch[0]); ha.K = cf.n_out; ha.softmax = cf.act_out;
+    ha.batch = batch; ha.hw = cf.h * cf.w; ha.thr = thr; ha.cmp_ge = cmp_ge; ha.img = img; ha.c = cf.c_in;
+    ha.block_in = block_in; ha.block_out = block_out; ha.img_out = img_out; ha.masks_out = masks_out; ha.im_out = im_out;
+    ha.im_size = im_size; ha.pred_size = pred_size; ha.presence = presence;
+    static const bool fuse_off = []() { const char *e = getenv("IMK_HEAD_IM_FUSE"); return e && e[0] == '0'; }();
+    bool fused = !fuse_off && !g_imk_materialize && imk_head_im_supported(ha) &&
+                 (int64_t)(head_slab_bytes(plan, batch, true) * n_models + ws.total) <= workspace_bytes;
+    const size_t slab = head_slab_bytes(plan, batch, fused);
+    if ((int64_t)(slab * n_models + ws.total) > workspace_bytes) return IMK_EWORKSPACE;
+    // the unfused probability stack must be contiguous [N,B,H,W,K]: only the last slab may be padded
     const size_t probs_exact = (size_t)batch * cf.h * cf.w * cf.n_out * sizeof(float);
     uint8_t *base = (uint8_t *)workspace;
-    // The models are independent until the IM kernel: with room for one activation workspace per stream (the caller
-    // passes probs + k * imk_unet_workspace_bytes, k <= 1 + MAX_SIDE) they run on k streams side by side -- the deep
+    // The models are independent until the IM stage: with room for one activation workspace per stream (the caller
+    // passes slabs + k * imk_unet_workspace_bytes, k <= 1 + MAX_SIDE) they run on k streams side by side -- the deep
     // layers of one model fill the gaps of the other's.  With room for one only, they run back to back.
     const int max_streams = 1 + imk_unet_plan::MAX_SIDE;
-    int n_slabs = (int)(((size_t)workspace_bytes - probs_one * n_models) / ws.total);
+    int n_slabs = (int)(((size_t)workspace_bytes - slab * n_models) / ws.total);
     if (n_slabs > n_models) n_slabs = n_models;
     if (n_slabs > max_streams) n_slabs = max_streams;
     static const bool conc_off = []() { const char *e = getenv("IMK_ENSEMBLE_STREAMS"); return e && e[0] == '0'; }();
@@ -279,19 +304,27 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
         IMK_HIP(hipEventRecord(plan->ev_fork[0], main_stream));
         for (int s = 1; s < n_slabs; ++s) IMK_HIP(hipStreamWaitEvent(plan->side[s - 1], plan->ev_fork[0], 0));
     }
-    const Topo topo = make_topo(plan);
+    const ImkLayer &o = plan->layers[topo.out];
     for (int m = 0; m < n_models; ++m) {
         const int sl = m % n_slabs;
-        Ctx c{plan, ws, base + probs_one * n_models + ws.total * sl, params[m], (const uint8_t *)packed[m], batch, false,
+        Ctx c{plan, ws, base + slab * n_models + ws.total * sl, params[m], (const uint8_t *)packed[m], batch, false,
               sl == 0 ? main_stream : plan->side[sl - 1]};
         c.x_in[0] = x;
-        int rc = run_forward(c, topo, (float *)(base + probs_exact * m), nullptr);
+        if (fused) {    // the last decoder activation goes to the model's head slab; no head launch
+            c.ovr_conv = topo.d_c1[3];
+            c.ovr_out = reinterpret_cast<f16 *>(base + slab * m);
+            ha.z[m] = c.ovr_out;
+            ha.sc[m] = c.bn_scale(topo.d_bnb[3]); ha.sh[m] = c.bn_shift(topo.d_bnb[3]);
+            ha.w[m] = params[m] + o.off_w; ha.bias[m] = params[m] + o.off_b;
+        }
+        int rc = run_forward(c, topo, fused ? nullptr : (float *)(base + probs_exact * m), nullptr);
         if (rc) return rc;
     }
     for (int s = 1; s < n_slabs; ++s) {
         IMK_HIP(hipEventRecord(plan->ev_join[s - 1], plan->side[s - 1]));
         IMK_HIP(hipStreamWaitEvent(main_stream, plan->ev_join[s - 1], 0));
     }
+    if (fused) return imk_launch_head_im(ha, main_stream);
     if (cf.act_out == 0)
         return imk_im_binary((const float *)base, n_models, batch, cf.h, cf.w, cf.n_out, thr, cmp_ge, img, cf.c_in, block_in,
                              block_out, img_out, masks_out, im_out, im_size, pred_size, stream_);

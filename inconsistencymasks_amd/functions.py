@@ -188,9 +188,11 @@ class EnsembleIM:
         n = len(self.models)
         dev = x_u8.device
         if self._ws is None or self._ws_batch < b:
-            per = ((b * p.h * p.w * p.n_out * 4 + 255) // 256) * 256
             # one activation workspace per concurrently running model (imk_unet_forward_im puts up to 3 on streams)
-            self._ws = torch.empty(per * n + min(n, 3) * p.workspace_bytes(b, 0), dtype=torch.uint8, device=dev)
+            nbytes = lib.imk_unet_forward_im_workspace_bytes(p.ptr, n, b, min(n, 3))
+            if nbytes < 0:
+                check(int(nbytes), "imk_unet_forward_im_workspace_bytes")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._ws_batch = b
         binary = p.act_out == "sigmoid"
         kb = p.n_out if binary else 1
@@ -836,23 +838,44 @@ def get_min_dist(xy, positions):
 
 
 def _disc(img, cx, cy, r, value):
+    """cv2.circle(img, (cx, cy), r, value, -1): the filled circle of OpenCV's integer midpoint rasteriser (restated from
+    the published algorithm of imgproc's drawing code: horizontal spans cy +- dy: [cx - dx, cx + dx] and cy +- dx:
+    [cx - dy, cx + dy] while dx >= dy, error update err += 2 dy + 1, step dx inwards when err > 0), clipped to the image.
+    Not the Euclidean disc: r = 3 gives rows of 1, 5, 5, 7, 5, 5, 1 pixels.  Unpinned (needs OpenCV in the reference)."""
     h, w = img.shape[:2]
-    y0, y1, x0, x1 = max(cy - r, 0), min(cy + r, h - 1), max(cx - r, 0), min(cx + r, w - 1)
-    if y0 > y1 or x0 > x1:
-        return
-    yy, xx = np.mgrid[y0:y1 + 1, x0:x1 + 1]
-    img[y0:y1 + 1, x0:x1 + 1][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = value
+
+    def span(y, x0, x1):
+        if 0 <= y < h:
+            x0, x1 = max(x0, 0), min(x1, w - 1)
+            if x0 <= x1:
+                img[y, x0:x1 + 1] = value
+
+    err, dx, dy, plus, minus = 0, int(r), 0, 1, 2 * int(r) - 1
+    while dx >= dy:
+        span(cy - dy, cx - dx, cx + dx); span(cy + dy, cx - dx, cx + dx)
+        span(cy - dx, cx - dy, cx + dy); span(cy + dx, cx - dy, cx + dy)
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:
+            err -= minus
+            dx -= 1
+            minus -= 2
 
 
 def mod_pos_size(gray_img, max_pos_circle_size=8, min_pos_circle_size=3):
-    """functions.py:6255-6292: redraw every position blob as a disc of radius clamp(min_dist // 4, 3, 8)."""
+    """functions.py:6255-6292: redraw every position blob as a filled circle of radius clamp(min_dist // 4, 3, 8), then
+    `cv2.blur(out, (2, 2))` and `out[out < 254] = 0`: a pixel survives iff its whole 2x2 window (itself, left, upper,
+    upper-left neighbour; BORDER_REFLECT_101 at the image edge) is set."""
     positions = get_pos_contours(gray_img)
     out = np.zeros(gray_img.shape, np.uint8)
     for p in positions:
         r = int(get_min_dist(p, positions) // 4)
         r = max(min(r, max_pos_circle_size), min_pos_circle_size)
         _disc(out, p[0], p[1], r, 255)
-    return out
+    on = np.pad(out > 0, ((1, 0), (1, 0)), mode="reflect")            # row / column -1 -> row / column 1
+    keep = on[1:, 1:] & on[1:, :-1] & on[:-1, 1:] & on[:-1, :-1]
+    return np.where(keep, 255, 0).astype(np.uint8)
 
 
 def get_cell_count(positions, img_alive, img_dead, measuring_range=3):

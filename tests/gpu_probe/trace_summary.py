@@ -9,7 +9,8 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?"),
                  r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
-stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4")]          # uint8 stem: start of a forward
+# start of a forward: the uint8 stem (training) or the first encoder conv with the input block on load (inference, LM_STEM = 6)
+stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4") or r[2].startswith("conv_pipe_kernel<6")]
 folds = [i for i, r in enumerate(rows) if r[2].startswith("pack_conv_batched_kernel")]   # end of an optimizer step
 heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2]]                          # end of an inference call
 def show(seg, title):
@@ -41,4 +42,4 @@ infer = [(st, min(h for h in heads if h > st)) for st in stems if any(h > st for
          and not any(f > st and f < min(h for h in heads if h > st) for f in folds)]
 if len(infer) >= 2:
     st, en = infer[-2]
-    show(rows[st:en + 1], "inference call B=128 (second to last)")
+    show(rows[st:en + 1], "inference call (second to last)")

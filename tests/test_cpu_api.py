@@ -333,3 +333,51 @@ def test_color_tables_follow_the_public_palettes():
     assert c[(0, 0, 0)] == 0 and c[(0, 0, 128)] == 1 and c[(128, 128, 128)] == 7 and c[(0, 0, 64)] == 8
     assert c[(64, 0, 0)] == 32 and c[(64, 128, 0)] == 34 and c[(192, 192, 192)] == -1 and len(c) == 36
     assert len(color_mapping("SUIM", 3)) == 3          # toy configurations fall back to a generated palette
+
+
+def test_keras_checkpoint_converter_mapping(built_lib, tmp_path):
+    """tools/keras_h5_to_safetensors.py (runs offline where h5py exists): its layer table is the plan's, Keras'
+    auto-numbered layer names map to ours by creation order whatever the session's counter offset, HWIO kernels pass through
+    unchanged, and the `model.get_weights()`-order export round-trips through load_model."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import keras_h5_to_safetensors as K
+    import torch
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd.unet import Plan, UNet
+    from oracle import unet_oracle as U
+    for c, k, alpha in ((3, 1, 0.5), (1, 3, 1.0), (3, 35, 1.25)):
+        table = K.layer_table(c, k, alpha)
+        assert table == U.layer_table(c, k, alpha)
+        p = Plan(64, 64, c, k, alpha, "sigmoid")
+        assert [(l["name"], {0: "conv", 1: "bn"}[l["kind"]], l["ksize"], l["cin"], l["cout"]) for l in p.layers] == table
+    table = K.layer_table(3, 1, 0.5)
+    # a model built as the 3rd in a Keras session: conv2d_48 ... conv2d_70, batch_normalization_28 ... _41, 'out'
+    m = UNet(64, 64, 3, 1, 0.5, "sigmoid", seed=5, device="cpu")
+    sd = {kk: v.numpy() for kk, v in m.state_dict().items()}
+    weights_of, ci, bi = {}, 48, 28
+    for name, kind, *_ in table:
+        if kind == "conv":
+            kn = "out" if name == "out" else f"conv2d_{ci}"
+            ci += name != "out"
+            weights_of[kn] = {"kernel": sd[name + ".w"], "bias": sd[name + ".b"]}
+        else:
+            weights_of[f"batch_normalization_{bi}"] = {"gamma": sd[name + ".gamma"], "beta": sd[name + ".beta"],
+                                                       "moving_mean": sd[name + ".mean"], "moving_variance": sd[name + ".var"]}
+            bi += 1
+    names = K.match_keras_layers(list(weights_of), table)
+    assert names["in.c"] == "conv2d_48" and names["e1.c3"] == "conv2d_49" and names["d9.c1"] == "conv2d_70" and names["out"] == "out"
+    assert names["in.bn"] == "batch_normalization_28" and names["d9.bnb"] == "batch_normalization_41"
+    back = K.state_dict_from_keras(weights_of, table)
+    assert set(back) == set(sd) and all(np.array_equal(back[kk], sd[kk]) for kk in sd)
+    assert K.infer_config(sd["in.c.w"].shape, sd["out.w"].shape) == (3, 1, 0.5)
+    with pytest.raises(ValueError):
+        K.match_keras_layers([n for n in weights_of if n != "conv2d_60"], table)
+    # safetensors -> get_weights() order -> safetensors, through the CLI and load_model
+    src, npz, dst = str(tmp_path / "a.h5"), str(tmp_path / "w.npz"), str(tmp_path / "b.h5")
+    F.save_model(m, src)
+    assert K.main(["--to-keras-npz", src, npz]) == 0
+    d = np.load(npz)
+    assert len(d.files) == 2 * 24 + 4 * 14 and d["w000"].shape == (1, 1, 3, 8)       # Keras: kernel, bias, gamma, beta, mean, var ...
+    assert K.main(["--from-keras-npz", npz, dst, "--height", "64", "--width", "64", "--act-out", "sigmoid"]) == 0
+    m2 = F.load_model(dst, device="cpu")
+    assert torch.equal(m2.params, m.params) and (m2.plan.alpha, m2.plan.act_out) == (0.5, "sigmoid")

@@ -253,13 +253,27 @@ def test_overflow_skips_step_and_halves_scale(UNet):
     assert scale == 2.0 ** 39
 
 
-def test_ensemble_forward_im_matches_unfused(UNet):
+ENSEMBLE_CASES = {   # name -> (config, number of models)
+    "isic": (CFGS["isic"], 3), "suim": (CFGS["suim"], 3), "hela": (CFGS["hela"], 3), "odd_k35": (CFGS["odd"], 2),
+    "isic_256_n2": (dict(h=256, w=256, c=3, k=1, alpha=0.5, act="sigmoid", loss="mse", b=5), 2),
+    "isic_n4": (dict(CFGS["isic"], b=3), 4),
+    "cityscapes_208x416": (dict(h=208, w=416, c=3, k=35, alpha=1.0, act="softmax", loss="cce", b=2), 2),
+}
+
+
+@pytest.mark.parametrize("case", list(ENSEMBLE_CASES))
+def test_ensemble_forward_im_matches_unfused(UNet, case):
+    """imk_unet_forward_im (the head evaluated inside the IM kernel, no probability stack) against imk_unet_forward's
+    probabilities pushed through the oracle's IM chain: every output bit-identical, i.e. the fused kernel computes the very
+    same fp32 probabilities as head_kernel and votes on them like functions.py:3104-3137, 3157, 3187, 3225."""
     from inconsistencymasks_amd import functions as F
     from inconsistencymasks_amd import im as imk_im
     from oracle import im_oracle as O
-    for name in ("isic", "suim", "hela"):
-        cfg = CFGS[name]
-        models = [UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=50 + j) for j in range(3)]
+    for name, (cfg, n_models) in [(case, ENSEMBLE_CASES[case])]:
+        models = [UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=50 + j) for j in range(n_models)]
+        if case in ("isic_256_n2", "isic_n4"):      # decisive, disagreeing predictions instead of ~0.5 everywhere
+            for j, mm in enumerate(models):
+                mm.load_state_dict(randomize_bn(mm.state_dict(), 70 + j))
         x, _, _ = make_input(cfg, 51)
         xd = torch.from_numpy(x).cuda()
         r = F.EnsembleIM(models).run(xd, 0.5, name == "hela", True, True, want_presence=True)
@@ -280,6 +294,10 @@ def test_ensemble_forward_im_matches_unfused(UNet):
                 assert np.array_equal(r["presence"][:, i].cpu().numpy(), e["presence"])
             assert np.array_equal(r["im"][i].cpu().numpy(), e["im"])
             assert np.array_equal(r["img_out"][i].cpu().numpy(), eimg)
+        n_im = int(r["im_size"].sum())
+        assert n_im > 0
+        if case in ("isic_256_n2", "isic_n4"):
+            assert n_im < cfg["b"] * cfg["h"] * cfg["w"] and int(r["pred_size"].sum()) > 0    # neither all-agree nor all-differ
 
 
 BASELINE_SHAPES = {   # BASELINE.json configs at their real sizes (config.ini:18-26, 39-48, 61-69, 82-91 of the reference)
