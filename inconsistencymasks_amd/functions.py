@@ -89,6 +89,30 @@ def _pool():
     return ThreadPoolExecutor(max_workers=_IO_THREADS)
 
 
+# PNG encoding is the slowest part of a real generation (1.6 k images/s against 20 k images/s for the GPU stages), so file
+# writes are queued on a background pool and overlap with whatever comes next: the next batch's decode + GPU work inside a
+# writer, and -- for the prediction dumps of benchmark_*, which nothing in the pipeline reads back -- the next candidate's
+# training.  Writers flush before they return (callers list their output directories); everything is flushed at exit.
+_WRITE_POOL = None
+_PENDING = []
+
+
+def write_png_async(path, arr):
+    global _WRITE_POOL
+    if _WRITE_POOL is None:
+        import atexit
+        _WRITE_POOL = ThreadPoolExecutor(max_workers=_IO_THREADS)
+        atexit.register(flush_writes)
+    _PENDING.append(_WRITE_POOL.submit(write_png, path, arr))
+
+
+def flush_writes():
+    """wait for every queued PNG write (re-raising the first failure)"""
+    pending, _PENDING[:] = list(_PENDING), []
+    for f in pending:
+        f.result()
+
+
 # ---------------------------------------------------------------------------------------------------
 # IM cores (functions.py:3104-3238)
 # ---------------------------------------------------------------------------------------------------
@@ -320,7 +344,9 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
                     jobs.append((os.path.join(out_dirs["images"], name), img_np[j]))
                     jobs.append((os.path.join(out_dirs["masks"], name), m_np[j, 0]))
                 jobs.append((os.path.join(out_dirs["im"], name), im_np[j]))
-            list(pool.map(lambda a: write_png(*a), jobs))
+            for job in jobs:
+                write_png_async(*job)      # encoded while the next batch is decoded and run
+    flush_writes()
     tot_im, tot_n = _all_reduce_sum([sum_im, count])
     return round(tot_im / tot_n, 0) if tot_n else 0.0
 
@@ -596,6 +622,34 @@ def load_model(path, custom_objects=None, device="cuda"):
 
 _VAL_CACHE = {}   # (directories, file list) -> decoded validation set on the device: the monitor runs once per epoch
 
+# Decoded benchmark sets (images + ground truth of the val / test / unlabeled splits) stay on the device across the
+# candidates of a generation: every candidate is evaluated on the same three directories (functions.py:221-226), and
+# decoding them again costs more than evaluating them.  Keyed by the files' names, sizes and modification times; bounded
+# by IMK_DECODE_CACHE_GB (default 16 of the 288 GB; 0 switches it off).
+_DECODE_CACHE = {}
+_DECODE_CACHE_BYTES = int(float(os.environ.get("IMK_DECODE_CACHE_GB", 16)) * 2 ** 30)
+
+
+def _decoded_set(pool, dirs_and_channels, names):
+    """[(directory, channels)] x names -> list of uint8 device tensors [N,H,W,C] (one per directory), cached"""
+    def sig(d):
+        st = [os.stat(os.path.join(d, n)) for n in names]
+        return (d, tuple(names), sum(x.st_size for x in st), max((x.st_mtime_ns for x in st), default=0))
+    key = tuple((sig(d), c) for d, c in dirs_and_channels)
+    hit = _DECODE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    out = []
+    for d, c in dirs_and_channels:
+        arrs = list(pool.map(lambda n: read_png(os.path.join(d, n), c), names))
+        out.append(torch.from_numpy(np.stack(arrs, 0)).cuda())
+    nbytes = sum(t.numel() for t in out)
+    if 0 < nbytes <= _DECODE_CACHE_BYTES:
+        while _DECODE_CACHE and sum(sum(t.numel() for t in v) for v in _DECODE_CACHE.values()) + nbytes > _DECODE_CACHE_BYTES:
+            _DECODE_CACHE.pop(next(iter(_DECODE_CACHE)))
+        _DECODE_CACHE[key] = out
+    return out
+
 
 def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
     """Keras BinaryIoU(target_class_ids=[1], threshold=0.5) accumulated over the whole directory (the
@@ -625,16 +679,15 @@ def benchmark_ISIC2018(model, images_dir, masks_dir, pred_path, h, w, c, batch_s
     names = _bench_names(images_dir)
     ious, dices = [], []
     with _pool() as pool:
+        xs, gs = _decoded_set(pool, [(images_dir, c), (masks_dir, 1)], names) if names else (None, None)
         for i in range(0, len(names), batch_size):
             chunk = names[i:i + batch_size]
-            imgs = list(pool.map(lambda n: read_png(os.path.join(images_dir, n), c), chunk))
-            gts = list(pool.map(lambda n: read_png(os.path.join(masks_dir, n), 1)[..., 0], chunk))
-            probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda())
-            pred_d, counts = _ev.eval_binary(probs, torch.from_numpy(np.stack(gts, 0)).cuda(), 0.5, False,
-                                             want_pred=create_images)
-            if create_images:
+            probs = model.predict_device(xs[i:i + batch_size])
+            pred_d, counts = _ev.eval_binary(probs, gs[i:i + batch_size, ..., 0], 0.5, False, want_pred=create_images)
+            if create_images:      # prediction dumps: nothing reads them back, they are written in the background
                 pred = pred_d.cpu().numpy()
-                list(pool.map(lambda a: write_png(*a), [(os.path.join(pred_path, n), pred[j]) for j, n in enumerate(chunk)]))
+                for j, n in enumerate(chunk):
+                    write_png_async(os.path.join(pred_path, n), pred[j])
             for j, n in enumerate(chunk):
                 iou, dice = _ev.iou_dice_from_counts(counts[j])
                 d = round(float(dice), 4)
@@ -705,7 +758,7 @@ def convert_class_to_color_mask(class_mask, output_path, class_to_color_mapping)
     color = np.zeros(tuple(class_mask.shape) + (3,), dtype=np.uint8)
     for col, cls in class_to_color_mapping.items():
         color[class_mask == cls] = col
-    write_png(output_path, color)
+    write_png_async(output_path, color)
 
 
 class MeanIoU:
@@ -739,18 +792,19 @@ def benchmark_multiclass(model, image_path, gt_path, pred_path, h, w, c, class_t
     names = _bench_names(image_path)
     ious, pas = [], []
     with _pool() as pool:
+        xs, gs = _decoded_set(pool, [(image_path, c), (gt_path, 1)], names) if names else (None, None)
         for i in range(0, len(names), batch_size):
             chunk = names[i:i + batch_size]
-            imgs = list(pool.map(lambda n: read_png(os.path.join(image_path, n), c), chunk))
-            gts = list(pool.map(lambda n: read_png(os.path.join(gt_path, n), 1)[..., 0], chunk))
-            probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda())
-            pred_d, counts = _ev.eval_multiclass(probs, torch.from_numpy(np.stack(gts, 0)).cuda(), want_pred=create_images)
+            gts = gs[i:i + batch_size, ..., 0]
+            probs = model.predict_device(xs[i:i + batch_size])
+            pred_d, counts = _ev.eval_multiclass(probs, gts, want_pred=create_images)
             pred = pred_d.cpu().numpy() if create_images else None
+            n_px = int(gts.shape[1] * gts.shape[2])
             for j, n in enumerate(chunk):
                 if create_images:
-                    write_png(os.path.join(pred_path, n), pred[j])
+                    write_png_async(os.path.join(pred_path, n), pred[j])
                     convert_class_to_color_mask(pred[j], os.path.join(pred_path, f"{n[:-4]}_color.png"), class_to_color_mapping)
-                pa_f, iou_f = _ev.pa_iou_from_counts(counts[j], gts[j].size)
+                pa_f, iou_f = _ev.pa_iou_from_counts(counts[j], n_px)
                 pa = round(float(pa_f), 4)
                 iou = round(float(iou_f), 4)
                 pas.append(pa); ious.append(iou)
@@ -954,7 +1008,9 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
                 jobs += [(os.path.join(out["brightfield"], name), bf), (os.path.join(out["alive"], name), alive),
                          (os.path.join(out["dead"], name), dead), (os.path.join(out["mod_position"], name), pos),
                          (os.path.join(out["im"], name), im_np[j])]
-            list(pool.map(lambda a: write_png(*a), jobs))
+            for job in jobs:
+                write_png_async(*job)
+    flush_writes()
     tot_im, tot_n = _all_reduce_sum([sum_im, count])
     return round(tot_im / tot_n, 0) if tot_n else 0.0
 
@@ -984,9 +1040,9 @@ def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_s
                 qa, qd, _ = get_cell_count(get_pos_contours(gp), ga, gd)
                 delta += abs(pa - qa) + abs(pd - qd)
             if save_output:
-                write_png(os.path.join(pred_dir, "alive", n), a_u)
-                write_png(os.path.join(pred_dir, "dead", n), d_u)
-                write_png(os.path.join(pred_dir, sub, n), p_u)
+                write_png_async(os.path.join(pred_dir, "alive", n), a_u)
+                write_png_async(os.path.join(pred_dir, "dead", n), d_u)
+                write_png_async(os.path.join(pred_dir, sub, n), p_u)
     mious, mious_ad, deltas = _gather_lists(mious, mious_ad, [delta])
     delta = sum(deltas)
     return (round(float(np.sum(mious) / len(mious)), 3), round(float(np.sum(mious_ad) / len(mious_ad)), 3),
