@@ -233,6 +233,15 @@ IMK_API int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uin
 IMK_API int imk_eval_multiclass(const float *probs, const uint8_t *gt, int batch, int h, int w, int k, uint8_t *pred_out,
                         int64_t *counts, void *stream);
 
+/* Reductions of the validation monitors of train_multiclass / train_hela (the ModelCheckpoint criteria, functions.py:
+ * 255-258, 303-306), deterministic (fixed summation order):
+ *   mode 0 -- MeanIoU.update_state (functions.py:75-86): probs [n_pix,K] f32, gt [n_pix] u8 class ids ->
+ *             out[0..K) = sum_p [gt == k] p_k,  out[K..2K) = sum_p [gt == k],  out[2K..3K) = sum_p p_k
+ *   mode 1 -- squared error of Keras' val_loss for 'mse': gt [n_pix,K] u8 targets -> out[0] = sum (p - y)^2
+ * out: device buffer of imk_eval_soft_out_doubles(K) doubles (results first, block partials behind them); K <= 64. */
+IMK_API int64_t imk_eval_soft_out_doubles(int k);
+IMK_API int imk_eval_soft_sums(const float *probs, const uint8_t *gt, int64_t n_pix, int k, int mode, double *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * EvalNet (evalnet.py:24-73): the quality-scoring network of IM++ / AIM++
  * ----------------------------------------------------------------------------------------------

@@ -74,6 +74,8 @@ SIGNATURES = {
     "imk_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "imk_eval_binary": (c_int, [c_void_p, c_float, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_eval_multiclass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "imk_eval_soft_out_doubles": (c_int64, [c_int]),
+    "imk_eval_soft_sums": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "imk_debug_materialize": (c_int, [c_int]),
     "imk_debug_single_stream": (c_int, [c_int]),
     "imk_prof_enable": (c_int, [c_int]),

@@ -106,7 +106,74 @@ __global__ __launch_bounds__(256) void eval_multi_kernel(const float *__restrict
         if (hist[i]) atomicAdd(counts + (size_t)b * 1024 + i, (unsigned long long)hist[i]);
 }
 
+// ---- soft reductions of the validation monitors ---------------------------------------------------------------------
+// mode 0 (MeanIoU.update_state, functions.py:75-86): per class k  {sum_p [gt == k] * p_k, sum_p [gt == k], sum_p p_k}
+// mode 1 (Keras' val_loss for 'mse'): sum over all elements of (p - y)^2
+// Deterministic: a thread owns one class (mode 0) and a fixed subset of the pixels, partials are summed in a fixed order.
+constexpr int SOFT_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void eval_soft_kernel(const float *__restrict__ probs, const uint8_t *__restrict__ gt,
+                                                        long long n_pix, int K, int mode, double *__restrict__ out) {
+    __shared__ float s_acc[256][3];
+    const int t = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (mode == 0) {
+        const int G = 256 / K;                       // pixel groups per block (K <= 64: at least 4)
+        const int g = t / K, k = t - g * K;
+        if (g < G)
+            for (long long p = (long long)blockIdx.x * G + g; p < n_pix; p += (long long)gridDim.x * G) {
+                const float v = probs[p * K + k];
+                const bool hit = gt[p] == k;
+                a0 += hit ? v : 0.f; a1 += hit ? 1.f : 0.f; a2 += v;
+            }
+    } else {
+        const long long n = n_pix * K;
+        for (long long i = (long long)blockIdx.x * 256 + t; i < n; i += (long long)gridDim.x * 256) {
+            const float e = probs[i] - (float)gt[i];
+            a0 += e * e;
+        }
+    }
+    s_acc[t][0] = a0; s_acc[t][1] = a1; s_acc[t][2] = a2;
+    __syncthreads();
+    double *row = out + (size_t)(1 + blockIdx.x) * 3 * K;
+    if (mode == 0) {
+        if (t < K) {
+            const int G = 256 / K;
+            double r0 = 0, r1 = 0, r2 = 0;
+            for (int g = 0; g < G; ++g) { r0 += s_acc[g * K + t][0]; r1 += s_acc[g * K + t][1]; r2 += s_acc[g * K + t][2]; }
+            row[t] = r0; row[K + t] = r1; row[2 * K + t] = r2;
+        }
+    } else if (t == 0) {
+        double r = 0;
+        for (int i = 0; i < 256; ++i) r += s_acc[i][0];
+        row[0] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void eval_soft_finalize_kernel(double *__restrict__ out, int n_cols, int n_rows) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    double r = 0;
+    for (int b = 0; b < n_rows; ++b) r += out[(size_t)(1 + b) * n_cols + c];
+    out[c] = r;
+}
+
 }  // namespace
+
+extern "C" int64_t imk_eval_soft_out_doubles(int k) { return k > 0 && k <= 64 ? (int64_t)(SOFT_BLOCKS + 1) * 3 * k : IMK_EINVAL; }
+
+extern "C" int imk_eval_soft_sums(const float *probs, const uint8_t *gt, int64_t n_pix, int k, int mode, double *out,
+                                  void *stream_) {
+    IMK_CHECK_ARG(probs && gt && out && n_pix > 0 && k > 0 && (mode == 0 || mode == 1));
+    if (k > 64) return IMK_EUNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    IMK_HIP(hipMemsetAsync(out, 0, (size_t)(SOFT_BLOCKS + 1) * 3 * k * sizeof(double), stream));
+    eval_soft_kernel<<<SOFT_BLOCKS, 256, 0, stream>>>(probs, gt, (long long)n_pix, k, mode, out);
+    IMK_LAUNCH_CHECK();
+    eval_soft_finalize_kernel<<<imk_cdiv(3 * k, 256), 256, 0, stream>>>(out, 3 * k, SOFT_BLOCKS);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
 
 extern "C" int imk_eval_binary(const float *probs, float thr, int cmp_ge, const uint8_t *gt, int batch, int h, int w,
                                uint8_t *pred_out, int64_t *counts, void *stream_) {

@@ -55,3 +55,19 @@ def pa_iou_from_counts(c, n_pix):
     for i in classes:
         total += np.int64(n_both[i]) / ((np.int64(n_gt[i]) + np.int64(n_pr[i]) - np.int64(n_both[i])) + 1e-7)
     return pa, total / len(classes)
+
+
+def soft_sums(probs, gt, mode):
+    """Validation-monitor reductions on the device (imk_eval_soft_sums), deterministic.
+    mode 0: probs [..., K] f32, gt [...] u8 class ids -> float64 numpy [3, K] = (sum [gt == k] p_k, sum [gt == k], sum p_k)
+    mode 1: probs [..., K] f32, gt [..., K] u8 targets -> float64 sum of squared errors"""
+    probs, gt = probs.contiguous(), gt.contiguous()
+    K = probs.shape[-1]
+    n_pix = probs.numel() // K
+    assert probs.is_cuda and probs.dtype == torch.float32 and gt.dtype == torch.uint8
+    assert gt.numel() == (n_pix if mode == 0 else n_pix * K)
+    out = torch.empty(lib.imk_eval_soft_out_doubles(K), dtype=torch.float64, device=probs.device)
+    check(lib.imk_eval_soft_sums(probs.data_ptr(), gt.data_ptr(), n_pix, K, int(mode), out.data_ptr(), _stream()),
+          "imk_eval_soft_sums")
+    res = out[:3 * K].cpu().numpy()
+    return res.reshape(3, K) if mode == 0 else float(res[0])

@@ -459,11 +459,12 @@ def create_augment_images_and_masks_hela(main_input_path, main_output_path, num_
 # metrics (functions.py:162-184, 1767-1861)
 # ---------------------------------------------------------------------------------------------------
 def dice_loss(y_true, y_pred, smooth=1):
-    """functions.py:162-184 on torch tensors [B,H,W,K]."""
-    y_true = torch.as_tensor(y_true).float()
-    y_pred = torch.as_tensor(y_pred).float()
-    inter = (y_true * y_pred).sum(dim=(1, 2, 3))
-    union = y_true.sum(dim=(1, 2, 3)) + y_pred.sum(dim=(1, 2, 3))
+    """functions.py:162-184 on arrays [B,H,W,K] (the `custom_objects` entry of the scripts' load_model calls; no shipped
+    script trains with it)."""
+    y_true = np.asarray(y_true, dtype=np.float32)
+    y_pred = np.asarray(y_pred, dtype=np.float32)
+    inter = (y_true * y_pred).sum(axis=(1, 2, 3))
+    union = y_true.sum(axis=(1, 2, 3)) + y_pred.sum(axis=(1, 2, 3))
     return 1 - ((2 * inter + smooth) / (union + smooth)).mean()
 
 
@@ -773,11 +774,13 @@ class MeanIoU:
         self.total, self.count = 0.0, 0.0
 
     def update_state(self, y_true_ids, probs):
-        """y_true_ids [B,H,W] integer device tensor, probs [B,H,W,K] float device tensor."""
-        onehot = torch.nn.functional.one_hot(y_true_ids.long(), self.num_classes).to(probs.dtype)
-        inter = (onehot * probs).sum(dim=(0, 1, 2))
-        union = onehot.sum(dim=(0, 1, 2)) + probs.sum(dim=(0, 1, 2)) - inter
-        self.total += float((inter / union).mean())       # 0/0 -> nan propagates exactly like the reference
+        """y_true_ids [B,H,W] uint8 class ids (device), probs [B,H,W,K] float32 (device): the per-class sums come from
+        imk_eval_soft_sums, the ratios are formed like compute_iou (functions.py:75-80)."""
+        s = _ev.soft_sums(probs, y_true_ids.to(torch.uint8), 0)
+        inter, n_true, n_pred = s[0], s[1], s[2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (n_true + n_pred - inter)            # 0/0 -> nan propagates exactly like the reference
+        self.total += float(np.mean(iou.astype(np.float32)))
         self.count += 1.0
 
     def result(self):
@@ -831,12 +834,16 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
 
     def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_mean_io_u', mode='max')
         metric = MeanIoU(n_classes)
-        with _pool() as pool:
-            for i in range(0, len(val_files), BATCH_SIZE):
-                items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files[i:i + BATCH_SIZE]))
-                x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
-                y = torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda()
-                metric.update_state(y, model.predict_device(x))
+        key = ("multi", val_images_dir, c, tuple(val_files))
+        if key not in _VAL_CACHE:      # the validation set is decoded once and stays on the device over the epochs
+            _VAL_CACHE.clear()
+            with _pool() as pool:
+                items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files))
+            _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                               torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
+        xs, ys = _VAL_CACHE[key]
+        for i in range(0, len(val_files), BATCH_SIZE):      # per-batch IoU, averaged over the batches (functions.py:82-90)
+            metric.update_state(ys[i:i + BATCH_SIZE], model.predict_device(xs[i:i + BATCH_SIZE]))
         v = metric.result()
         if v > best["miou"]:
             best["miou"] = v
@@ -1059,15 +1066,23 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
     best = {"loss": float("inf")}
 
-    def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_loss', mode='min')
-        tot, n = 0.0, 0
+    def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_loss', mode='min'): Keras' sample-weighted mean of the mse
+        key = ("hela", val_images_dir, c, tuple(val_files))
+        if key not in _VAL_CACHE:
+            _VAL_CACHE.clear()
+            with _pool() as pool:
+                items = list(pool.map(lambda p: parse_image_hela(p, c), val_files))
+            _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                               torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
+        xs, ys = _VAL_CACHE[key]
+        sq, n = 0.0, 0
         for i in range(0, len(val_files), BATCH_SIZE):
-            items = [parse_image_hela(p, c) for p in val_files[i:i + BATCH_SIZE]]
-            x = torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda()
-            y = torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda().float()
-            tot += float(((model.predict_device(x) - y) ** 2).mean()); n += 1
-        if tot / max(n, 1) < best["loss"]:
-            best["loss"] = tot / max(n, 1)
+            y = ys[i:i + BATCH_SIZE]
+            sq += _ev.soft_sums(model.predict_device(xs[i:i + BATCH_SIZE]), y, 1)
+            n += y.numel()
+        val_loss = sq / max(n, 1)
+        if val_loss < best["loss"]:
+            best["loss"] = val_loss
             if _rank_world()[0] == 0:
                 save_model(model, filepath_h5)
 

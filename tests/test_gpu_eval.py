@@ -70,3 +70,35 @@ def test_eval_golden_metrics(golden_dir):
         _, c = E.eval_multiclass(torch.from_numpy(probs[None]).cuda(), torch.from_numpy(gt[None]).cuda())
         pa, iou = E.pa_iou_from_counts(c[0], gt.size)
         assert pa == float(g[k + "_pa"][0]) and iou == float(g[k + "_iou"][0])
+
+
+def test_soft_sums_and_mean_iou_monitor():
+    """imk_eval_soft_sums against numpy in float64, and the MeanIoU monitor built on it against the reference's formula
+    (functions.py:75-90: per class intersection / (sum_true + sum_pred - intersection), mean over classes, mean over batches)."""
+    from inconsistencymasks_amd import evaluate as E
+    from inconsistencymasks_amd import functions as F
+    rng = np.random.default_rng(4)
+    for (b, h, w, k) in ((3, 32, 48, 9), (2, 16, 16, 35), (5, 64, 64, 3), (1, 16, 16, 64)):
+        p = rng.random((b, h, w, k)).astype(np.float32)
+        p /= p.sum(-1, keepdims=True)
+        gt = rng.integers(0, k, (b, h, w)).astype(np.uint8)
+        gt[gt == k - 1] = 0                                   # one class absent from the ground truth
+        s = E.soft_sums(torch.from_numpy(p).cuda(), torch.from_numpy(gt).cuda(), 0)
+        oh = np.eye(k)[gt]
+        want = np.stack([(oh * p).sum((0, 1, 2)), oh.sum((0, 1, 2)), p.astype(np.float64).sum((0, 1, 2))])
+        assert np.allclose(s, want, rtol=2e-6, atol=1e-6)
+        assert np.array_equal(s[1], oh.sum((0, 1, 2)))        # counts are exact
+        again = E.soft_sums(torch.from_numpy(p).cuda(), torch.from_numpy(gt).cuda(), 0)
+        assert np.array_equal(s, again)                       # deterministic
+        m = F.MeanIoU(k)
+        m.update_state(torch.from_numpy(gt).cuda(), torch.from_numpy(p).cuda())
+        m.update_state(torch.from_numpy(gt[:1]).cuda(), torch.from_numpy(p[:1]).cuda())
+        def ref(pp, gg):
+            o = np.eye(k)[gg]
+            inter = (o * pp).sum((0, 1, 2))
+            return float(np.mean(inter / (o.sum((0, 1, 2)) + pp.sum((0, 1, 2)) - inter)))
+        assert m.result() == pytest.approx((ref(p, gt) + ref(p[:1], gt[:1])) / 2, rel=1e-5)
+    y = rng.integers(0, 4, (4, 32, 32, 3)).astype(np.uint8)
+    p = rng.random((4, 32, 32, 3)).astype(np.float32)
+    sq = E.soft_sums(torch.from_numpy(p).cuda(), torch.from_numpy(y).cuda(), 1)
+    assert sq == pytest.approx(float(((p.astype(np.float64) - y) ** 2).sum()), rel=2e-6)
