@@ -44,9 +44,13 @@ def main(out):
         rows = list(csv.DictReader(open(files[0])))
         # only the generations (warm-up, timed, exclusive pass): everything from the first fused-IM launch on -- the
         # 1800 pre-training steps of the synthetic ensemble before it would swamp the launch mix of the timed region
-        first = min((int(r["Dispatch_Id"]) for r in rows if "im_binary" in r["Kernel_Name"]), default=0)
-        first_gen = max((int(r["Dispatch_Id"]) for r in rows if int(r["Dispatch_Id"]) < first and "conv_pipe_kernel<4" in r["Kernel_Name"]),
-                        default=0)   # the stem of that first ensemble forward
+        # (the first ensemble forward starts with the inference-only stem-on-load kernel conv_pipe_kernel<6, ...>; before
+        # round 2 the marker was the first fused-IM launch and the uint8 stem conv_pipe_kernel<4, ...> in front of it)
+        first_gen = min((int(r["Dispatch_Id"]) for r in rows if "conv_pipe_kernel<6" in r["Kernel_Name"]), default=None)
+        if first_gen is None:
+            first = min((int(r["Dispatch_Id"]) for r in rows if "im_binary" in r["Kernel_Name"] or "head_im" in r["Kernel_Name"]), default=0)
+            first_gen = max((int(r["Dispatch_Id"]) for r in rows if int(r["Dispatch_Id"]) < first and "conv_pipe_kernel<4" in r["Kernel_Name"]),
+                            default=0)
         for r in rows:
             if int(r["Dispatch_Id"]) < first_gen:
                 continue
