@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         save_mean[ch] = (float)mean;
         save_invstd[ch] = invstd;
         mov_mean[ch] = mov_mean[ch] * BN_MOMENTUM + (float)mean * (1.f - BN_MOMENTUM);
-        mov_var[ch] = mov_var[ch] * BN_MOMENTUM + (float)var * (1.f - BN_MOMENTUM);
+        // Keras' fused BatchNormalization feeds the moving average the Bessel-corrected batch variance (n / (n - 1); the
+        // normalisation itself uses the biased one)
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        mov_var[ch] = mov_var[ch] * BN_MOMENTUM + (float)unbiased * (1.f - BN_MOMENTUM);
     }
 }
 

@@ -133,7 +133,10 @@ def _bn(x, p, name, training, f16, stats_out):
         mean = x.mean(dim=(0, 2, 3))
         var = x.var(dim=(0, 2, 3), unbiased=False)
         if stats_out is not None:
-            stats_out[name] = (mean.detach().clone(), var.detach().clone())
+            # Keras' fused BatchNormalization (the default for 4-D inputs) normalises with the biased batch variance but
+            # feeds the moving average the Bessel-corrected one (`_bessels_correction_test_only`): factor n / (n - 1)
+            n = x.numel() // x.shape[1]
+            stats_out[name] = (mean.detach().clone(), var.detach().clone() * (n / max(n - 1, 1)))
     else:
         mean, var = p[name + ".mean"], p[name + ".var"]
     scale = g * torch.rsqrt(var + BN_EPS)
