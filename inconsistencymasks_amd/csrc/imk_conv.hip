@@ -566,9 +566,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // With that the waits become vmcnt(#prefetch loads) before the epilogue and vmcnt(#stores) before staging, i.e. the
 // prefetch stays in flight across the MFMAs and the epilogue and the stores across the next staging.
 // CHAIN: 0 none, 1 chained 1x1 with the intermediate stored (training), 2 chained, intermediate not stored (inference).
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
+// WG (dgrad of a 1x1 conv behind a BatchNorm, ReLU mask = the conv's own input x; LM_BNBWD, EP_MASK, full tiles): the launch
+// also accumulates the conv's weight / bias gradient.  x is staged in LDS next to the gradient tile (the epilogue then takes
+// its mask from there instead of from global memory), and per tile every wave adds its 64 pixels to
+// dW[ci][co] += x^T . dA with transposed LDS reads (ds_read_tr16_b64) -- 4 MFMAs and 8 LDS reads per wave and tile.
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, bool WG = false>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         float inv_tx, float inv_pi) {
+    static_assert(!WG || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -644,6 +649,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     // per pixel and thread); the bytes go through LDS to the pixel that owns them.
     constexpr bool U8ROWS = (LM == LM_U8) && FULL;
     uint8_t *s_u8 = reinterpret_cast<uint8_t *>(s_red + 4 * 2 * 16);   // [16 rows][cin * 16 bytes], cin <= 4
+    // WG: x tile [256 px][XS chunks] behind it, and the two persistent accumulators of the weight / bias gradient
+    constexpr int NCX = PAIR ? 1 : 2, XS = NCX | 1;     // x = the dgrad's OUTPUT channels: 8 (pair layout) or 16
+    uint8_t *s_x = s_u8 + 1024;
+    f16x8 xr[NCX];
+    f32x4 wacc = {0, 0, 0, 0}, bacc = {0, 0, 0, 0};
     uint4 rowseg = {0, 0, 0, 0};
     const int u8_cin = a.x.cin, u8_nseg = 16 * u8_cin;
     const int u8_t = t < u8_nseg ? t : 0;                 // idle threads repeat segment 0 (loads are unconditional)
@@ -661,6 +671,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             const bool ok = it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
             raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
             valid |= (ok ? 1u : 0u) << k;
+        }
+        if constexpr (WG) {      // thread t <-> pixel t of the (full) tile
+            const f16 *px = a.mask + ((size_t)(tc.b * H + tc.ty0 + (t >> 4)) * W + tc.tx0 + (t & 15)) * a.cs_out;
+#pragma unroll
+            for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 8);
         }
     };
 
@@ -688,6 +703,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
                 }
             }
+            if constexpr (WG) {
+#pragma unroll
+                for (int q = 0; q < NCX; ++q) *reinterpret_cast<f16x8 *>(s_x + (t * XS + q) * 16) = xr[q];
+            }
         }
         const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
         const int x = tc.tx0 + n;
@@ -704,7 +723,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         f16x4 mk[P], zq[P];
         if (EPI == EP_MASK) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+            for (int p = 0; p < P; ++p) {
+                if constexpr (WG) mk[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
+                else mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+            }
         }
         if (DYSTAT) {
 #pragma unroll
@@ -712,6 +734,29 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         }
         const int next = tile + gridDim.x;
         issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
+        if constexpr (WG) {
+            // this wave's 4 tile rows = 2 k-steps of 32 pixels; k-slot <-> pixel map as in wgrad_mfma_body (lane group g:
+            // elements 0-3 = pixels x = 4(g&1) + 0..3 of row r0 + (g >> 1), elements 4-7 the pixels 8 further right)
+            const int qq = n >> 2, pp = n & 3;
+            f16x8 ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (f16)(n == 0 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int pi = (wave * 4 + 2 * kk + (g >> 1)) * 16 + 4 * (g & 1) + qq;
+                const uint8_t *pb = s_tile + (size_t)pi * PS * 16 + pp * 8;      // dA[pixel][co]
+                const uint8_t *pa = s_x + (size_t)pi * XS * 16 + pp * 8;         // x[pixel][ci]
+                const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
+                const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 8 * PS * 16));
+                const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa));
+                const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa + 8 * XS * 16));
+                f16x8 bfw, afw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bfw[e] = (f16)b0[e]; bfw[4 + e] = (f16)b1[e]; afw[e] = (f16)a0[e]; afw[4 + e] = (f16)a1[e]; }
+                wacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afw, bfw, wacc, 0, 0, 0);
+                bacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bfw, bacc, 0, 0, 0);   // column sums -> bias gradient
+            }
+        }
         f32x4 acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = f32x4{0, 0, 0, 0};
@@ -774,6 +819,20 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
+    }
+    if constexpr (WG) {    // the 4 waves' weight / bias gradient accumulators -> this workgroup's partial row [2][256]
+        float *s_acc = reinterpret_cast<float *>(smem);          // [4][2][256]: the tile region is free now
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s_acc[(wave * 2 + 0) * 256 + r * 64 + lane] = wacc[r];
+            s_acc[(wave * 2 + 1) * 256 + r * 64 + lane] = bacc[r];
+        }
+        __syncthreads();
+        float *dst = a.wg_partial + (size_t)blockIdx.x * 2 * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            dst[i * 256 + t] = s_acc[(0 * 2 + i) * 256 + t] + s_acc[(1 * 2 + i) * 256 + t] + s_acc[(2 * 2 + i) * 256 + t] +
+                               s_acc[(3 * 2 + i) * 256 + t];
     }
     if (want_stats) {      // one partial row per workgroup
 #pragma unroll
@@ -1007,15 +1066,17 @@ __global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
     const int local = blockIdx.x - jb.work1_begin;
     const int tile = local / jb.n_chunks, chunk = local - tile * jb.n_chunks;
     const int t = threadIdx.x;
-    const int s0 = chunk * WG_RED_CHUNK, s1 = min(jb.n_split, s0 + WG_RED_CHUNK);
+    const int s0 = chunk * jb.chunk, s1 = min(jb.n_split, s0 + jb.chunk);    // jb.chunk: a multiple of WG_RED_CHUNK
     const size_t stride = (size_t)jb.n_tiles * 256;
     const float *p = jb.partial + (size_t)tile * 256 + t;
-    float v[WG_RED_CHUNK];
-#pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = p[(size_t)min(s0 + i, s1 - 1) * stride];   // unconditional: all 16 in flight
     float acc = 0.f;
+    for (int sb = s0; sb < s1; sb += WG_RED_CHUNK) {
+        float v[WG_RED_CHUNK];
 #pragma unroll
-    for (int i = 0; i < WG_RED_CHUNK; ++i) acc += (s0 + i < s1) ? v[i] : 0.f;
+        for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = p[(size_t)min(sb + i, s1 - 1) * stride];   // unconditional: all 16 in flight
+#pragma unroll
+        for (int i = 0; i < WG_RED_CHUNK; ++i) acc += (sb + i < s1) ? v[i] : 0.f;
+    }
     jb.red[((size_t)chunk * jb.n_tiles + tile) * 256 + t] = acc;
 }
 
@@ -1124,8 +1185,9 @@ int imk_wgf_add_job(ImkWgFinalJobs &jobs, float *partial, int n_split, int ksize
     ImkWgFinalJob &jb = jobs.j[jobs.n++];
     jb.partial = partial;
     jb.n_split = n_split;
-    jb.n_chunks = imk_cdiv(n_split, WG_RED_CHUNK);
-    if (jb.n_chunks > 64) return IMK_EUNSUPPORTED;
+    jb.chunk = WG_RED_CHUNK;
+    while (imk_cdiv(n_split, jb.chunk) > 64) jb.chunk *= 2;      // stage 2 sums at most 64 chunks
+    jb.n_chunks = imk_cdiv(n_split, jb.chunk);
     jb.n_tiles = cit_n * cot_n * (T + 1);
     jb.red = partial + (size_t)n_split * jb.n_tiles * 256;
     jb.T = T; jb.cin = cin; jb.cout = cout; jb.cot_n = cot_n;
@@ -1309,11 +1371,12 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL>
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, bool WG = false>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024;   // tile, affine table, statistics, u8 rows
-    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL>;
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +   // tile, affine table, statistics, u8 rows
+                       (WG ? (size_t)256 * ((PAIR ? 1 : 2) | 1) * 16 + 64 : 0);                            // fused wgrad: the x tile (+ slack: its transposed reads reach 16 bytes past a pixel)
+    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG>;
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 4;
@@ -1353,6 +1416,14 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_PIPE_FWD
     }
     if (a.wpk2) return IMK_EUNSUPPORTED;
+    if (a.wg_partial) {      // dgrad + weight gradient of a 1x1 conv in one launch (callers check imk_conv_can_fuse_wgrad)
+        if constexpr (FULL) {
+            if (a.x.lmode != LM_BNBWD || a.epi != EP_MASK || a.ksize != 1 || (a.dystat_z && a.stats_partial)) return IMK_EUNSUPPORTED;
+            return launch_conv_pipe_k<LM_BNBWD, NC8, 0, PAIR, EP_MASK, false, true, true>(a, stream);
+        } else {
+            return IMK_EUNSUPPORTED;
+        }
+    }
     const bool dystat = a.dystat_z && a.stats_partial;
 #define IMK_PIPE_BWD(LM)                                                                                         \
     (a.epi == EP_MASK ? (dystat ? launch_conv_pipe_k<LM, NC8, 0, PAIR, EP_MASK, true, FULL>(a, stream)           \
@@ -1404,6 +1475,19 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
 
+// Can this dgrad launch also produce the weight gradient of its conv (ImkConvArgs::wg_partial)?  Mirrors the choices of
+// imk_launch_conv / launch_conv_pipe_any: pipelined kernel, full tiles, every lane owning real channels.
+bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
+    static const bool off = []() { const char *e = getenv("IMK_FUSE_WGRAD"); return e && e[0] == '0'; }();
+    if (off || !pipe_enabled()) return false;
+    if (a.ksize != 1 || a.x.lmode != LM_BNBWD || a.epi != EP_MASK || !a.mask || a.wpk2) return false;
+    if (a.x.cs_in > 16 || a.cout > 16) return false;
+    const bool pair = pair_enabled() && a.cout <= 8;
+    const bool all_ch = pair || a.cs_out == 16;
+    return (a.H % 16 == 0) && (a.W % TW == 0) && all_ch && (pair ? a.cs_out == 8 : true);
+}
+int imk_conv_fused_wgrad_rows_max() { return 256 * 8; }
+
 static bool g_use_pipe = true;   // IMK_CONV_PIPE=0 in the environment falls back to the per-tile kernel (A/B runs)
 
 int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
@@ -1440,7 +1524,10 @@ int imk_wgrad_splits(int B, int H, int W, int cin, int cout) {
 size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout) {
     const int n_pairs = ((imk_pad8(cin) + 15) / 16) * ((imk_pad8(cout) + 15) / 16);
     const int T = ksize == 3 ? 9 : 1;
-    const size_t ns = (size_t)imk_wgrad_splits(B, H, W, cin, cout);
+    size_t ns = (size_t)imk_wgrad_splits(B, H, W, cin, cout);
+    // a 1x1 conv between narrow layers may get its weight gradient from its dgrad launch: one row per workgroup of that
+    if (ksize == 1 && imk_pad8(cin) <= 16 && imk_pad8(cout) <= 16 && ns < (size_t)imk_conv_fused_wgrad_rows_max())
+        ns = (size_t)imk_conv_fused_wgrad_rows_max();
     return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch
 }
 

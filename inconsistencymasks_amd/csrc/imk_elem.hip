@@ -393,13 +393,12 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
     for (int i = threadIdx.x; i < K; i += 256) s_b[i] = bias[i];
     for (int i = threadIdx.x; i < CS; i += 256) { s_sc[i] = sc[i]; s_sh[i] = sh[i]; }
     __syncthreads();
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     const float S = ctl->loss_scale;
     // start of the step's gradient part: clear the overflow flag stats[1] (every kernel that can set it runs after this
     // one, the optimizer step that consumed the previous value ran before it) and note the scale / step in use
     if (blockIdx.x == 0 && threadIdx.x == 0) { stats[1] = 0.f; stats[2] = S; stats[3] = (float)ctl->step; }
     float l = 0.f;
-    if (p < n_pix) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (long long)gridDim.x * 256) {
         float xin[CS];
 #pragma unroll
         for (int q = 0; q < CS / 8; ++q) {
@@ -447,7 +446,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
                     const int k = k0 + j;
                     if (k < K) {
                         const float pk = row[k] * inv;
-                        if (k == t) l = -logf(fmaxf(pk, 1.17549435e-38f));
+                        if (k == t) l += -logf(fmaxf(pk, 1.17549435e-38f));
                         g8[j] = (f16)(S * (pk - (k == t ? 1.0f : 0.0f)) * inv_n);
                     }
                 }
@@ -715,7 +714,11 @@ int imk_bn_prep_blocks(int B, int H, int W, int cs) {
     const int slots = 256 / nc8p;                      // pixels per block per sweep
     const long long pix = (long long)B * H * W;
     long long nb = (pix + (long long)slots * 2 - 1) / ((long long)slots * 2);
-    if (nb > 4096) nb = 4096;
+    // (cap measured on the training step, ISIC / SUIM / HeLa / Cityscapes shapes: 4096 blocks -- one window or pixel pair per
+    //  thread, every block resident and in the same phase at the same time -- 1.191 / 2.260 / 2.237 / 3.382 ms; 1024: 1.170;
+    //  512: 1.167 / 2.230 / 2.204 / 3.344; 256: 1.168)
+    static const int cap = []() { const char *e = getenv("IMK_PREP_MAX_BLOCKS"); return e ? atoi(e) : 512; }();
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -777,7 +780,12 @@ int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float 
     return IMK_OK;
 }
 
-int imk_loss_blocks(long long n_pix) { return (int)((n_pix + 255) / 256); }
+// blocks of head_loss_kernel = rows of its loss partials: grid-stride over the pixels beyond IMK_HEAD_LOSS_BLOCKS blocks
+int imk_loss_blocks(long long n_pix) {
+    static const int cap = []() { const char *e = getenv("IMK_HEAD_LOSS_BLOCKS"); return e ? atoi(e) : 1024; }();
+    const long long nb = (n_pix + 255) / 256;
+    return (int)(nb > cap ? cap : nb);
+}
 
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                          int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats,

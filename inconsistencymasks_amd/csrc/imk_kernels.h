@@ -57,7 +57,14 @@ struct ImkConvArgs {
     int *stats_rows;       // host, optional: receives the number of partial rows this launch writes
     int epi;
     int pair;              // set by imk_launch_conv: weights are in the pair layout (imk_conv_pair_layout)
+    // optional, dgrad of a 1x1 conv whose forward input is exactly `mask` (Conv3x3+ReLU -> Conv1x1: the ReLU mask of the
+    // dgrad IS the conv's input x): the same launch also produces the conv's weight / bias gradient partials
+    // dW[ci][co] = sum_px x[px][ci] * dA[px][co] -- both operands are in LDS anyway -- one row [2][256] per workgroup
+    // (stats_rows receives the row count); see imk_conv_can_fuse_wgrad.
+    float *wg_partial;
 };
+bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
+int imk_conv_fused_wgrad_rows_max();   // capacity the partial buffer needs: rows (workgroups) of the largest such launch
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize);  // rows of stats_partial
 int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream);
 
@@ -104,7 +111,7 @@ struct ImkWgFinalJob {
     const float *partial;   // [n_split][n_tiles][256]
     float *red;             // [n_chunks][n_tiles][256]
     float *dw, *db;
-    int n_split, n_chunks, n_tiles, T, cin, cout, cot_n;
+    int n_split, n_chunks, chunk, n_tiles, T, cin, cout, cot_n;   // chunk: splits summed per stage-1 work item
     int work1_begin;        // prefix sum of n_tiles * n_chunks
     int tile_begin;         // prefix sum of n_tiles
 };

@@ -383,6 +383,24 @@ struct Bwd {
     // (dgrad and wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per
     // step) -- the common LDS footprint of the fused kernel leaves one workgroup per CU.
     int wgrad_dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        // A 1x1 conv whose forward input is the tensor its dgrad masks with (Conv3x3+ReLU -> Conv1x1): the pipelined dgrad
+        // kernel has both operands of the weight gradient in LDS and produces it on the side (imk_conv_can_fuse_wgrad) --
+        // no weight-gradient launch, no second read of dy, z and x.
+        const ImkLayer &l = c.p->layers[conv];
+        if (mask && stat_bn < 0 && l.ksize == 1 && l.lmode == LM_RAW && l.src >= 0 && mask == c.act(l.src)) {
+            ImkConvArgs a{};
+            int rows = 0;
+            dgrad_args(conv, dst, mask, -1, nullptr, a);
+            if (imk_conv_can_fuse_wgrad(a)) {
+                a.wg_partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
+                a.stats_rows = &rows;
+                int rc = imk_launch_conv(a, c.stream);
+                if (rc) return rc;
+                if (rows <= 0 || rows > imk_conv_fused_wgrad_rows_max()) return IMK_EWORKSPACE;
+                // its split reduction joins the next batch of the side stream (or the end of the step)
+                return imk_wgf_add_job(jobs, a.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+            }
+        }
         int rc = wgrad(conv);
         if (rc) return rc;
         return dgrad(conv, dst, mask, stat_bn);
