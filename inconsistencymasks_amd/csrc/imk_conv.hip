@@ -570,10 +570,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // also accumulates the conv's weight / bias gradient.  x is staged in LDS next to the gradient tile (the epilogue then takes
 // its mask from there instead of from global memory), and per tile every wave adds its 64 pixels to
 // dW[ci][co] += x^T . dA with transposed LDS reads (ds_read_tr16_b64) -- 4 MFMAs and 8 LDS reads per wave and tile.
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, bool WG = false>
+// WG = 2: the same for a 1x1 conv that READS a BatchNorm output (the U-Net's output layer; LM_RAW, EP_PLAIN, DYSTAT):
+// x = fp16(z * sc + sh) with z the tensor the BN-gradient statistics need anyway -- staged raw (the epilogue's z comes from
+// LDS, too), the affine applied to the transposed reads with the lane's channel constants.
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         float inv_tx, float inv_pi) {
-    static_assert(!WG || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
+    static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
+    static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -654,6 +658,8 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     uint8_t *s_x = s_u8 + 1024;
     f16x8 xr[NCX];
     f32x4 wacc = {0, 0, 0, 0}, bacc = {0, 0, 0, 0};
+    float x_sc = 0.f, x_sh = 0.f;                       // WG = 2: BatchNorm of this lane's input channel (row n of the A operand)
+    if constexpr (WG == 2) { if (n < a.cs_out) { x_sc = a.wg_sc[n]; x_sh = a.wg_sh[n]; } }
     uint4 rowseg = {0, 0, 0, 0};
     const int u8_cin = a.x.cin, u8_nseg = 16 * u8_cin;
     const int u8_t = t < u8_nseg ? t : 0;                 // idle threads repeat segment 0 (loads are unconditional)
@@ -672,8 +678,8 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
             valid |= (ok ? 1u : 0u) << k;
         }
-        if constexpr (WG) {      // thread t <-> pixel t of the (full) tile
-            const f16 *px = a.mask + ((size_t)(tc.b * H + tc.ty0 + (t >> 4)) * W + tc.tx0 + (t & 15)) * a.cs_out;
+        if constexpr (WG != 0) {      // thread t <-> pixel t of the (full) tile
+            const f16 *px = (WG == 1 ? a.mask : a.dystat_z) + ((size_t)(tc.b * H + tc.ty0 + (t >> 4)) * W + tc.tx0 + (t & 15)) * a.cs_out;
 #pragma unroll
             for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 8);
         }
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
                 }
             }
-            if constexpr (WG) {
+            if constexpr (WG != 0) {
 #pragma unroll
                 for (int q = 0; q < NCX; ++q) *reinterpret_cast<f16x8 *>(s_x + (t * XS + q) * 16) = xr[q];
             }
@@ -724,17 +730,20 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         if (EPI == EP_MASK) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                if constexpr (WG) mk[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
+                if constexpr (WG == 1) mk[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
                 else mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out ? co0 : 0));
             }
         }
         if (DYSTAT) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+            for (int p = 0; p < P; ++p) {
+                if constexpr (WG == 2) zq[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
+                else zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+            }
         }
         const int next = tile + gridDim.x;
         issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
-        if constexpr (WG) {
+        if constexpr (WG != 0) {
             // this wave's 4 tile rows = 2 k-steps of 32 pixels; k-slot <-> pixel map as in wgrad_mfma_body (lane group g:
             // elements 0-3 = pixels x = 4(g&1) + 0..3 of row r0 + (g >> 1), elements 4-7 the pixels 8 further right)
             const int qq = n >> 2, pp = n & 3;
@@ -753,6 +762,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 f16x8 bfw, afw;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bfw[e] = (f16)b0[e]; bfw[4 + e] = (f16)b1[e]; afw[e] = (f16)a0[e]; afw[4 + e] = (f16)a1[e]; }
+                if constexpr (WG == 2) {      // x = the BatchNorm output: fp16(z * sc + sh), what LM_AFFINE staging computes
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) afw[e] = (f16)((float)afw[e] * x_sc + x_sh);
+                }
                 wacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afw, bfw, wacc, 0, 0, 0);
                 bacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bfw, bacc, 0, 0, 0);   // column sums -> bias gradient
             }
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
     }
-    if constexpr (WG) {    // the 4 waves' weight / bias gradient accumulators -> this workgroup's partial row [2][256]
+    if constexpr (WG != 0) {    // the 4 waves' weight / bias gradient accumulators -> this workgroup's partial row [2][256]
         float *s_acc = reinterpret_cast<float *>(smem);          // [4][2][256]: the tile region is free now
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1371,7 +1384,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, bool WG = false>
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +   // tile, affine table, statistics, u8 rows
@@ -1418,8 +1431,13 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
     if (a.wpk2) return IMK_EUNSUPPORTED;
     if (a.wg_partial) {      // dgrad + weight gradient of a 1x1 conv in one launch (callers check imk_conv_can_fuse_wgrad)
         if constexpr (FULL) {
-            if (a.x.lmode != LM_BNBWD || a.epi != EP_MASK || a.ksize != 1 || (a.dystat_z && a.stats_partial)) return IMK_EUNSUPPORTED;
-            return launch_conv_pipe_k<LM_BNBWD, NC8, 0, PAIR, EP_MASK, false, true, true>(a, stream);
+            if (a.ksize != 1) return IMK_EUNSUPPORTED;
+            const bool dys = a.dystat_z && a.stats_partial;
+            if (a.x.lmode == LM_BNBWD && a.epi == EP_MASK && !dys)
+                return launch_conv_pipe_k<LM_BNBWD, NC8, 0, PAIR, EP_MASK, false, true, 1>(a, stream);
+            if (a.x.lmode == LM_RAW && a.epi == EP_PLAIN && dys && a.wg_sc && a.wg_sh)
+                return launch_conv_pipe_k<LM_RAW, NC8, 0, PAIR, EP_PLAIN, true, true, 2>(a, stream);
+            return IMK_EUNSUPPORTED;
         } else {
             return IMK_EUNSUPPORTED;
         }
@@ -1480,7 +1498,10 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_FUSE_WGRAD"); return e && e[0] == '0'; }();
     if (off || !pipe_enabled()) return false;
-    if (a.ksize != 1 || a.x.lmode != LM_BNBWD || a.epi != EP_MASK || !a.mask || a.wpk2) return false;
+    if (a.ksize != 1 || a.wpk2) return false;
+    const bool form1 = a.x.lmode == LM_BNBWD && a.epi == EP_MASK && a.mask && !(a.dystat_z && a.stats_partial);
+    const bool form2 = a.x.lmode == LM_RAW && a.epi == EP_PLAIN && a.dystat_z && a.stats_partial;
+    if (!form1 && !form2) return false;
     if (a.x.cs_in > 16 || a.cout > 16) return false;
     const bool pair = pair_enabled() && a.cout <= 8;
     const bool all_ch = pair || a.cs_out == 16;

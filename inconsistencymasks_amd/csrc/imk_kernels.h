@@ -62,6 +62,9 @@ struct ImkConvArgs {
     // dW[ci][co] = sum_px x[px][ci] * dA[px][co] -- both operands are in LDS anyway -- one row [2][256] per workgroup
     // (stats_rows receives the row count); see imk_conv_can_fuse_wgrad.
     float *wg_partial;
+    // second form (the U-Net's output layer: 1x1 conv on a BatchNorm output, dgrad = LM_RAW / EP_PLAIN with the BN-gradient
+    // statistics): x = fp16(dystat_z * wg_sc + wg_sh), the BatchNorm being applied to the transposed LDS reads
+    const float *wg_sc, *wg_sh;
 };
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
 int imk_conv_fused_wgrad_rows_max();   // capacity the partial buffer needs: rows (workgroups) of the largest such launch

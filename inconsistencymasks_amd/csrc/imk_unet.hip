@@ -385,26 +385,46 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
     Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !g_imk_single_stream) ? n_side_env : 0, side_px};
-    // head: its "dA" is dlogit
-    OK(b.wgrad(t.out, dlogit));
-    // the loss value only needs head_loss_kernel's partials: its reduction rides on the side stream, behind the head's
-    // weight gradient, instead of sitting at the end of the step
-    const bool loss_on_side = b.n_side > 0 && b.n_fork > 0;
-    if (loss_on_side)
-        OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, plan->side[(b.n_fork - 1) % b.n_side]));
+    // head: its "dA" is dlogit.  Its dgrad (dlogit -> dy of the last BatchNorm, with that BN's gradient statistics) reads
+    // exactly the operands of its weight gradient (dlogit, and z = the last decoder activation, whose BatchNorm output is
+    // the head's input): where the pipelined kernel covers the shape, one launch produces both.
+    ImkConvArgs ha{};
     {
         const ImkLayer &l = plan->layers[t.out];
-        ImkConvArgs a{};
-        a.x.in = dlogit; a.x.lmode = LM_RAW; a.x.cin = l.cout; a.x.cs_in = imk_pad8(l.cout);
-        a.B = batch; a.H = cf.h; a.W = cf.w; a.ksize = 1; a.cout = l.cin; a.cs_out = imk_pad8(l.cin);
-        a.wpk = c.wbwd(t.out); a.out = c.dy(t.d_bnb[3]); a.epi = EP_PLAIN;
+        const int bn = t.d_bnb[3];
+        ha.x.in = dlogit; ha.x.lmode = LM_RAW; ha.x.cin = l.cout; ha.x.cs_in = imk_pad8(l.cout);
+        ha.B = batch; ha.H = cf.h; ha.W = cf.w; ha.ksize = 1; ha.cout = l.cin; ha.cs_out = imk_pad8(l.cin);
+        ha.wpk = c.wbwd(t.out); ha.out = c.dy(bn); ha.epi = EP_PLAIN;
+        ha.dystat_z = c.act(t.d_c1[3]);
+        ha.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].bwd_partial);
+    }
+    const bool head_fused = imk_conv_can_fuse_wgrad(ha);
+    if (!head_fused) OK(b.wgrad(t.out, dlogit));
+    // the loss value only needs head_loss_kernel's partials: its reduction rides on the side stream, behind the head's
+    // weight gradient, instead of sitting at the end of the step
+    bool loss_done = false;
+    auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than head_loss_kernel)
+        if (loss_done || b.n_side <= 0 || b.n_fork <= 0) return IMK_OK;
+        loss_done = true;
+        return imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, plan->side[(b.n_fork - 1) % b.n_side]);
+    };
+    OK(loss_on_side());
+    {
+        const ImkLayer &l = plan->layers[t.out];
+        const int bn = t.d_bnb[3];
         int rows = 0;
-        a.dystat_z = c.act(t.d_c1[3]);
-        a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[t.d_bnb[3]].bwd_partial);
-        a.stats_rows = &rows;
-        OK(imk_launch_conv(a, stream));
-        if (rows <= 0 || rows > c.ws.L[t.d_bnb[3]].n_bwd_rows) return IMK_EWORKSPACE;
-        b.dy_rows[t.d_bnb[3]] = rows;
+        ha.stats_rows = &rows;
+        if (head_fused) {
+            ha.wg_partial = reinterpret_cast<float *>(c.base + c.ws.L[t.out].wg_partial);
+            ha.wg_sc = c.bn_scale(bn); ha.wg_sh = c.bn_shift(bn);
+        }
+        OK(imk_launch_conv(ha, stream));
+        if (rows <= 0 || rows > c.ws.L[bn].n_bwd_rows) return IMK_EWORKSPACE;
+        b.dy_rows[bn] = rows;
+        if (head_fused) {
+            if (rows > imk_conv_fused_wgrad_rows_max()) return IMK_EWORKSPACE;
+            OK(imk_wgf_add_job(b.jobs, ha.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b));
+        }
     }
     // decoders 9..6
     for (int j = 3; j >= 0; --j) {
@@ -416,6 +436,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
         OK(b.wgrad_dgrad(t.d_ca[j], dU, nullptr));
         OK(b.flush_wgrads());   // the block's weight gradients (and the head's, for the first block) -> side stream
+        OK(loss_on_side());
     }
     // bottleneck: dy = 2x2 sum of dU[decoder 6]
     OK(b.bn_bwd(t.b_bn, 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[0])));
@@ -435,7 +456,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     OK(b.wgrad(t.in_c));
     OK(b.finish_wgrads());
-    if (!loss_on_side) OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, stream));
+    if (!loss_done) OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, stream));
 #undef OK
     return IMK_OK;
 }
