@@ -384,3 +384,48 @@ def test_fused_input_block_matches_stored_one(UNet, name):
         lib.imk_debug_materialize(0)
     assert np.abs(fused - stored).max() <= 2e-3
     assert (np.abs(fused - stored) > 0).mean() < 0.5 or np.abs(fused - stored).max() <= 1e-3
+
+
+def test_full_size_ensemble_im_properties(UNet):
+    """BASELINE configs[1] at its FULL size (2 335 images of 256 x 256 x 3, 2 models, alpha 0.5) through the product
+    path (`EnsembleIM.run`, batches of 256), checked by size-independent properties instead of the oracle (which would need
+    minutes): the fused head + IM kernel equals `imk_unet_forward` + `imk_im_binary` bit for bit on every image; N = 2
+    binary IM == XOR of the two votes; label map and IM are disjoint under output blocking; sizes are pixel counts; the
+    result does not depend on how the set is cut into batches / rank shards (functions.shard_list blocks of 8 ranks)."""
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd import im as imk_im
+    U_, H_, W_ = 2335, 256, 256
+    models = [UNet(H_, W_, 3, 1, 0.5, "sigmoid", seed=90 + j) for j in range(2)]
+    for j, mm in enumerate(models):
+        mm.load_state_dict(randomize_bn(mm.state_dict(), 95 + j))
+    g = torch.Generator(device="cuda").manual_seed(9)
+    yy = torch.arange(H_, device="cuda").view(1, H_, 1, 1)
+    x = (torch.randint(0, 64, (U_, H_, W_, 3), device="cuda", generator=g) + (yy // 2)).clamp(0, 255).to(torch.uint8)
+    ens = F.EnsembleIM(models)
+    def run(lo, hi):
+        r = ens.run(x[lo:hi], 0.5, False, True, True)
+        return {k: r[k].clone() for k in ("img_out", "masks", "im", "im_size", "pred_size")}
+    whole = [run(i, min(i + 256, U_)) for i in range(0, U_, 256)]
+    cat = {k: torch.cat([w[k] for w in whole], 0) for k in whole[0]}
+    n_im, n_fg = int(cat["im_size"].sum()), int(cat["pred_size"].sum())
+    assert 0 < n_im < U_ * H_ * W_ and n_fg > 0
+    # (1) fused == unfused, on a sample of batches (the unfused route materialises 2 x 256 x 256 KB of probabilities)
+    for lo in (0, 1024, 2304):
+        hi = min(lo + 256, U_)
+        probs = torch.stack([mm.predict_device(x[lo:hi]) for mm in models], 0)
+        u = imk_im.im_binary(probs, 0.5, False, x[lo:hi], True, True)
+        for k in ("img_out", "masks", "im", "im_size", "pred_size"):
+            assert torch.equal(u[k], cat[k][lo:hi]), (k, lo)
+        v = probs[..., 0] > 0.5
+        assert torch.equal(cat["im"][lo:hi] > 0, v[0] ^ v[1])                      # (2) N = 2: the IM is the XOR of the votes
+        assert torch.equal(cat["pred_size"][lo:hi, 0], (v[0] & v[1]).sum(dim=(1, 2)))
+    # (3) structure
+    assert not bool(((cat["masks"][:, 0] > 0) & (cat["im"] > 0)).any())
+    assert torch.equal(cat["im_size"][:, 0], (cat["im"] > 0).sum(dim=(1, 2)))
+    assert torch.equal(cat["img_out"], x * (cat["im"] == 0)[..., None])
+    # (4) any cut of the set gives the same masks: the 8-rank shards of functions.shard_list
+    for rank in range(8):
+        lo, hi = (U_ * rank) // 8, (U_ * (rank + 1)) // 8
+        part = run(lo, hi)
+        for k in part:
+            assert torch.equal(part[k], cat[k][lo:hi]), (k, rank)
