@@ -190,8 +190,15 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
     } else {
         const int nb = LM == LM_STEM ? in.u8_c : in.cin;     // bytes per pixel
         const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * nb;
+        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
+        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
+        // bytes early, so nothing past the image is read (H * W * nb >= 4).
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        const int rem = (H * W - (y * W + x)) * nb;          // bytes from this pixel to the end of its image
+        const int back = rem >= 4 ? 0 : 4 - rem;
+        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(p - back) >> (8 * back);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < nb) ? p[j] : 0;
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
     }
 }
 
