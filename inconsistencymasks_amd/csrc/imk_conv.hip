@@ -1400,7 +1400,8 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 4;
-        blocks_per_cu = nb > 8 ? 8 : nb;
+        static const int cap = []() { const char *e = getenv("IMK_PIPE_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
+        blocks_per_cu = nb > cap ? cap : nb;
     }
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
     const int n_tiles = a.B * tiles_x * tiles_y;
