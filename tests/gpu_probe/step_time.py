@@ -9,6 +9,7 @@ CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "hela": (256, 256, 1, 3, 1.0
        "suim": (256, 256, 3, 9, 1.0, "softmax", 1), "city": (208, 416, 3, 35, 1.0, "softmax", 1)}
 name = os.environ.get("CONFIG", "isic")
 H, W, C, K, ALPHA, ACT, LOSS = CFG[name]
+ALPHA = float(os.environ.get("ALPHA", ALPHA))      # e.g. the IM+ width schedule: CONFIG=city ALPHA=2
 B = int(os.environ.get("INFER_B", 128))
 x = torch.randint(0, 256, (B, H, W, C), dtype=torch.uint8, device="cuda")
 if LOSS == 0:
@@ -25,6 +26,6 @@ def timeit(fn, n, reps=5):
         for _ in range(n): fn()
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / n * 1e3)
     return sorted(ts)[len(ts) // 2]
-print("config", name, "env", {k: v for k, v in os.environ.items() if k.startswith("IMK_")})
+print("config", name, "alpha", ALPHA, "env", {k: v for k, v in os.environ.items() if k.startswith("IMK_")})
 print("train step B=32: %.3f ms" % timeit(lambda: m.train_step(xs, y, LOSS, 3e-3, 1e-4), 40))
 print("inference B=%d: %.3f ms (%.2f us/img)" % (B, timeit(lambda: m.predict_device(x), 20), 0))

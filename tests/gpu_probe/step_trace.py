@@ -7,6 +7,7 @@ from inconsistencymasks_amd.unet import UNet
 CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "hela": (256, 256, 1, 3, 1.0, "sigmoid", 0),
        "suim": (256, 256, 3, 9, 1.0, "softmax", 1), "city": (208, 416, 3, 35, 1.0, "softmax", 1)}
 H, W, C, K, ALPHA, ACT, LOSS = CFG[os.environ.get("CONFIG", "isic")]
+ALPHA = float(os.environ.get("ALPHA", ALPHA))
 x = torch.randint(0, 256, (int(os.environ.get("INFER_B", 128)), H, W, C), dtype=torch.uint8, device="cuda")
 if LOSS == 0:
     y = (torch.rand((32, H, W, K), device="cuda") > 0.7).to(torch.uint8)
