@@ -99,6 +99,26 @@ def _calibrate_threads(candidates, run, warm):
     return best[0], tried
 
 
+def parity_sample(models, x_dev, n=4):
+    """"also compare outputs" -- the bench's own ensemble on a few of its images, GPU against the oracle
+    (fp16-emulating torch-CPU restatement): largest probability difference, decision flips, and the IM pixels that differ
+    when the oracle's IM chain runs on the oracle's probabilities (the IM chain itself is bit-exact given equal inputs)."""
+    from oracle import im_oracle, unet_oracle as U
+    x = x_dev[:n].cpu().numpy()
+    gpu = [m.predict_device(x_dev[:n]).cpu().numpy() for m in models]
+    ref = [U.forward(m.state_dict(), x, C, K, ALPHA, "sigmoid", emulate_fp16=True).numpy() for m in models]
+    dp = max(float(np.abs(g - r).max()) for g, r in zip(gpu, ref))
+    flips = float(np.mean([((g > 0.5) != (r > 0.5)).mean() for g, r in zip(gpu, ref)]))
+    im_diff = 0
+    for i in range(n):
+        a = im_oracle.im_binary(np.stack([g[i] for g in gpu], 0), 0.5, False)["im"]
+        b = im_oracle.im_binary(np.stack([r[i] for r in ref], 0), 0.5, False)["im"]
+        im_diff += int((a != b).sum())
+    return {"images": n, "max_abs_dp": round(dp, 5), "decision_flip_rate": round(flips, 6),
+            "im_pixels_differing": im_diff, "im_pixels_total": n * H * W,
+            "note": "GPU vs fp16-emulating oracle on the bench's trained ensemble; tolerance of the parity tests: |dp| <= 3e-2, flips <= 1 %"}
+
+
 def cpu_baseline():
     """The oracle (torch-CPU fp32 restatement, reference-structured: batch-1 forward per image per model, numpy IM,
     batch-32 training) on a bounded sample, extrapolated to one generation.  BASELINE.md section 3: >= 3 repetitions,
@@ -496,6 +516,7 @@ def main():
             out["sharding_check"] = sharding_check
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is a 1-GPU-run item (rank 0 only)
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["parity_sample"] = parity_sample(models, x_unl)
             out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
         print(json.dumps(out))
     if world > 1:

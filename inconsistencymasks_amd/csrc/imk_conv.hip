@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                                                         float inv_tx, float inv_pi) {
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
+    static_assert(WG != 3 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 3x3 dgrad in front of a BatchNorm");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -663,8 +664,28 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     // WG: x tile [256 px][XS chunks] behind it, and the two persistent accumulators of the weight / bias gradient
     constexpr int NCX = PAIR ? 1 : 2, XS = NCX | 1;     // x = the dgrad's OUTPUT channels: 8 (pair layout) or 16
     uint8_t *s_x = s_u8 + 1024;
-    f16x8 xr[NCX];
+    // WG = 3 (3x3 conv on a BatchNorm output): x = fp16(z * sc + sh) WITH its halo, 18 x 18 pixels, zero outside the image
+    constexpr int MAX_XI = WG == 3 ? (18 * 18 * NCX + 255) / 256 : NCX;
+    f16x8 xr[MAX_XI];
+    unsigned xvalid = 0;
+    int xi_lds[MAX_XI], xi_py[MAX_XI], xi_px[MAX_XI], xi_c8[MAX_XI];
+    if constexpr (WG == 3) {
+#pragma unroll
+        for (int k = 0; k < MAX_XI; ++k) {
+            const int i = t + 256 * k;
+            const bool live = i < 18 * 18 * NCX;
+            const int ii = live ? i : t;                 // idle slots repeat slot 0 (t < 324 * NCX always)
+            const int pix = ii / NCX;
+            xi_c8[k] = ii - pix * NCX;
+            xi_py[k] = pix / 18;
+            xi_px[k] = pix - xi_py[k] * 18;
+            xi_lds[k] = live ? (pix * XS + xi_c8[k]) * 16 : -1;
+        }
+    }
     f32x4 wacc = {0, 0, 0, 0}, bacc = {0, 0, 0, 0};
+    f32x4 wtap[WG == 3 ? 9 : 1];
+#pragma unroll
+    for (int i = 0; i < (WG == 3 ? 9 : 1); ++i) wtap[i] = f32x4{0, 0, 0, 0};
     float x_sc = 0.f, x_sh = 0.f;                       // WG = 2: BatchNorm of this lane's input channel (row n of the A operand)
     if constexpr (WG == 2) { if (n < a.cs_out) { x_sc = a.wg_sc[n]; x_sh = a.wg_sh[n]; } }
     uint4 rowseg = {0, 0, 0, 0};
@@ -685,16 +706,29 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
             valid |= (ok ? 1u : 0u) << k;
         }
-        if constexpr (WG != 0) {      // thread t <-> pixel t of the (full) tile
+        if constexpr (WG == 1 || WG == 2) {      // thread t <-> pixel t of the (full) tile
             const f16 *px = (WG == 1 ? a.mask : a.dystat_z) + ((size_t)(tc.b * H + tc.ty0 + (t >> 4)) * W + tc.tx0 + (t & 15)) * a.cs_out;
 #pragma unroll
             for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 8);
+        }
+        if constexpr (WG == 3) {
+            xvalid = 0;
+#pragma unroll
+            for (int k = 0; k < MAX_XI; ++k) {
+                const int y = tc.ty0 + xi_py[k] - 1, x = tc.tx0 + xi_px[k] - 1;
+                const bool ok = xi_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+                xr[k] = *reinterpret_cast<const f16x8 *>(a.dystat_z + ((size_t)(tc.b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1)) * a.cs_out + xi_c8[k] * 8);
+                xvalid |= (ok ? 1u : 0u) << k;
+            }
         }
     };
 
     int tile = blockIdx.x;
     issue(tile < n_tiles ? tile : n_tiles - 1);
     stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
+    if constexpr (WG == 3) {              // BatchNorm of the conv's input (LM_RAW leaves the table free)
+        if (t < a.cs_out) { s_aff[t] = a.wg_sc[t]; s_aff[16 + t] = a.wg_sh[t]; }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in; nothing older is pending in the loop
     __syncthreads();                      // affine table visible
     while (tile < n_tiles) {
@@ -716,9 +750,19 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
                 }
             }
-            if constexpr (WG != 0) {
+            if constexpr (WG == 1 || WG == 2) {
 #pragma unroll
                 for (int q = 0; q < NCX; ++q) *reinterpret_cast<f16x8 *>(s_x + (t * XS + q) * 16) = xr[q];
+            }
+            if constexpr (WG == 3) {      // the conv's input: BatchNorm applied, zero padding outside the image
+#pragma unroll
+                for (int k = 0; k < MAX_XI; ++k) {
+                    if (xi_lds[k] >= 0) {
+                        f16x8 v = affine8(xr[k], s_aff + xi_c8[k] * 8, s_aff + 16 + xi_c8[k] * 8);
+                        if (!(xvalid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        *reinterpret_cast<f16x8 *>(s_x + xi_lds[k]) = v;
+                    }
+                }
             }
         }
         const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
@@ -750,7 +794,36 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         }
         const int next = tile + gridDim.x;
         issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
-        if constexpr (WG != 0) {
+        if constexpr (WG == 3) {
+            // as below, with the 9 taps: dW[tap][ci][co] += x[pixel + tap][ci] * dA[pixel][co]; both tiles carry a halo here
+            const int qq = n >> 2, pp = n & 3;
+            f16x8 ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (f16)(n == 0 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int row = wave * 4 + 2 * kk + (g >> 1), xx = 4 * (g & 1) + qq;
+                const uint8_t *pb = s_tile + (size_t)((row + 1) * 18 + xx + 1) * PS * 16 + pp * 8;     // dA, interior pixel
+                const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
+                const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 8 * PS * 16));
+                f16x8 bfw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bfw[e] = (f16)b0[e]; bfw[4 + e] = (f16)b1[e]; }
+                const uint8_t *pa = s_x + (size_t)(row * 18 + xx) * XS * 16 + pp * 8;                    // x at tap (0, 0)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const uint8_t *p = pa + (size_t)((tap / 3) * 18 + tap % 3) * XS * 16;
+                    const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p));
+                    const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p + 8 * XS * 16));
+                    f16x8 afw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { afw[e] = (f16)a0[e]; afw[4 + e] = (f16)a1[e]; }
+                    wtap[tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afw, bfw, wtap[tap], 0, 0, 0);
+                }
+                bacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bfw, bacc, 0, 0, 0);
+            }
+        }
+        if constexpr (WG == 1 || WG == 2) {
             // this wave's 4 tile rows = 2 k-steps of 32 pixels; k-slot <-> pixel map as in wgrad_mfma_body (lane group g:
             // elements 0-3 = pixels x = 4(g&1) + 0..3 of row r0 + (g >> 1), elements 4-7 the pixels 8 further right)
             const int qq = n >> 2, pp = n & 3;
@@ -840,7 +913,27 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
     }
-    if constexpr (WG != 0) {    // the 4 waves' weight / bias gradient accumulators -> this workgroup's partial row [2][256]
+    if constexpr (WG == 3) {    // [10][256]: 9 taps + bias, reduced over the 4 waves in two rounds of 5 (20 KB of LDS)
+        float *s_acc = reinterpret_cast<float *>(smem);
+        float *dst = a.wg_partial + (size_t)blockIdx.x * 10 * 256;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const f32x4 v = (rd * 5 + i < 9) ? wtap[(rd * 5 + i) % 9] : bacc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[(wave * 5 + i) * 256 + r * 64 + lane] = v[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                dst[(rd * 5 + i) * 256 + t] = s_acc[(0 * 5 + i) * 256 + t] + s_acc[(1 * 5 + i) * 256 + t] + s_acc[(2 * 5 + i) * 256 + t] +
+                                              s_acc[(3 * 5 + i) * 256 + t];
+        }
+        __syncthreads();
+    }
+    if constexpr (WG == 1 || WG == 2) {    // the 4 waves' weight / bias gradient accumulators -> this workgroup's partial row [2][256]
         float *s_acc = reinterpret_cast<float *>(smem);          // [4][2][256]: the tile region is free now
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1394,8 +1487,9 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +   // tile, affine table, statistics, u8 rows
-                       (WG ? (size_t)256 * ((PAIR ? 1 : 2) | 1) * 16 + 64 : 0);                            // fused wgrad: the x tile (+ slack: its transposed reads reach 16 bytes past a pixel)
+    size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +   // tile, affine table, statistics, u8 rows
+                 (WG ? (size_t)(WG == 3 ? 18 * 18 : 256) * ((PAIR ? 1 : 2) | 1) * 16 + 64 : 0);              // fused wgrad: the x tile (+ slack: its transposed reads reach 16 bytes past a pixel)
+    if (WG == 3 && lds < 4 * 5 * 256 * sizeof(float)) lds = 4 * 5 * 256 * sizeof(float);                    // ... and its final reduction
     auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG>;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -1439,8 +1533,12 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
     if (a.wpk2) return IMK_EUNSUPPORTED;
     if (a.wg_partial) {      // dgrad + weight gradient of a 1x1 conv in one launch (callers check imk_conv_can_fuse_wgrad)
         if constexpr (FULL) {
-            if (a.ksize != 1) return IMK_EUNSUPPORTED;
             const bool dys = a.dystat_z && a.stats_partial;
+            if (a.ksize == 3) {
+                if (a.x.lmode == LM_RAW && a.epi == EP_PLAIN && dys && a.wg_sc && a.wg_sh)
+                    return launch_conv_pipe_k<LM_RAW, NC8, 0, PAIR, EP_PLAIN, true, true, 3>(a, stream);
+                return IMK_EUNSUPPORTED;
+            }
             if (a.x.lmode == LM_BNBWD && a.epi == EP_MASK && !dys)
                 return launch_conv_pipe_k<LM_BNBWD, NC8, 0, PAIR, EP_MASK, false, true, 1>(a, stream);
             if (a.x.lmode == LM_RAW && a.epi == EP_PLAIN && dys && a.wg_sc && a.wg_sh)
@@ -1506,10 +1604,12 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_FUSE_WGRAD"); return e && e[0] == '0'; }();
     if (off || !pipe_enabled()) return false;
-    if (a.ksize != 1 || a.wpk2) return false;
-    const bool form1 = a.x.lmode == LM_BNBWD && a.epi == EP_MASK && a.mask && !(a.dystat_z && a.stats_partial);
-    const bool form2 = a.x.lmode == LM_RAW && a.epi == EP_PLAIN && a.dystat_z && a.stats_partial;
+    if (a.wpk2) return false;
+    const bool form1 = a.ksize == 1 && a.x.lmode == LM_BNBWD && a.epi == EP_MASK && a.mask && !(a.dystat_z && a.stats_partial);
+    const bool form2 = a.x.lmode == LM_RAW && a.epi == EP_PLAIN && a.dystat_z && a.stats_partial;     // 1x1 and 3x3
+    static const bool c3_off = []() { const char *e = getenv("IMK_FUSE_WGRAD_C3"); return e && e[0] == '0'; }();
     if (!form1 && !form2) return false;
+    if (a.ksize == 3 && c3_off) return false;
     if (a.x.cs_in > 16 || a.cout > 16) return false;
     const bool pair = pair_enabled() && a.cout <= 8;
     const bool all_ch = pair || a.cs_out == 16;
@@ -1555,7 +1655,7 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
     const int T = ksize == 3 ? 9 : 1;
     size_t ns = (size_t)imk_wgrad_splits(B, H, W, cin, cout);
     // a 1x1 conv between narrow layers may get its weight gradient from its dgrad launch: one row per workgroup of that
-    if (ksize == 1 && imk_pad8(cin) <= 16 && imk_pad8(cout) <= 16 && ns < (size_t)imk_conv_fused_wgrad_rows_max())
+    if (imk_pad8(cin) <= 16 && imk_pad8(cout) <= 16 && ns < (size_t)imk_conv_fused_wgrad_rows_max())
         ns = (size_t)imk_conv_fused_wgrad_rows_max();
     return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch
 }

@@ -401,6 +401,24 @@ struct Bwd {
                 return imk_wgf_add_job(jobs, a.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
             }
         }
+        // A 3x3 conv that reads a BatchNorm output, its dgrad feeding that BatchNorm's gradient (Conv1x1 -> BN -> Conv3x3 of
+        // the decoder blocks, input block -> first encoder conv): x = BN(z) with z the tensor the gradient statistics read.
+        if (!mask && stat_bn >= 0 && l.ksize == 3 && l.lmode == LM_AFFINE && l.src_bn == stat_bn &&
+            l.src == c.p->layers[stat_bn].producer) {
+            ImkConvArgs a{};
+            int rows = 0;
+            dgrad_args(conv, dst, nullptr, stat_bn, &rows, a);
+            a.wg_sc = c.bn_scale(stat_bn); a.wg_sh = c.bn_shift(stat_bn);
+            if (imk_conv_can_fuse_wgrad(a)) {
+                a.wg_partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
+                int rc = imk_launch_conv(a, c.stream);
+                if (rc) return rc;
+                rc = dgrad_done(stat_bn, rows);
+                if (rc) return rc;
+                if (rows > imk_conv_fused_wgrad_rows_max()) return IMK_EWORKSPACE;
+                return imk_wgf_add_job(jobs, a.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+            }
+        }
         int rc = wgrad(conv);
         if (rc) return rc;
         return dgrad(conv, dst, mask, stat_bn);
