@@ -90,6 +90,10 @@ def _load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    # PyTorch-ROCm ships its own HIP / HSA runtime (torch/lib/libamdhip64.so): it has to be the one in the process before
+    # libimk.so's dependency on libamdhip64 is resolved -- with /opt/rocm's copy loaded first, torch brings a second runtime
+    # and one of the two fails with "no ROCm-capable device is detected" at its first call.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
