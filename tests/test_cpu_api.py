@@ -381,3 +381,35 @@ def test_keras_checkpoint_converter_mapping(built_lib, tmp_path):
     assert K.main(["--from-keras-npz", npz, dst, "--height", "64", "--width", "64", "--act-out", "sigmoid"]) == 0
     m2 = F.load_model(dst, device="cpu")
     assert torch.equal(m2.params, m.params) and (m2.plan.alpha, m2.plan.act_out) == (0.5, "sigmoid")
+
+
+def test_background_png_writes_flush(built_lib, tmp_path):
+    """write_png_async / flush_writes: every queued file exists and round-trips after the flush; failures are re-raised."""
+    from inconsistencymasks_amd import functions as F
+    rng = np.random.default_rng(0)
+    arrs = {f"a_{i}.png": rng.integers(0, 256, (17, 23, 3)).astype(np.uint8) for i in range(40)}
+    arrs["g.png"] = rng.integers(0, 256, (9, 11)).astype(np.uint8)
+    for n, a in arrs.items():
+        F.write_png_async(str(tmp_path / n), a)
+    F.flush_writes()
+    assert not F._PENDING
+    for n, a in arrs.items():
+        back = F.read_png(str(tmp_path / n), 3 if a.ndim == 3 else 1)
+        assert np.array_equal(back if a.ndim == 3 else back[..., 0], a)
+    F.write_png_async(str(tmp_path / "no_such_dir" / "x.png"), arrs["g.png"])
+    with pytest.raises(Exception):
+        F.flush_writes()
+    assert not F._PENDING
+
+
+def test_dilate_mask_is_grey_dilation_in_the_oracle():
+    """The identity the product relies on (functions.dilate_mask = 3x3 grey-level dilation of the class-id map): the
+    reference's per-class loop with later classes overwriting earlier ones (functions.py:3075-3100) is a neighbourhood
+    maximum -- checked here on the oracle's literal restatement of that loop."""
+    from scipy import ndimage
+    from oracle import im_oracle as O
+    rng = np.random.default_rng(2)
+    for k in (2, 9, 35):
+        m = rng.integers(0, k, (37, 41)).astype(np.uint8)
+        m[rng.random(m.shape) < 0.5] = 0
+        assert np.array_equal(O.dilate_mask_per_class(m, 3), ndimage.grey_dilation(m, size=(3, 3), mode="constant", cval=0))
