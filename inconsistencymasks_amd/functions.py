@@ -875,8 +875,56 @@ def _erode3(mask):
     return ndimage.grey_erosion(mask, size=(3, 3), mode="constant", cval=255)
 
 
+def _trace_outer_border(comp):
+    """Outer border of one 8-connected component (boolean array, padded by one background pixel on every side), followed
+    clockwise from its top-left pixel with Moore-neighbour tracing -- the closed polygon through the border pixels' centres
+    that cv2.findContours reports for an outer contour (CHAIN_APPROX_SIMPLE only drops collinear points, which changes
+    neither the area nor the moments).  Returns the vertices as (x, y) in visiting order."""
+    ys, xs = np.nonzero(comp)
+    y0 = int(ys.min())
+    x0 = int(xs[ys == y0].min())
+    nbr = [(-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1)]     # (dy, dx), clockwise from north
+    pts = [(x0, y0)]
+    cy, cx, back = y0, x0, 6          # we "came from" the west: the pixel left of the start is background
+    first_move = None
+    for _ in range(4 * comp.size + 8):
+        for k in range(1, 9):          # first foreground pixel clockwise after the backtrack direction
+            d = (back + k) % 8
+            ny, nx = cy + nbr[d][0], cx + nbr[d][1]
+            if comp[ny, nx]:
+                break
+        else:
+            return pts                 # isolated pixel
+        if first_move is None:
+            first_move = (cy, cx, d)
+        elif (cy, cx, d) == first_move:
+            return pts[:-1]            # back at the start, about to repeat the first move: the polygon is closed
+        cy, cx = ny, nx
+        back = (d + 4) % 8             # direction pointing back to where we came from
+        pts.append((cx, cy))
+    return pts
+
+
+def _polygon_moments(pts):
+    """m00, m10, m01 of a closed polygon (Green's theorem), as cv2.moments computes them for a contour"""
+    a = m10 = m01 = 0.0
+    n = len(pts)
+    for i in range(n):
+        x0, y0 = pts[i]
+        x1, y1 = pts[(i + 1) % n]
+        cr = x0 * y1 - x1 * y0
+        a += cr
+        m10 += (x0 + x1) * cr
+        m01 += (y0 + y1) * cr
+    return a / 2.0, m10 / 6.0, m01 / 6.0
+
+
 def get_pos_contours(img, erode_kernel=3):
-    """functions.py:6181-6218: centres (x, y) of the blobs of a position mask (+1 offset like the reference)."""
+    """functions.py:6181-6218: centres (x, y) of the blobs of a position mask.  The reference erodes, thresholds at 10,
+    takes cv2.findContours + cv2.moments of every contour and reports (int(m10 / m00) + 1, int(m01 / m00) + 1), skipping
+    contours whose polygon area m00 is zero (single pixels, one-pixel-wide lines).  Restated here with connected components
+    (scipy), Moore-neighbour border tracing and Green's-theorem polygon moments; contours of HOLES (RETR_TREE reports them
+    as extra contours) are not traced.  Unpinned: OpenCV is not available to the reference in this environment."""
     from scipy import ndimage
     a = np.asarray(img)
     assert a.ndim in (2, 3), "Invalid image dimensions."
@@ -886,8 +934,14 @@ def get_pos_contours(img, erode_kernel=3):
         a = ndimage.grey_erosion(a.astype(np.uint8), size=(erode_kernel, erode_kernel), mode="constant", cval=255)
     lab, n = ndimage.label(a > 10, structure=np.ones((3, 3)))
     pos = []
-    for cy, cx in ndimage.center_of_mass(a > 10, lab, range(1, n + 1)):
-        pos.append((int(cx) + 1, int(cy) + 1))
+    for sl, idx in zip(ndimage.find_objects(lab), range(1, n + 1)):
+        comp = np.pad(lab[sl] == idx, 1)
+        pts = _trace_outer_border(comp)
+        m00, m10, m01 = _polygon_moments(pts)
+        if m00 != 0:
+            cx = m10 / m00 + sl[1].start - 1        # back to image coordinates (the component was cropped and padded)
+            cy = m01 / m00 + sl[0].start - 1
+            pos.append((int(cx) + 1, int(cy) + 1))
     return pos
 
 

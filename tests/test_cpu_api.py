@@ -413,3 +413,25 @@ def test_dilate_mask_is_grey_dilation_in_the_oracle():
         m = rng.integers(0, k, (37, 41)).astype(np.uint8)
         m[rng.random(m.shape) < 0.5] = 0
         assert np.array_equal(O.dilate_mask_per_class(m, 3), ndimage.grey_dilation(m, size=(3, 3), mode="constant", cval=0))
+
+
+def test_position_contour_centres_known_answers():
+    """get_pos_contours (functions.py:6181-6218) restated without OpenCV: polygon through the border pixels' centres,
+    Green's-theorem moments, int(m10 / m00) + 1.  Known answers that follow from that definition: an axis-aligned
+    rectangle's centre, a disc's centre, and NO position for blobs whose contour polygon has zero area (a single pixel, a
+    one-pixel-wide line) -- cv2.moments gives m00 = 0 for those and the reference skips them."""
+    from inconsistencymasks_amd import functions as F
+    m = np.zeros((40, 40), np.uint8)
+    m[10:21, 5:16] = 255                                   # rows 10..20, columns 5..15: centre (x 10, y 15)
+    assert F.get_pos_contours(m, erode_kernel=0) == [(11, 16)]
+    assert F.get_pos_contours(m) == [(11, 16)]             # a 3x3 erosion shrinks the square around the same centre
+    thin = np.zeros((20, 20), np.uint8)
+    thin[5, 5] = 255
+    thin[10, 3:9] = 255
+    assert F.get_pos_contours(thin, erode_kernel=0) == []
+    yy, xx = np.mgrid[0:64, 0:64]
+    disc = (((yy - 30) ** 2 + (xx - 20) ** 2) <= 36).astype(np.uint8) * 255
+    assert F.get_pos_contours(disc, erode_kernel=0) == [(21, 31)]
+    # the polygon of a 3x3 ring of pixels is the 2x2 square through their centres
+    ring = np.pad(np.array([[1, 1, 1], [1, 0, 1], [1, 1, 1]], bool), 1)
+    assert F._polygon_moments(F._trace_outer_border(ring)) == (4.0, 8.0, 8.0)
