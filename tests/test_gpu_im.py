@@ -160,3 +160,57 @@ def test_sharding_invariance(im):
     parts = [im.im_binary(preds[:, a:b].contiguous(), 0.5, False, img[a:b].contiguous(), True, True) for a, b in zip(cuts, cuts[1:])]
     for key in ("masks", "im", "im_size", "pred_size", "img_out"):
         assert torch.equal(whole[key], torch.cat([p[key] for p in parts], 0))
+
+
+def test_randomized_shapes_vs_oracle(im):
+    """60 random cases (seeded): models 2-6, batch 1-4, ragged sizes that exercise the vector / generic paths and partial
+    workgroups, 1-5 sigmoid maps or 2-40 classes, thresholds incl. exact ties with the data, image channels 1 / 3 / none,
+    every blocking combination; probabilities salted with the values SURVEY 8a' lists (0.5, neighbours of 0.5, 0, 1, -0.0,
+    inf, denormals; NaN only for the binary chain, where the comparison defines its vote).  Bit-exact against the oracle."""
+    rng = np.random.default_rng(2024)
+    special = np.array([0.5, np.nextafter(np.float32(0.5), np.float32(1)), np.nextafter(np.float32(0.5), np.float32(0)),
+                        0.0, 1.0, -0.0, np.inf, -np.inf, 1e-38, 0.25, 0.75], np.float32)
+    for case in range(60):
+        n, b = int(rng.integers(2, 7)), int(rng.integers(1, 5))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        c = int(rng.choice([0, 1, 3]))
+        bi, bo = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        img = rng.integers(0, 256, (b, h, w, max(c, 1))).astype(np.uint8) if c else None
+        imgd = torch.from_numpy(img).cuda() if c else None
+        if case % 2 == 0:                                    # binary / HeLa chain
+            kb = int(rng.integers(1, 6))
+            ge = bool(rng.integers(0, 2))
+            thr = float(rng.choice([0.5, 0.3, 0.75]))
+            base = rng.random((1, b, h, w, kb), dtype=np.float32)
+            p = np.clip(base + (rng.random((n, b, h, w, kb), dtype=np.float32) - 0.5) * 0.4, 0, 1).astype(np.float32)
+            flat = p.reshape(-1)
+            idx = rng.choice(flat.size, size=max(1, flat.size // 6), replace=False)
+            flat[idx] = np.concatenate([special, [np.nan, thr]]).astype(np.float32)[rng.integers(0, len(special) + 2, idx.size)]
+            r = im.im_binary(torch.from_numpy(p).cuda(), thr, ge, imgd, bi, bo)
+            for i in range(b):
+                e = O.im_binary(p[:, i], thr, ge)
+                eimg, emasks = O.block(img[i] if c else np.zeros((h, w, 1), np.uint8), list(e["final"]), e["im"], bi, bo)
+                assert np.array_equal(_np(r["im"])[i], e["im"]), case
+                assert np.array_equal(_np(r["masks"])[i], np.stack(emasks)), case
+                assert _np(r["im_size"])[i].tolist() == e["im_size_ch"].tolist(), case
+                assert _np(r["pred_size"])[i].tolist() == e["pred_size_ch"].tolist(), case
+                if c:
+                    assert np.array_equal(_np(r["img_out"])[i], eimg), case
+        else:                                                # multiclass chain
+            k = int(rng.integers(2, 41))
+            base = rng.random((1, b, h, w, k), dtype=np.float32)
+            p = (base + 0.3 * rng.random((n, b, h, w, k), dtype=np.float32)).astype(np.float32)
+            p[:, :, : h // 2] = np.round(p[:, :, : h // 2] * 4) / 4          # exact ties between classes
+            flat = p.reshape(-1)
+            idx = rng.choice(flat.size, size=max(1, flat.size // 10), replace=False)
+            flat[idx] = special[rng.integers(0, len(special), idx.size)]
+            r = im.im_multiclass(torch.from_numpy(p).cuda(), imgd, bi, bo)
+            for i in range(b):
+                e = O.im_multiclass(p[:, i])
+                eimg, (efinal,) = O.block(img[i] if c else np.zeros((h, w, 1), np.uint8), [e["final"]], e["im"], bi, bo)
+                assert np.array_equal(_np(r["im"])[i], e["im"]), case
+                assert np.array_equal(_np(r["final"])[i], efinal), case
+                assert int(r["im_size"][i]) == int(e["im_size"]), case
+                assert np.array_equal(_np(r["presence"])[:, i], e["presence"]), case
+                if c:
+                    assert np.array_equal(_np(r["img_out"])[i], eimg), case

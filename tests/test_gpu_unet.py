@@ -429,3 +429,43 @@ def test_full_size_ensemble_im_properties(UNet):
         part = run(lo, hi)
         for k in part:
             assert torch.equal(part[k], cat[k][lo:hi]), (k, rank)
+
+
+def test_randomized_ensembles_fused_vs_unfused(UNet):
+    """14 random ensembles (seeded): 2-5 models, alpha 0.25-1.5, 1-4 sigmoid maps or 2-40 classes, ragged (multiple-of-16)
+    sizes, `>` and `>=`, every blocking combination -- `imk_unet_forward_im` (fused head + IM) against the probabilities
+    of `imk_unet_forward` pushed through the oracle's IM chain, bit for bit."""
+    from inconsistencymasks_amd import functions as F
+    from oracle import im_oracle as O
+    rng = np.random.default_rng(77)
+    for case in range(14):
+        n = int(rng.integers(2, 6))
+        h, w = 16 * int(rng.integers(1, 5)), 16 * int(rng.integers(1, 6))
+        c = int(rng.choice([1, 3]))
+        alpha = float(rng.choice([0.25, 0.5, 1.0, 1.25, 1.5]))
+        soft = bool(case % 2)
+        k = int(rng.integers(2, 41)) if soft else int(rng.integers(1, 5))
+        b = int(rng.integers(1, 4))
+        ge, bi, bo = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        models = [UNet(h, w, c, k, alpha, "softmax" if soft else "sigmoid", seed=1000 * case + j) for j in range(n)]
+        for j, mm in enumerate(models):
+            mm.load_state_dict(randomize_bn(mm.state_dict(), 5000 + 10 * case + j))
+        x = rng.integers(0, 256, (b, h, w, c)).astype(np.uint8)
+        xd = torch.from_numpy(x).cuda()
+        r = F.EnsembleIM(models).run(xd, 0.5, ge, bi, bo, want_presence=True)
+        pn = torch.stack([mm.predict_device(xd) for mm in models], 0).cpu().numpy()
+        for i in range(b):
+            if soft:
+                e = O.im_multiclass(pn[:, i])
+                eimg, (ef,) = O.block(x[i], [e["final"]], e["im"], bi, bo)
+                assert np.array_equal(r["masks"][i, 0].cpu().numpy(), ef), case
+                assert int(r["im_size"][i, 0]) == int(e["im_size"]), case
+                assert np.array_equal(r["presence"][:, i].cpu().numpy(), e["presence"]), case
+            else:
+                e = O.im_binary(pn[:, i], 0.5, ge)
+                eimg, emasks = O.block(x[i], list(e["final"]), e["im"], bi, bo)
+                assert np.array_equal(r["masks"][i].cpu().numpy(), np.stack(emasks)), case
+                assert r["im_size"][i].cpu().tolist() == e["im_size_ch"].tolist(), case
+                assert r["pred_size"][i].cpu().tolist() == e["pred_size_ch"].tolist(), case
+            assert np.array_equal(r["im"][i].cpu().numpy(), e["im"]), case
+            assert np.array_equal(r["img_out"][i].cpu().numpy(), eimg), case
