@@ -51,6 +51,19 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+def init_distributed():
+    """One process per GPU under torch.distributed.run: pick the rank's device and join the process group (RCCL, i.e. the
+    "nccl" backend).  IMK_DIST_BACKEND=gloo + IMK_ONE_GPU=1 run several ranks on ONE GPU (functional testing of the
+    multi-rank path on a single-GPU box: RCCL refuses two ranks on one device)."""
+    import torch.distributed as dist
+    if int(os.environ.get("WORLD_SIZE", 1)) <= 1 or dist.is_initialized():
+        return
+    local = 0 if os.environ.get("IMK_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("IMK_DIST_BACKEND", "nccl"))
+
+
 def _rank_world():
     d = _dist()
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)

@@ -124,9 +124,7 @@ def run(dataset, approach="IM"):
         n_plus = int(S.get("NUM_IMAGES_IM_PLUS", 1))
     P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
     base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
-    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        torch.distributed.init_process_group("nccl")
+    F.init_distributed()
     rank, world = F._rank_world()
     tag = {"HeLa": "HELA", "Cityscapes": "CITYSCAPES"}.get(dataset, dataset)   # name prefix of models / CSVs (HeLa/09_HeLa_IM.py:61)
 

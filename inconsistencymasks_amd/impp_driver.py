@@ -52,9 +52,7 @@ def run(dataset, aug=False, train_new_evalnet=True):
     base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
     labeled_dir = os.path.join(base, "train_labeled_aug") if aug else P("TRAIN_LABELED_DIR")
     subs = ("brightfield", "alive", "dead", "mod_position") if hela else ("images", "masks")
-    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        torch.distributed.init_process_group("nccl")
+    F.init_distributed()
     rank, world = F._rank_world()
     barrier = lambda: torch.distributed.barrier() if torch.distributed.is_initialized() else None
 

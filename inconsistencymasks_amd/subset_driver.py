@@ -43,9 +43,7 @@ def run(dataset):
     batch, top_k = int(F.config["DEFAULT"]["BATCH_SIZE"]), int(F.config["DEFAULT"]["TOP_Ks"])
     P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
     base, model_dir, csv_dir = P("BASE_DIR"), P("MODEL_DIR"), P("CSV_DIR")
-    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        torch.distributed.init_process_group("nccl")
+    F.init_distributed()
     rank, world = F._rank_world()
     tag = {"HeLa": "HELA", "Cityscapes": "CITYSCAPES"}.get(dataset, dataset)
     approach = "subset"

@@ -598,3 +598,81 @@ def test_reference_style_script_with_compat_namespace(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert float(line[1]) >= 0 and int(line[2]) == 6
     assert os.path.exists(base / "models" / "ref_style_0.h5")
+
+
+def _run_one_and_two_ranks(tmp_path, config, setup, script, extra_env=None):
+    """the same toy driver run with one rank and with two ranks time-slicing one GPU over gloo; returns the two data dirs"""
+    import socket
+    outs = {}
+    for world in (1, 2):
+        work = tmp_path / f"w{world}"
+        base = work / "data"
+        work.mkdir()
+        cfg = work / "config.ini"
+        cfg.write_text(config.format(base=base))
+        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1",
+               **(extra_env or {})}
+        subprocess.run([sys.executable, "-c", setup.format(root=ROOT)], env=env, check=True, cwd=work)
+        if world == 1:
+            cmd = [sys.executable, script]
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env.update(IMK_DIST_BACKEND="gloo", IMK_ONE_GPU="1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), script]
+        r = subprocess.run(cmd, env=env, cwd=work, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[world] = base
+    return outs
+
+
+def _same_png_tree(a, b, subs, channels):
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    for sub in subs:
+        assert sorted(os.listdir(a / sub)) == sorted(os.listdir(b / sub)), sub
+        for n in sorted(os.listdir(a / sub)):
+            ch = channels.get(sub, 1)
+            assert np.array_equal(F.read_png(str(a / sub / n), ch), F.read_png(str(b / sub / n), ch)), (sub, n)
+
+
+def test_isic_driver_two_ranks_on_one_gpu(tmp_path):
+    """The multi-rank path of the IM driver end to end: `torch.distributed.run --nproc-per-node 2` of
+    ISIC_2018/09_ISIC_2018_IM.py with the two ranks time-slicing ONE GPU over gloo (IMK_DIST_BACKEND / IMK_ONE_GPU; RCCL
+    refuses two ranks on one device).  Sharded ensemble inference + IM must write exactly the files and pixels of the
+    single-rank run (same mean IM sizes), training runs data-parallel (gradient all-reduce, moving statistics averaged,
+    sharded benchmarks with gathered metric lists), rank 0 saves and ranks the candidates."""
+    outs = _run_one_and_two_ranks(tmp_path, CONFIG, SETUP, os.path.join(ROOT, "ISIC_2018", "09_ISIC_2018_IM.py"))
+    stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    a, b = (outs[w] / "train_unlabeled_predictions" / "IM" / stem for w in (1, 2))
+    _same_png_tree(a, b, ("im", "images", "masks"), {"images": 3})
+    im1, im2 = ((outs[w] / "csv" / f"mean_im_size_{stem}.csv").read_text() for w in (1, 2))
+    assert im1 == im2
+    models = sorted(os.listdir(outs[2] / "models"))
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(rows) == 3 and all(0.0 <= float(v) <= 1.0 for v in rows[1].split(";")[1:])
+    # every validation / test prediction was written exactly once although the benchmarks were sharded
+    assert len(os.listdir(outs[2] / "val_predictions" / "IM" / (stem + "_0"))) == 8
+    assert len(os.listdir(outs[2] / "test_predictions" / "IM" / (stem + "_0"))) == 8
+
+
+def test_suim_and_hela_drivers_two_ranks_on_one_gpu(tmp_path):
+    """the same for the multiclass (argmax IM, CCE, MeanIoU monitor, sharded benchmark_multiclass) and the HeLa (three `>=`
+    IMs, position discs, val-loss monitor, sharded benchmark_hela) drivers"""
+    (tmp_path / "suim").mkdir(); (tmp_path / "hela").mkdir()
+    outs = _run_one_and_two_ranks(tmp_path / "suim", MULTI_CONFIG, MULTI_SETUP, os.path.join(ROOT, "SUIM", "10_SUIM_IM.py"))
+    stem = "SUIM_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    a, b = (outs[w] / "train_unlabeled_predictions" / "IM" / stem for w in (1, 2))
+    _same_png_tree(a, b, ("im", "images", "masks"), {"images": 3})
+    assert (outs[1] / "csv" / f"mean_im_size_{stem}.csv").read_text() == (outs[2] / "csv" / f"mean_im_size_{stem}.csv").read_text()
+    rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(rows) == 3 and all(0.0 <= float(v) <= 1.0 for v in rows[1].split(";")[1:])
+    outs = _run_one_and_two_ranks(tmp_path / "hela", HELA_CONFIG, HELA_SETUP, os.path.join(ROOT, "HeLa", "09_HeLa_IM.py"))
+    stem = "HELA_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    a, b = (outs[w] / "train_unlabeled_predictions" / "IM" / stem for w in (1, 2))
+    _same_png_tree(a, b, ("im", "brightfield", "alive", "dead", "mod_position"), {"mod_position": 3})
+    rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(rows) == 3 and len(rows[1].split(";")) == 10
