@@ -676,3 +676,19 @@ def test_suim_and_hela_drivers_two_ranks_on_one_gpu(tmp_path):
     _same_png_tree(a, b, ("im", "brightfield", "alive", "dead", "mod_position"), {"mod_position": 3})
     rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(rows) == 3 and len(rows[1].split(";")) == 10
+
+
+def test_isic_im_plus_plus_two_ranks_on_one_gpu(tmp_path):
+    """ISIC_2018/12_ISIC_2018_IM++.py with two ranks: EvalNet training data, EvalNet candidates, EvalNet-weighted
+    augmentation and the U-Net generation all run under torch.distributed; the temp IM directory equals the single-rank one."""
+    extra = "NUM_EPOCHS_EVALNET = 2\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 2\nNUM_LOOPS_VAL = 1\n"
+    text = CONFIG.replace("TOP_Ks = 2\n", "TOP_Ks = 2\n" + extra) + "FREE_ROTATION = True\nALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n"
+    outs = _run_one_and_two_ranks(tmp_path, text, SETUP, os.path.join(ROOT, "ISIC_2018", "12_ISIC_2018_IM++.py"),
+                                  {"IM_EVALNET_CANDIDATES": "0,1,2"})
+    stem = "ISIC_2018_IM_plus_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    a, b = (outs[w] / "train_unlabeled_predictions" / "IM_plus_plus" / "temp" / stem for w in (1, 2))
+    _same_png_tree(a, b, ("im", "images", "masks"), {"images": 3})
+    models = sorted(os.listdir(outs[2] / "models"))
+    assert "ISIC_2018_evalnet_im_1_topK_1.h5" in models and stem + "_topK_1.h5" in models
+    res = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
+    assert len(res) == 3 and len(res[1].split(";")) == 7
