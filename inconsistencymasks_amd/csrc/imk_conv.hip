@@ -969,6 +969,216 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 }
 
 // =====================================================================================================
+// forward / dgrad of the full- and half-resolution layers with 17-32 channels on either side (alpha in (1, 2]: the later
+// generations of the IM+ width schedule, Cityscapes/11_Cityscapes_IM+.py:48; EvalNet's towers at ALPHA_EVALNET = 2).
+// The same persistent, register-prefetching scheme as conv_pipe_kernel, generalised where that kernel is specialised:
+// MT = 1 or 2 output-channel tiles per workgroup (accumulators [MT][4]), up to 4 input chunks per pixel (NC8), and the
+// packed weights -- up to 2 x 9 fragments -- in LDS instead of registers (copied once per workgroup; one ds_read_b128 per
+// channel tile and k-step), which keeps the kernel at 3-4 waves per SIMD.  No pair layout, chaining or fused weight
+// gradient here.  Before round 2 these layers ran on the per-tile kernel (one tile per workgroup, weights re-copied per
+// tile, no overlap of staging and MFMAs): 2.3x the step time from alpha 1 to 1.25 for 1.56x the flops.
+// =====================================================================================================
+template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL>
+__global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
+                                                        float inv_tx, float inv_pi) {
+    constexpr int P = 4;
+    constexpr int PS = NC8 | 1;
+    constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
+    constexpr int MAX_NS = (9 * NC8 + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int ks3 = (a.ksize == 3);
+    const int halo = ks3 ? 1 : 0;
+    const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
+    const int n_items = HT * WT * NC8;
+    const int nq = (ks3 ? 9 : 1) * NC8, ns = (nq + 3) / 4;
+    uint8_t *s_tile = smem;
+    float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);        // up to 4 x 32 floats (LM_UPADD)
+    float *s_red = s_aff + 4 * 32;                                             // [4 waves][2][16 * MT]
+    f16 *s_w = reinterpret_cast<f16 *>(s_red + 4 * 2 * 16 * MT);               // [MT][ns][512]
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int cs_in = a.x.cs_in;
+    const int per_img = tiles_x * tiles_y;
+
+    int off[MAX_NS];
+#pragma unroll
+    for (int s = 0; s < MAX_NS; ++s) {
+        const int q = 4 * s + g;
+        const bool vq = (s < ns) && (q < nq);          // k-slots beyond the real taps carry zero weights: read offset 0
+        const int tap = q / NC8, c8 = q - tap * NC8;
+        const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
+        off[s] = vq ? ((ty * WT + tx) * PS + c8) * 16 : 0;
+    }
+    int base[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) base[p] = ((wave * 4 + p) * WT + n) * PS * 16;
+    int it_lds[MAX_ITEMS], it_py[MAX_ITEMS], it_px[MAX_ITEMS], it_c8[MAX_ITEMS];
+#pragma unroll
+    for (int k = 0; k < MAX_ITEMS; ++k) {
+        const int i = t + 256 * k;
+        const bool live = i < n_items;
+        const int pix = (live ? i : t % n_items) / NC8;
+        it_c8[k] = (live ? i : t % n_items) - pix * NC8;
+        it_py[k] = pix / WT;
+        it_px[k] = pix - it_py[k] * WT;
+        it_lds[k] = live ? (pix * PS + it_c8[k]) * 16 : -1;
+    }
+    // packed weights -> LDS, once per workgroup (the per-tile kernel's fragment layout: [channel tile][k-step][lane][8])
+    {
+        const int n16 = MT * ns * 64;                   // 16-byte chunks
+        const int mt_have = (a.cout + 15) / 16;
+        for (int j = t; j < n16; j += 256) {
+            const int m = j / (ns * 64);
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < mt_have) v = *reinterpret_cast<const f16x8 *>(a.wpk + (size_t)j * 8);
+            *reinterpret_cast<f16x8 *>(s_w + (size_t)j * 8) = v;
+        }
+    }
+    float bias[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 16 * m + 4 * g + r;
+            bias[m][r] = (EPI == EP_RELU && a.bias && co < a.cout) ? a.bias[co] : 0.f;
+        }
+    const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);
+    bool lane_out[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) lane_out[m] = 16 * m + 4 * g < a.cs_out;      // this lane's 4 channels exist in the output tensor
+
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+    RawChunk<LM> raw[MAX_ITEMS];
+    unsigned valid = 0;
+    auto issue = [&](int tile) {
+        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
+        valid = 0;
+#pragma unroll
+        for (int k = 0; k < MAX_ITEMS; ++k) {
+            const int y = tc.ty0 + it_py[k] - halo, x = tc.tx0 + it_px[k] - halo;
+            const bool ok = it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+            raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
+            valid |= (ok ? 1u : 0u) << k;
+        }
+    };
+
+    int tile = blockIdx.x;
+    issue(tile < n_tiles ? tile : n_tiles - 1);
+    stage_affine_table(a.x, s_aff);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in
+    __syncthreads();                      // affine table and weights visible
+    while (tile < n_tiles) {
+#pragma unroll
+        for (int k = 0; k < MAX_ITEMS; ++k) {
+            if (it_lds[k] >= 0) {
+                f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div);
+                if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
+            }
+        }
+        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
+        const int x = tc.tx0 + n;
+        __syncthreads();
+        size_t pix[P];
+        bool inb[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int y = tc.ty0 + wave * 4 + p;
+            inb[p] = FULL || (y < H && x < W);
+            pix[p] = (size_t)(tc.b * H + (FULL ? y : min(y, H - 1))) * W + (FULL ? x : min(x, W - 1));
+        }
+        f16x4 mk[MT][P], zq[MT][P];
+        if (EPI == EP_MASK) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int p = 0; p < P; ++p) mk[m][p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out[m] ? 16 * m + 4 * g : 0));
+        }
+        if (DYSTAT) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int p = 0; p < P; ++p) zq[m][p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out[m] ? 16 * m + 4 * g : 0));
+        }
+        const int next = tile + gridDim.x;
+        issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
+        f32x4 acc[MT][P];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[m][p] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < MAX_NS; ++s) {
+            if (s < ns) {
+                f16x8 afm[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) afm[m] = *reinterpret_cast<const f16x8 *>(s_w + ((size_t)(m * ns + s) * 64 + lane) * 8);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_tile + base[p] + off[s]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afm[m], bf, acc[m][p], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                f16x4 v;
+                if (EPI == EP_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[m][p][r] + bias[m][r], 0.f);
+                } else if (EPI == EP_MASK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ((float)mk[m][p][r] > 0.f) ? (f16)acc[m][p][r] : (f16)0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (f16)acc[m][p][r];
+                }
+                if ((FULL || inb[p]) && lane_out[m]) {
+                    *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + 16 * m + 4 * g) = v;
+                    if (DYSTAT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * (float)zq[m][p][r]; }
+                    } else if (want_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * f; }
+                    }
+                }
+            }
+        __syncthreads();   // tile reads done: the LDS tile may be overwritten
+        tile = next;
+    }
+    if (want_stats) {      // one partial row per workgroup
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = wave_sum<16>(s1[m][r]), v2 = wave_sum<16>(s2[m][r]);
+                if (n == 0) {
+                    s_red[(wave * 2 + 0) * 16 * MT + 16 * m + 4 * g + r] = v1;
+                    s_red[(wave * 2 + 1) * 16 * MT + 16 * m + 4 * g + r] = v2;
+                }
+            }
+        __syncthreads();
+        if (t < 2 * 16 * MT) {
+            const int which = t / (16 * MT), c = t - which * 16 * MT;
+            if (c < a.cs_out) {
+                const float v = (s_red[(0 * 2 + which) * 16 * MT + c] + s_red[(1 * 2 + which) * 16 * MT + c]) +
+                                (s_red[(2 * 2 + which) * 16 * MT + c] + s_red[(3 * 2 + which) * 16 * MT + c]);
+                a.stats_partial[(size_t)blockIdx.x * 2 * a.cs_out + which * a.cs_out + c] = v;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
 // wgrad
 // =====================================================================================================
 constexpr int WG_STRIDE_H = 16;  // halfs per pixel in the wgrad LDS slices: 16 channels = 32 B, unpadded on purpose -- a 32-lane half
@@ -1574,6 +1784,79 @@ static int launch_conv_pipe_any(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_PIPE_SEL
 }
 
+template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL>
+static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
+    static int blocks_per_cu = 0;
+    const int ns = ((a.ksize == 3 ? 9 : 1) * NC8 + 3) / 4;
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 32 + 4 * 2 * 16 * MT) * sizeof(float) + (size_t)MT * ns * 1024;
+    auto kern = conv_wide_kernel<LM, NC8, MT, EPI, DYSTAT, FULL>;
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        blocks_per_cu = nb > 8 ? 8 : nb;
+    }
+    const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
+    const int n_tiles = a.B * tiles_x * tiles_y;
+    int grid = 256 * blocks_per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x, 1.0f / (tiles_x * tiles_y));
+    IMK_LAUNCH_CHECK();
+    if (a.stats_rows) *a.stats_rows = grid;
+    return IMK_OK;
+}
+
+template <int NC8, int MT, bool FULL>
+static int launch_conv_wide_v(const ImkConvArgs &a, hipStream_t stream) {
+    if (a.epi == EP_RELU) {
+        switch (a.x.lmode) {
+            case LM_RAW: return launch_conv_wide_k<LM_RAW, NC8, MT, EP_RELU, false, FULL>(a, stream);
+            case LM_AFFINE: return launch_conv_wide_k<LM_AFFINE, NC8, MT, EP_RELU, false, FULL>(a, stream);
+            case LM_UPADD: return launch_conv_wide_k<LM_UPADD, NC8, MT, EP_RELU, false, FULL>(a, stream);
+            case LM_U8: if constexpr (NC8 == 1) return launch_conv_wide_k<LM_U8, 1, MT, EP_RELU, false, FULL>(a, stream); else return IMK_EUNSUPPORTED;
+            default: return IMK_EUNSUPPORTED;
+        }
+    }
+    const bool dystat = a.dystat_z && a.stats_partial;
+#define IMK_WIDE_BWD(LM)                                                                                          \
+    (a.epi == EP_MASK ? (dystat ? launch_conv_wide_k<LM, NC8, MT, EP_MASK, true, FULL>(a, stream)                 \
+                                : launch_conv_wide_k<LM, NC8, MT, EP_MASK, false, FULL>(a, stream))               \
+                      : (dystat ? launch_conv_wide_k<LM, NC8, MT, EP_PLAIN, true, FULL>(a, stream)                \
+                                : launch_conv_wide_k<LM, NC8, MT, EP_PLAIN, false, FULL>(a, stream)))
+    switch (a.x.lmode) {
+        case LM_RAW: return IMK_WIDE_BWD(LM_RAW);
+        case LM_BNBWD: return IMK_WIDE_BWD(LM_BNBWD);
+        default: return IMK_EUNSUPPORTED;
+    }
+#undef IMK_WIDE_BWD
+}
+
+// 17-32 channels on at least one side, at most 32 on both: the wide persistent kernel (see conv_wide_kernel)
+static bool conv_wide_ok(const ImkConvArgs &a) {
+    static const bool off = []() { const char *e = getenv("IMK_CONV_WIDE"); return e && e[0] == '0'; }();
+    if (off || a.wpk2 || a.x.cs_in > 32 || a.cout > 32) return false;
+    if (a.x.lmode == LM_POOL || a.x.lmode == LM_STEM) return false;
+    if (a.x.lmode == LM_U8 && a.x.cin > 4) return false;
+    return true;
+}
+
+static int launch_conv_wide_any(const ImkConvArgs &a, hipStream_t stream) {
+    const bool full = (a.H % 16 == 0) && (a.W % TW == 0);
+    const int nc8 = a.x.cs_in / 8;
+    const int mt = a.cout > 16 ? 2 : 1;
+#define IMK_WIDE_SEL(NC8V, MTV) (full ? launch_conv_wide_v<NC8V, MTV, true>(a, stream) : launch_conv_wide_v<NC8V, MTV, false>(a, stream))
+#define IMK_WIDE_MT(NC8V) (mt == 2 ? IMK_WIDE_SEL(NC8V, 2) : IMK_WIDE_SEL(NC8V, 1))
+    switch (nc8) {
+        case 1: return IMK_WIDE_MT(1);
+        case 2: return IMK_WIDE_MT(2);
+        case 3: return IMK_WIDE_MT(3);
+        case 4: return IMK_WIDE_MT(4);
+        default: return IMK_EUNSUPPORTED;
+    }
+#undef IMK_WIDE_MT
+#undef IMK_WIDE_SEL
+}
+
 static bool pipe_enabled() {
     static const bool on = []() { const char *e = getenv("IMK_CONV_PIPE"); return !(e && e[0] == '0'); }();
     return on;
@@ -1637,6 +1920,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
     if (a.x.lmode == LM_STEM) return IMK_EUNSUPPORTED;
+    if (conv_wide_ok(a)) return launch_conv_wide_any(a, stream);
     return launch_conv_mfma(a, stream);
 }
 
