@@ -27,6 +27,10 @@ CFGS = {
     "odd": dict(h=48, w=80, c=3, k=35, alpha=1.25, act="softmax", loss="cce", b=2),
     "wide": dict(h=32, w=32, c=3, k=9, alpha=1.5, act="softmax", loss="cce", b=2),
     "alpha2": dict(h=32, w=48, c=3, k=1, alpha=2.0, act="sigmoid", loss="mse", b=2),   # 512-channel bottleneck: 2 K passes
+    # 28 / 56 / ... channels: the wide persistent kernel with a partly filled second channel tile (28 of 32), half-resolution
+    # rows that are not a multiple of the tile height (24), one input channel
+    "alpha175": dict(h=48, w=32, c=1, k=2, alpha=1.75, act="sigmoid", loss="mse", b=2),
+    "tiny16": dict(h=16, w=16, c=3, k=3, alpha=1.0, act="softmax", loss="cce", b=5),       # one tile per image, 1x1 pixels at the bottom
 }
 
 
