@@ -330,25 +330,32 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     info = {}
 
-    def im_stage(x):
-        imgs, masks, ps, ims = [], [], [], []
+    # Whole-set buffers: the IM kernel writes every batch's blocked images / pseudo-labels straight into [0, U), the
+    # labelled pairs sit behind them once -- the "directory" the reference builds (kept pseudo-labelled pairs + labelled
+    # pairs) is then ONE gather with the composed (keep, shuffle) index instead of cat / index / cat / index passes.
+    pool_x = torch.empty((U + x_lab.shape[0], H, W, C), dtype=torch.uint8, device=dev)
+    pool_y = torch.empty((U + x_lab.shape[0], 1, H, W), dtype=torch.uint8, device=dev)
+    pool_x[U:] = x_lab
+    pool_y[U:, 0] = m_lab[..., 0]                                   # {0, 255} like the written mask files
+    lab_idx = torch.arange(U, U + x_lab.shape[0], device=dev)
+
+    def im_stage(x, into_pool=True):
+        ps, ims = [], []
         for i in range(0, x.shape[0], args.infer_batch):
-            r = ens.run(x[i:i + args.infer_batch], 0.5, False, True, True)
-            imgs.append(r["img_out"]); masks.append(r["masks"][:, 0])
+            j = min(i + args.infer_batch, x.shape[0])
+            r = ens.run(x[i:j], 0.5, False, True, True, out={"img_out": pool_x[i:j], "masks": pool_y[i:j]} if into_pool else None)
             ps.append(r["pred_size"][:, 0]); ims.append(r["im_size"][:, 0])
         ps, ims = torch.cat(ps), torch.cat(ims)
-        return imgs, masks, ps, ims, (ps > ims) & (ps > 0)            # keep rule functions.py:2878-2886
+        return ps, ims, (ps > ims) & (ps > 0)            # keep rule functions.py:2878-2886
 
     def generation(record=None):
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
-        imgs, masks, ps, ims, keep = im_stage(x_unl)
+        ps, ims, keep = im_stage(x_unl)
         e1.record()
         # training set = kept pseudo-labelled pairs + labelled pairs (the directory the reference builds)
-        kidx = torch.nonzero(keep).squeeze(1)
-        tx = torch.cat([torch.cat(imgs)[kidx], x_lab])
-        ty = torch.cat([(torch.cat(masks)[kidx] // 255)[..., None], y_lab])
-        n_train = tx.shape[0]
+        src = torch.cat([torch.nonzero(keep).squeeze(1), lab_idx])
+        n_train = src.shape[0]
         steps = n_train // BATCH
         if world > 1:   # every rank must run the same number of gradient all-reduces: the smallest shard decides
             st = torch.tensor([steps], device=dev)
@@ -357,8 +364,9 @@ def main():
         student.params.copy_(init_params)
         student._packed_ok = False
         student.init_train_state()
-        perm = torch.randperm(n_train, device=dev, generator=gen_perm)
-        tx, ty = tx[perm], ty[perm]          # the epoch's shuffle as one gather; batches are then contiguous views
+        src = src[torch.randperm(n_train, device=dev, generator=gen_perm)]
+        tx = pool_x[src]                     # the epoch's shuffle and the keep filter as one gather; batches are contiguous views
+        ty = pool_y[src].reshape(n_train, H, W, 1) // 255            # parse_image_ISIC_2018: 255 -> 1 (functions.py:955-977)
         for s in range(steps):
             student.fwd_bwd(tx[s * BATCH:(s + 1) * BATCH], ty[s * BATCH:(s + 1) * BATCH], 0)
             scale = F._grad_allreduce(student)
@@ -405,7 +413,7 @@ def main():
     # ---- sharding changes nothing: the whole set on one rank gives the ranks' summed sizes and kept count --------------
     sharding_check = None
     if strong and world > 1 and rank == 0:
-        _, _, ps, ims, keep = im_stage(x_all)
+        ps, ims, keep = im_stage(x_all, into_pool=False)
         whole = [float(ps.sum()), float(ims.sum()), float(keep.sum())]
         sharding_check = {"sum_pred_size": whole[0], "sum_im_size": whole[1], "kept": whole[2],
                           "equals_sum_over_ranks": whole == [float(v) for v in totals[:3]]}

@@ -946,6 +946,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         for (int i = 0; i < 2; ++i)
             dst[i * 256 + t] = s_acc[(0 * 2 + i) * 256 + t] + s_acc[(1 * 2 + i) * 256 + t] + s_acc[(2 * 2 + i) * 256 + t] +
                                s_acc[(3 * 2 + i) * 256 + t];
+        __syncthreads();   // s_acc overlaps the statistics scratch (s_red) that the block below writes
     }
     if (want_stats) {      // one partial row per workgroup
 #pragma unroll

@@ -218,8 +218,10 @@ class EnsembleIM:
         self._ws = None
         self._ws_batch = 0
 
-    def run(self, x_u8, thr=0.5, cmp_ge=False, block_in=True, block_out=True, want_presence=False):
-        """x_u8 [B,H,W,C] uint8 device -> dict(img_out, masks [B,Kb,H,W] | final [B,H,W], im, im_size, pred_size, presence)"""
+    def run(self, x_u8, thr=0.5, cmp_ge=False, block_in=True, block_out=True, want_presence=False, out=None):
+        """x_u8 [B,H,W,C] uint8 device -> dict(img_out, masks [B,Kb,H,W] | final [B,H,W], im, im_size, pred_size, presence).
+        out: optional dict with preallocated contiguous `img_out` [B,H,W,C] and / or `masks` [B,Kb,H,W] uint8 tensors (e.g.
+        slices of a whole-set buffer) that the kernel writes into directly."""
         p = self.plan
         b = x_u8.shape[0]
         n = len(self.models)
@@ -233,12 +235,13 @@ class EnsembleIM:
             self._ws_batch = b
         binary = p.act_out == "sigmoid"
         kb = p.n_out if binary else 1
-        masks = torch.empty((b, kb, p.h, p.w), dtype=torch.uint8, device=dev)
+        masks = out["masks"] if out and "masks" in out else torch.empty((b, kb, p.h, p.w), dtype=torch.uint8, device=dev)
         im = torch.empty((b, p.h, p.w), dtype=torch.uint8, device=dev)
         im_size = torch.empty((b, kb), dtype=torch.int64, device=dev)
         pred_size = torch.zeros((b, kb), dtype=torch.int64, device=dev)
         presence = torch.empty((n, b, p.n_out), dtype=torch.uint8, device=dev) if (want_presence and not binary) else None
-        img_out = torch.empty_like(x_u8)
+        img_out = out["img_out"] if out and "img_out" in out else torch.empty_like(x_u8)
+        assert img_out.is_contiguous() and masks.is_contiguous() and img_out.shape == x_u8.shape and masks.shape == (b, kb, p.h, p.w)
         check(lib.imk_unet_forward_im(p.ptr, n, self._params, self._packed, x_u8.data_ptr(), b, float(thr),
                                       int(bool(cmp_ge)), x_u8.data_ptr(), int(bool(block_in)), int(bool(block_out)),
                                       img_out.data_ptr(), masks.data_ptr(), im.data_ptr(), im_size.data_ptr(),

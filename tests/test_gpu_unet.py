@@ -473,3 +473,22 @@ def test_randomized_ensembles_fused_vs_unfused(UNet):
                 assert r["pred_size"][i].cpu().tolist() == e["pred_size_ch"].tolist(), case
             assert np.array_equal(r["im"][i].cpu().numpy(), e["im"]), case
             assert np.array_equal(r["img_out"][i].cpu().numpy(), eimg), case
+
+
+def test_training_run_is_bit_reproducible(UNet):
+    """Two runs of 80 training steps from the same seed give bit-identical parameters (no float atomics, fixed reduction
+    orders) -- the property that makes the ranks of a multi-GPU run build identical ensembles.  At 256 x 256 on purpose:
+    a missing barrier in the fused weight-gradient epilogue (found by bench.py's sharding check in round 2) only showed
+    with many tiles per workgroup."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randint(0, 256, (96, 256, 256, 3), dtype=torch.uint8, device="cuda", generator=g)
+    y = (torch.rand((96, 256, 256, 1), device="cuda", generator=g) > 0.6).to(torch.uint8)
+    def run():
+        m = UNet(256, 256, 3, 1, 0.5, "sigmoid", seed=1000)
+        gi = torch.Generator(device="cuda").manual_seed(5)
+        for _ in range(80):
+            idx = torch.randint(0, 96, (32,), device="cuda", generator=gi)
+            m.train_step(x[idx].contiguous(), y[idx].contiguous(), 0, 3e-3, 1e-4)
+        return m.params.clone()
+    a, b = run(), run()
+    assert torch.equal(a, b)
