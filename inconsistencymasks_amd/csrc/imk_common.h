@@ -53,3 +53,43 @@ struct ImkProfScope {
     ImkProfScope(const ImkProfScope &) = delete;
     ImkProfScope &operator=(const ImkProfScope &) = delete;
 };
+
+// ---- in-kernel phase stamps (probe builds only: -DIMK_STAMPS; tests/gpu_probe/stamps.py) ---------------------------------
+// One thread of the first workgroup of a stamped kernel writes the shader clock at a few points of its path into a
+// per-translation-unit table: where a latency-bound launch spends its microseconds, without a profiler attached.
+#ifdef IMK_STAMPS
+#define IMK_STAMP_ROWS 4096
+#define IMK_STAMP_COLS 16
+#define IMK_STAMP_TABLE(tu)                                                                                          \
+    __device__ unsigned long long g_stamps_##tu[IMK_STAMP_ROWS * IMK_STAMP_COLS];                                     \
+    __device__ unsigned g_stamps_n_##tu;                                                                              \
+    extern "C" __attribute__((visibility("default"))) int imk_debug_stamps_##tu(unsigned long long *out, int reset) { \
+        unsigned n = 0;                                                                                               \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                          \
+        if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamps_n_##tu), sizeof n) != hipSuccess) return -1;                  \
+        if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_##tu), sizeof(unsigned long long) * IMK_STAMP_ROWS * IMK_STAMP_COLS) != hipSuccess) return -1; \
+        if (reset) { unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_n_##tu), &z, sizeof z) != hipSuccess) return -1; } \
+        return (int)(n < IMK_STAMP_ROWS ? n : IMK_STAMP_ROWS);                                                        \
+    }
+// col 0: kernel id, col 1: gridDim.x * gridDim.y, col 2: s_memrealtime at entry (100 MHz, orders the rows), col 3..: s_memtime
+#define IMK_STAMP_BEGIN(tu, kid)                                                                                      \
+    unsigned long long *stamp_row_ = nullptr;                                                                         \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                                     \
+        const unsigned r_ = atomicAdd(&g_stamps_n_##tu, 1u);                                                          \
+        if (r_ < IMK_STAMP_ROWS) {                                                                                    \
+            stamp_row_ = g_stamps_##tu + (size_t)r_ * IMK_STAMP_COLS;                                                 \
+            stamp_row_[0] = (unsigned long long)(kid);                                                                \
+            stamp_row_[1] = (unsigned long long)gridDim.x * gridDim.y;                                                \
+            stamp_row_[2] = __builtin_amdgcn_s_memrealtime();                                                         \
+            stamp_row_[3] = __builtin_amdgcn_s_memtime();                                                             \
+        }                                                                                                             \
+    }
+#define IMK_STAMP(i) do { if (stamp_row_) stamp_row_[3 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// last stamp of a kernel: the shader clock and (col 15) the 100 MHz counter again, which calibrates the former per launch
+#define IMK_STAMP_END(i) do { if (stamp_row_) { stamp_row_[3 + (i)] = __builtin_amdgcn_s_memtime(); stamp_row_[15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define IMK_STAMP_TABLE(tu)
+#define IMK_STAMP_BEGIN(tu, kid)
+#define IMK_STAMP(i) do { } while (0)
+#define IMK_STAMP_END(i) do { } while (0)
+#endif

@@ -25,6 +25,8 @@
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T *)(p))
 
+IMK_STAMP_TABLE(conv)
+
 namespace {
 
 constexpr int TW = 16;  // tile width = one MFMA pixel group per tile row
@@ -289,6 +291,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     const int H = a.H, W = a.W;
     const int ns_total = n_pass * nsp;
 
+    IMK_STAMP_BEGIN(conv, 10000 + LM * 1000 + MT * 100 + n_pass * 10 + ks3);
     stage_affine_table(a.x, s_aff);   // visible after the barrier inside the first staging batch
     bool aff_pending = (LM != LM_RAW && LM != LM_U8);
 
@@ -375,6 +378,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asynchronous weight copy has landed
         __syncthreads();
+        if (pass == 0) IMK_STAMP(1);
 
         // ---- MFMA loop over (tap, chunk) of this pass ----------------------------------------------------------
         const int nq = T * nc8p;          // the packing pads every pass to nc8p chunks (zero weights beyond nc8_cur)
@@ -428,7 +432,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             }
         };
         k_loop();
+        if (pass == 0) IMK_STAMP(2);
     }
+    IMK_STAMP(3);
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // A lane owns 4 channels of one pixel per (m, p): stored directly, that is 8 bytes every cs_out * 2 bytes -- a third of
@@ -502,6 +508,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     else if (a.epi == EP_MASK) { if (dystat) write_tile(I2{}, I2{}); else write_tile(I2{}, I0{}); }
     else { if (dystat) write_tile(I1{}, I2{}); else write_tile(I1{}, I0{}); }
     __syncthreads();
+    IMK_STAMP(4);
     {   // copy-out: 16-byte chunks, (MT * 2) per pixel; channel tiles beyond cs_out are skipped
         const int cpp = MT * 2;                                // chunks per pixel
         const int n_live = min(cpp, (a.cs_out - ct0 * 16) / 8);   // cs_out is a multiple of 8
@@ -514,6 +521,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
                     *reinterpret_cast<const f16x8 *>(s_out + pixl * OPITCH + ch * 8);
         }
     }
+    IMK_STAMP(5);
     if (want_stats) {  // workgroup-uniform branch
         __syncthreads();  // everyone is done reading the tile; reuse its LDS
         float *s_red = reinterpret_cast<float *>(smem);  // [NW waves][2][16*MT]
@@ -539,6 +547,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             }
         }
     }
+    IMK_STAMP_END(6);
 }
 
 template <int TH, int MT, int LM>

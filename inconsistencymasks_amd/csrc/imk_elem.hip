@@ -8,10 +8,42 @@
 #include "imk_elem.h"
 #include "imk_head.h"
 
+IMK_STAMP_TABLE(elem)
+
 namespace {
 
 constexpr float BN_EPS = 1e-3f;       // Keras BatchNormalization default epsilon
 constexpr float BN_MOMENTUM = 0.99f;  // Keras default momentum
+
+// Column sums of the two halves of partial[n_part][2 * cs] for channel ch in double precision, by one 256-thread block:
+// every thread's rows are requested before any is used (one memory latency), lanes combine with shuffles, the 4 waves through
+// LDS (one barrier).  Fixed order: deterministic.  The result is valid in every thread.
+__device__ __forceinline__ void block_sum_rows(const float *__restrict__ partial, int n_part, int cs, int ch, int t,
+                                               double &o1, double &o2) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i0 = t; i0 < n_part; i0 += 8 * 256) {     // 16 independent loads in flight per thread
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, n_part - 1);           // unconditional loads (no branch between them) ...
+            v1[u] = partial[(size_t)i * 2 * cs + ch];
+            v2[u] = partial[(size_t)i * 2 * cs + cs + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double live = (i0 + u * 256 < n_part) ? 1.0 : 0.0;   // ... rows beyond the end count as zero
+            s1 += live * (double)v1[u];
+            s2 += live * (double)v2[u];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    __shared__ double r1[4], r2[4];
+    if ((t & 63) == 0) { r1[t >> 6] = s1; r2[t >> 6] = s2; }
+    __syncthreads();
+    o1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    o2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+}
 
 // ---- BatchNorm forward statistics ---------------------------------------------------------------
 // partial [n_part][2*cs] (sum | sumsq) -> scale/shift for the consumers, saved mean/invstd for backward,
@@ -28,45 +60,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         if (t == 0) { scale[ch] = 0.f; shift[ch] = 0.f; save_mean[ch] = 0.f; save_invstd[ch] = 0.f; }
         return;
     }
-    double s1 = 0.0, s2 = 0.0;
-    for (int i0 = t; i0 < n_part; i0 += 8 * 256) {     // 16 independent loads in flight per thread; same summation order
-        float v1[8], v2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * 256, n_part - 1);           // unconditional loads (no branch between them) ...
-            v1[u] = partial[(size_t)i * 2 * cs + ch];
-            v2[u] = partial[(size_t)i * 2 * cs + cs + ch];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double live = (i0 + u * 256 < n_part) ? 1.0 : 0.0;   // ... rows beyond the end count as zero
-            s1 += live * (double)v1[u];
-            s2 += live * (double)v2[u];
-        }
-    }
-    __shared__ double r1[256], r2[256];
-    r1[t] = s1; r2[t] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) { r1[t] += r1[t + o]; r2[t] += r2[t + o]; }
-        __syncthreads();
-    }
+    IMK_STAMP_BEGIN(elem, 1);
+    // the channel's parameters: requested first, so their latency runs under the partial rows' (they are only needed at the end)
+    const float gam = gamma[ch], bet = beta[ch], mm = mov_mean[ch], mv = mov_var[ch];
+    double s1, s2;
+    block_sum_rows(partial, n_part, cs, ch, t, s1, s2);
+    IMK_STAMP(1);
     if (t == 0) {
-        const double mean = r1[0] / count;
-        double var = r2[0] / count - mean * mean;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
         if (var < 0) var = 0;
         const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-        const float sc = gamma[ch] * invstd;
+        const float sc = gam * invstd;
         scale[ch] = sc;
-        shift[ch] = beta[ch] - (float)mean * sc;
+        shift[ch] = bet - (float)mean * sc;
         save_mean[ch] = (float)mean;
         save_invstd[ch] = invstd;
-        mov_mean[ch] = mov_mean[ch] * BN_MOMENTUM + (float)mean * (1.f - BN_MOMENTUM);
+        mov_mean[ch] = mm * BN_MOMENTUM + (float)mean * (1.f - BN_MOMENTUM);
         // Keras' fused BatchNormalization feeds the moving average the Bessel-corrected batch variance (n / (n - 1); the
         // normalisation itself uses the biased one)
         const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        mov_var[ch] = mov_var[ch] * BN_MOMENTUM + (float)unbiased * (1.f - BN_MOMENTUM);
+        mov_var[ch] = mv * BN_MOMENTUM + (float)unbiased * (1.f - BN_MOMENTUM);
     }
+    IMK_STAMP_END(2);
 }
 
 // inference: fold the moving statistics of all BatchNorm layers (one job each) into scale | shift
@@ -299,43 +315,25 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float *__restric
         if (t == 0) { coef[ch] = 0.f; coef[cs + ch] = 0.f; coef[2 * cs + ch] = 0.f; }
         return;
     }
-    double s1 = 0.0, s2 = 0.0;
-    for (int i0 = t; i0 < n_part; i0 += 8 * 256) {     // 16 independent loads in flight per thread; same summation order
-        float v1[8], v2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * 256, n_part - 1);           // unconditional loads (no branch between them) ...
-            v1[u] = partial[(size_t)i * 2 * cs + ch];
-            v2[u] = partial[(size_t)i * 2 * cs + cs + ch];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double live = (i0 + u * 256 < n_part) ? 1.0 : 0.0;   // ... rows beyond the end count as zero
-            s1 += live * (double)v1[u];
-            s2 += live * (double)v2[u];
-        }
-    }
-    __shared__ double r1[256], r2[256];
-    r1[t] = s1; r2[t] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) { r1[t] += r1[t + o]; r2[t] += r2[t + o]; }
-        __syncthreads();
-    }
+    IMK_STAMP_BEGIN(elem, 2);
+    // requested first: only needed after the reduction
+    const double mean = save_mean[ch], invstd = save_invstd[ch], gam = gamma[ch];
+    const float inv = *inv_scale_ptr;
+    double S1, S2;
+    block_sum_rows(partial, n_part, cs, ch, t, S1, S2);
+    IMK_STAMP(1);
     if (t == 0) {
-        const double S1 = r1[0], S2 = r2[0];
-        const double mean = save_mean[ch], invstd = save_invstd[ch];
         const double dg = (S2 - mean * S1) * invstd;   // sum dy * zhat
-        const double A = (double)gamma[ch] * invstd;
+        const double A = gam * invstd;
         coef[ch] = (float)A;
         coef[cs + ch] = (float)(-A * invstd * dg / count);
         coef[2 * cs + ch] = (float)(-A * S1 / count + A * mean * invstd * dg / count);
-        const float inv = *inv_scale_ptr;
         const float g1 = (float)dg * inv, g2 = (float)S1 * inv;
         if (!isfinite(g1) || !isfinite(g2)) *found_inf = 1.0f;
         dgamma[ch] = g1;
         dbeta[ch] = g2;
     }
+    IMK_STAMP_END(2);
 }
 
 // ---- output head: BN on load -> 1x1 conv in fp32 -> sigmoid / softmax --------------------------------

@@ -1,0 +1,72 @@
+"""GPU: where do the latency-bound launches of a training step spend their time?  Builds nothing: run
+`python tests/gpu_probe/stamps.py build` here (cross-compiles build/stamps/libimk_stamps.so with -DIMK_STAMPS), then on the
+GPU box `IMK_LIB_PATH=build/stamps/libimk_stamps.so python tests/gpu_probe/stamps.py`.  One thread of the first workgroup of
+every stamped kernel (conv_mfma_kernel, bn_finalize_kernel, bn_bwd_coef_kernel) records the shader clock at a few points
+(csrc/imk_common.h: IMK_STAMP); printed per launch of the last of a few steps, in microseconds from kernel entry."""
+import ctypes, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "build", "stamps", "libimk_stamps.so")
+
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    from inconsistencymasks_amd import build as B
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs, procs = [], []
+    for s in sorted(glob.glob(os.path.join(B.CSRC, "*.hip"))):
+        o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ".o")
+        objs.append(o)
+        procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + ["-DIMK_STAMPS", "-c", s, "-o", o]))
+    assert all(p.wait() == 0 for p in procs)
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    print(OUT)
+    sys.exit(0)
+
+import numpy as np
+import torch
+from inconsistencymasks_amd import _lib
+from inconsistencymasks_amd.unet import UNet
+CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "hela": (256, 256, 1, 3, 1.0, "sigmoid", 0),
+       "suim": (256, 256, 3, 9, 1.0, "softmax", 1), "city": (208, 416, 3, 35, 1.0, "softmax", 1)}
+H, W, C, K, ALPHA, ACT, LOSS = CFG[os.environ.get("CONFIG", "isic")]
+lib = _lib.lib
+ROWS, COLS = 4096, 16
+x = torch.randint(0, 256, (32, H, W, C), dtype=torch.uint8, device="cuda")
+y = ((torch.rand((32, H, W, K), device="cuda") > 0.7).to(torch.uint8) if LOSS == 0
+     else torch.randint(0, K, (32, H, W), dtype=torch.uint8, device="cuda"))
+m = UNet(H, W, C, K, ALPHA, ACT, seed=3)
+for _ in range(5):
+    m.train_step(x, y, LOSS, 3e-3, 1e-4)
+torch.cuda.synchronize()
+tabs = {}
+for tu in ("conv", "elem"):
+    fn = getattr(lib, "imk_debug_stamps_" + tu)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    fn(None, 1)
+if os.environ.get("INFER"):
+    xi = torch.randint(0, 256, (int(os.environ["INFER"]), H, W, C), dtype=torch.uint8, device="cuda")
+    m.predict_device(xi)
+else:
+    m.train_step(x, y, LOSS, 3e-3, 1e-4)
+torch.cuda.synchronize()
+rows = []
+for tu in ("conv", "elem"):
+    buf = np.zeros((ROWS, COLS), dtype=np.uint64)
+    n = getattr(lib, "imk_debug_stamps_" + tu)(buf.ctypes.data, 0)
+    for r in buf[:n]:
+        rows.append((int(r[2]), tu, r))
+rows.sort(key=lambda e: e[0])
+# shader clock per microsecond: every launch carries the 100 MHz counter at entry (col 2) and at its last stamp (col 15)
+num = den = 0
+for rt, tu, r in rows:
+    st = [int(v) for v in r[3:15] if int(v)]
+    if int(r[15]) > rt:
+        num += st[-1] - st[0]; den += int(r[15]) - rt
+mhz = num / den * 100.0
+prev_end = None
+for rt, tu, r in rows:
+    st = [int(v) for v in r[3:15] if int(v)]
+    rel = [(v - st[0]) / mhz for v in st]
+    gap = "" if prev_end is None else f"{(rt - prev_end) / 100.0:7.1f}"
+    prev_end = rt + int(rel[-1] * 100)
+    print(f"{(rt - rows[0][0]) / 100.0:9.1f} us  since-prev-end {gap:>7}  {tu}:{int(r[0]):6d} grid {int(r[1]):5d}  " +
+          " ".join(f"{v:6.2f}" for v in rel[1:]))
