@@ -268,11 +268,15 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 // its channel slice of the tile and of the packed weights; any width up to 512 channels runs this way.
 // k order = (pass, tap, chunk in pass) -- see pack_conv_batched_kernel.
 struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp; };
+// LDS offset of a chained launch's second weight set: behind the first stage's regions and the output tile that reuses them
+__host__ __device__ inline size_t imk_chain_w2_offset(size_t stage1_bytes, size_t out_bytes) {
+    return ((stage1_bytes > out_bytes ? stage1_bytes : out_bytes) + 15) & ~(size_t)15;
+}
 
 // bx = spatial tile, by = group of MT output-channel tiles (the launch grid, or a slice of a fused launch's 1-D grid)
 // (Measured and dropped for the launches that do not fill the chip -- deep layers at batch 32: staging batches of 6-12
 // items per thread, 1.386 vs 1.369 ms per step; 1024-thread workgroups with one wave per tile row, 1.450 ms.)
-template <int TH, int MT, int LM>
+template <int TH, int MT, int LM, bool CHAIN = false>
 __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkConvGeom &gm, int bx, int by) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, mt_total = gm.mt_total, nc8 = gm.nc8, nc8p = gm.nc8p;
     const int n_pass = gm.n_pass, ps = gm.ps, nsp = gm.nsp;
@@ -286,6 +290,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     uint8_t *s_tile = smem;
     float *s_aff = reinterpret_cast<float *>(smem + (size_t)HT * WT * ps * 16);
     f16 *s_w = reinterpret_cast<f16 *>(s_aff + 4 * a.x.cs_in);   // [MT][nsp][512] packed weight fragments of one pass
+    // CHAIN: the second conv's weight fragments [mt2][ns2][512], behind everything the first stage and its output tile use
+    f16 *s_w2 = reinterpret_cast<f16 *>(smem + imk_chain_w2_offset((size_t)HT * WT * ps * 16 + 4 * (size_t)a.x.cs_in * sizeof(float) +
+                                                                   (size_t)MT * nsp * 1024, (size_t)TH * 16 * (MT * 16 + 8) * sizeof(f16)));
     const int t = threadIdx.x;
     const TileCoord tc = tile_coord(bx, tiles_x, tiles_y, TH);
     const int H = a.H, W = a.W;
@@ -316,6 +323,13 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             // wave and instruction), so all of it is in flight while the input tile is staged below.
             // (no division in the copy loop: one (channel tile, chunk) walk per m)
             const int n16m = nsp * 64;       // 16-byte chunks per channel tile; a multiple of 64: wave-uniform bounds
+            if (CHAIN && pass == 0) {        // the chained 1x1's fragments: contiguous in its pack, landed by the first barrier
+                const int nc8_2 = a.cs_out / 8;
+                const int n16 = ((a.cout2 + 15) / 16) * imk_cdiv_d(nc8_2, imk_pass_chunks(nc8_2)) * 64;
+                for (int j = t; j < n16; j += NT)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.wpk2 + (size_t)j * 8),
+                                                     (__attribute__((address_space(3))) void *)(s_w2 + (size_t)(j - lane) * 8), 16, 0, 0);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 int ct = by * MT + m;
@@ -447,8 +461,8 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
-    const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
-    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
+    const bool dystat = !CHAIN && (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
+    const bool want_stats = !CHAIN && (((a.epi == EP_RELU) && a.stats_partial) || dystat);
     // biases of this lane's channels: one batch of loads, in flight across the barrier below
     float bias[MT][4];
 #pragma unroll
@@ -462,7 +476,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     f16 *s_out = reinterpret_cast<f16 *>(smem);
     __syncthreads();                                           // every wave is done reading the input tile
     // one straight-line copy of the (m, p) loops per epilogue kind (the kind is uniform: decided once, outside)
-    auto write_tile = [&](auto EPI_T, auto STAT_T) {
+    auto write_tile = [&](auto EPI_T, auto STAT_T, const f32x4 (&ac)[MT][P], const float (&bs)[MT][4], int cs_o) {
         constexpr int EPI = decltype(EPI_T)::value;
         constexpr int STAT = decltype(STAT_T)::value;          // 0 none, 1 sum / sum of squares, 2 sum dy / sum dy*z
 #pragma unroll
@@ -474,8 +488,8 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int y = tc.ty0 + wave * P + p;
-                    const bool live = co0 < a.cs_out && y < H && x < W;
-                    const size_t o = live ? ((size_t)(tc.b * H + y) * W + x) * a.cs_out + co0 : 0;   // dead lanes: any valid address
+                    const bool live = co0 < cs_o && y < H && x < W;
+                    const size_t o = live ? ((size_t)(tc.b * H + y) * W + x) * cs_o + co0 : 0;   // dead lanes: any valid address
                     if (EPI == EP_MASK) mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + o);
                     if (STAT == 2) zz[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + o);
                 }
@@ -485,14 +499,14 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
                 f16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (EPI == EP_RELU) v[r] = (f16)fmaxf(acc[m][p][r] + bias[m][r], 0.f);
-                    else if (EPI == EP_MASK) v[r] = ((float)mk[p][r] > 0.f) ? (f16)acc[m][p][r] : (f16)0.f;
-                    else v[r] = (f16)acc[m][p][r];
+                    if (EPI == EP_RELU) v[r] = (f16)fmaxf(ac[m][p][r] + bs[m][r], 0.f);
+                    else if (EPI == EP_MASK) v[r] = ((float)mk[p][r] > 0.f) ? (f16)ac[m][p][r] : (f16)0.f;
+                    else v[r] = (f16)ac[m][p][r];
                 }
                 *reinterpret_cast<f16x4 *>(s_out + ((wave * P + p) * 16 + n) * OPITCH + m * 16 + 4 * g) = v;
                 if (STAT) {
                     const int y = tc.ty0 + wave * P + p;
-                    const float live = (co0 < a.cs_out && y < H && x < W) ? 1.f : 0.f;
+                    const float live = (co0 < cs_o && y < H && x < W) ? 1.f : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float f = live * (float)v[r];
@@ -503,26 +517,20 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             }
         }
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    if (a.epi == EP_RELU) { if (want_stats) write_tile(I0{}, I1{}); else write_tile(I0{}, I0{}); }
-    else if (a.epi == EP_MASK) { if (dystat) write_tile(I2{}, I2{}); else write_tile(I2{}, I0{}); }
-    else { if (dystat) write_tile(I1{}, I2{}); else write_tile(I1{}, I0{}); }
-    __syncthreads();
-    IMK_STAMP(4);
-    {   // copy-out: 16-byte chunks, (MT * 2) per pixel; channel tiles beyond cs_out are skipped
+    // copy-out: 16-byte chunks, (MT * 2) per pixel; channel tiles beyond cs_o are skipped
+    auto copy_out = [&](f16 *out, int cs_o) {
         const int cpp = MT * 2;                                // chunks per pixel
-        const int n_live = min(cpp, (a.cs_out - ct0 * 16) / 8);   // cs_out is a multiple of 8
+        const int n_live = min(cpp, (cs_o - ct0 * 16) / 8);    // cs_o is a multiple of 8
         for (int i = t; i < TH * 16 * cpp; i += NT) {
             const int pixl = i / cpp, ch = i - pixl * cpp;
             const int py = pixl >> 4, px = pixl & 15;
             const int y = tc.ty0 + py, xx = tc.tx0 + px;
             if (ch < n_live && y < H && xx < W)
-                *reinterpret_cast<f16x8 *>(a.out + ((size_t)(tc.b * H + y) * W + xx) * a.cs_out + ct0 * 16 + ch * 8) =
+                *reinterpret_cast<f16x8 *>(out + ((size_t)(tc.b * H + y) * W + xx) * cs_o + ct0 * 16 + ch * 8) =
                     *reinterpret_cast<const f16x8 *>(s_out + pixl * OPITCH + ch * 8);
         }
-    }
-    IMK_STAMP(5);
-    if (want_stats) {  // workgroup-uniform branch
+    };
+    auto reduce_stats = [&](int cs_o) {
         __syncthreads();  // everyone is done reading the tile; reuse its LDS
         float *s_red = reinterpret_cast<float *>(smem);  // [NW waves][2][16*MT]
 #pragma unroll
@@ -539,20 +547,78 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
         if (t < 2 * 16 * MT) {
             const int which = t / (16 * MT), c = t - which * 16 * MT;
             const int co = ct0 * 16 + c;
-            if (co < a.cs_out) {
+            if (co < cs_o) {
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += s_red[(w * 2 + which) * 16 * MT + c];
-                a.stats_partial[(size_t)bx * 2 * a.cs_out + which * a.cs_out + co] = v;
+                a.stats_partial[(size_t)bx * 2 * cs_o + which * cs_o + co] = v;
             }
         }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    if constexpr (CHAIN) {
+        // ---- chained 1x1 conv (Conv3x3+ReLU -> Conv1x1+ReLU of a block): this workgroup holds ALL channels of its tile, so
+        // the second conv's pixel operand is the first's output tile where the epilogue put it -- each wave reads back the
+        // 64 pixels it wrote itself (no barrier), 8 consecutive channels per lane and k-step, against the regular packed
+        // weights of the 1x1 (one k-step per channel pass), staged next to the tile at kernel entry.
+        write_tile(I0{}, I0{}, acc, bias, a.cs_out);
+        const int nc8_2 = a.cs_out / 8, nc8p2 = imk_pass_chunks(nc8_2), ns2 = imk_cdiv_d(nc8_2, nc8p2);
+        const int mt2 = (a.cout2 + 15) / 16;
+        f32x4 acc2[MT][P];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc2[m][p] = f32x4{0, 0, 0, 0};
+        float bias2[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m * 16 + 4 * g + r;
+                bias2[m][r] = co < a.cout2 ? a.bias2[co] : 0.f;
+            }
+        for (int s2i = 0; s2i < ns2; ++s2i) {
+            const int c8 = s2i * nc8p2 + g;
+            const int off = (g < nc8p2 && c8 < nc8_2) ? c8 * 8 : 0;     // invalid k-slots: zero weights
+            f16x8 bf[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(s_out + ((wave * P + p) * 16 + n) * OPITCH + off);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < mt2) {
+                    const f16x8 af = *reinterpret_cast<const f16x8 *>(s_w2 + ((size_t)(m * ns2 + s2i) * 64 + lane) * 8);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc2[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[p], acc2[m][p], 0, 0, 0);
+                }
+            }
+        }
+        if (a.out) {                       // training: the backward pass needs the intermediate
+            __syncthreads();
+            copy_out(a.out, a.cs_out);
+            __syncthreads();               // (without the copy-out nobody reads another wave's rows: no barrier)
+        }
+        IMK_STAMP(4);
+        if (a.stats_partial) write_tile(I0{}, I1{}, acc2, bias2, a.cs_out2); else write_tile(I0{}, I0{}, acc2, bias2, a.cs_out2);
+        __syncthreads();
+        copy_out(a.out2, a.cs_out2);
+        IMK_STAMP(5);
+        if (a.stats_partial) reduce_stats(a.cs_out2);
+    } else {
+        if (a.epi == EP_RELU) { if (want_stats) write_tile(I0{}, I1{}, acc, bias, a.cs_out); else write_tile(I0{}, I0{}, acc, bias, a.cs_out); }
+        else if (a.epi == EP_MASK) { if (dystat) write_tile(I2{}, I2{}, acc, bias, a.cs_out); else write_tile(I2{}, I0{}, acc, bias, a.cs_out); }
+        else { if (dystat) write_tile(I1{}, I2{}, acc, bias, a.cs_out); else write_tile(I1{}, I0{}, acc, bias, a.cs_out); }
+        __syncthreads();
+        IMK_STAMP(4);
+        copy_out(a.out, a.cs_out);
+        IMK_STAMP(5);
+        if (want_stats) reduce_stats(a.cs_out);  // workgroup-uniform branch
     }
     IMK_STAMP_END(6);
 }
 
-template <int TH, int MT, int LM>
+template <int TH, int MT, int LM, bool CHAIN = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGeom gm) {
-    conv_mfma_body<TH, MT, LM>(a, gm, blockIdx.x, blockIdx.y);
+    conv_mfma_body<TH, MT, LM, CHAIN>(a, gm, blockIdx.x, blockIdx.y);
 }
 
 // =====================================================================================================
@@ -1550,7 +1616,10 @@ int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
     double pk_bytes = 0;
     for (int i = 0; i < jobs.n; ++i) pk_bytes += (double)jobs.j[i].ksize * jobs.j[i].ksize * jobs.j[i].cin * jobs.j[i].cout * 6;
     ImkProfScope prof(PF_STEP_TAIL, pk_bytes, stream);
-    pack_conv_batched_kernel<<<dim3(16, jobs.n), 256, 0, stream>>>(jobs);
+    // blocks per job: the widest layer (147 k fragment slots at alpha = 0.5, 590 k at alpha = 1) then has 2-9 slots per thread --
+    // the kernel sits at the very end of the step's dependent chain, and a slot is a chain of index divisions and one load
+    static const int bpj = []() { const char *e = getenv("IMK_PACK_BLOCKS"); return e ? atoi(e) : 64; }();
+    pack_conv_batched_kernel<<<dim3(bpj, jobs.n), 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -1657,8 +1726,18 @@ static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
     while (mt > 1 && n_sp * imk_cdiv(mt_total, mt) < 512) mt >>= 1;
     // the weight fragments of one pass sit in LDS next to the tile (1 KB per (channel tile, k-step); a pass has at most
     // 9 k-steps, so this always fits)
+    if (a.wpk2) {   // chained 1x1: one workgroup owns all channels of its tile (imk_conv_can_chain has checked the sizes)
+        const int mt2 = (a.cout2 + 15) / 16;
+        mt = (mt_total <= 2 && mt2 <= 2) ? 2 : 4;
+        if (mt_total > mt || mt2 > mt || TH != 16) return IMK_EUNSUPPORTED;
+    }
     lds = lds_base + (size_t)mt * nsp * 1024;
     const size_t out_bytes = (size_t)TH * 16 * (mt * 16 + 8) * sizeof(f16);   // the epilogue's output tile reuses the LDS
+    if (a.wpk2) {
+        const int nc8_2 = a.cs_out / 8;
+        lds = imk_chain_w2_offset(lds_base + (size_t)mt * nsp * 1024, out_bytes) +
+              (size_t)((a.cout2 + 15) / 16) * imk_cdiv_d(nc8_2, imk_pass_chunks(nc8_2)) * 1024;
+    }
     if (lds < out_bytes) lds = out_bytes;
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
     L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp};
@@ -1685,6 +1764,16 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         return IMK_OK;
     };
     ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), conv_algorithmic_bytes(a), stream);
+    if (a.wpk2) {   // Conv3x3+ReLU -> Conv1x1+ReLU in one launch: encoder blocks pool on load, decoder blocks read a BatchNorm output
+        if (L.gy != 1 || L.th != 16) return IMK_EUNSUPPORTED;
+        if (a.x.lmode == LM_POOL) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4, LM_POOL, true>) : launch(conv_mfma_kernel<16, 2, LM_POOL, true>);
+        else if (a.x.lmode == LM_AFFINE) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4, LM_AFFINE, true>) : launch(conv_mfma_kernel<16, 2, LM_AFFINE, true>);
+        else return IMK_EUNSUPPORTED;
+        if (rc) return rc;
+        if (a.stats_rows) *a.stats_rows = L.gx;
+        IMK_LAUNCH_CHECK();
+        return IMK_OK;
+    }
 #define IMK_MFMA_MT(TH, LM) \
     (L.mt == 4 ? launch(conv_mfma_kernel<TH, 4, LM>) : (L.mt == 2 ? launch(conv_mfma_kernel<TH, 2, LM>) : launch(conv_mfma_kernel<TH, 1, LM>)))
 #define IMK_MFMA_TH(LM) (L.th == 16 ? IMK_MFMA_MT(16, LM) : IMK_MFMA_MT(8, LM))
@@ -1892,6 +1981,26 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
 
+// The per-tile kernel's chain (conv_mfma_kernel<..., CHAIN>): a 3x3 conv with 17-64 output channels that pools or reads a
+// BatchNorm output, followed by a 1x1 with at most as many 16-channel tiles -- the mid / deep blocks.  The second conv uses
+// its regular forward pack.  Bit-identical to the two per-tile launches.  Measured (ms per training step B = 32 | inference
+// call B = 128; off / on): ISIC 1.104 / 1.095 | 0.637 / 0.592, SUIM 2.052 / 2.028 | 1.463 / 1.360, HeLa 2.022 / 2.002 | 1.386 /
+// 1.288, Cityscapes 3.11 / 3.10 | 2.652 / 2.534: inference drops the intermediate tensor's write and read, training keeps
+// the write and trades a launch for fewer, longer workgroups.  Layers the 17-32 channel kernel would take (conv_wide_ok)
+// chain when the intermediate is not stored or the launch is small (EvalNet's full-resolution towers in training: 2.87 ms
+// per step as two conv_wide launches, 2.94 chained).  IMK_CONV_CHAIN_TILE = 0 off, 2 always.
+bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
+    static const int mode = []() { const char *e = getenv("IMK_CONV_CHAIN_TILE"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return false;
+    const bool pipe_ok = pipe_enabled() && a.x.cs_in <= 16 && a.cout <= 16;
+    if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;
+    if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
+    const bool wide = a.x.cs_in <= 32 && a.cout <= 32 && a.x.lmode != LM_POOL;     // conv_wide_kernel's layers
+    if (mode == 1 && wide && store_mid && (long long)a.B * imk_cdiv(a.H, 16) * imk_cdiv(a.W, TW) > 2048) return false;
+    const int mt1 = (a.cout + 15) / 16, mt2 = (cout2 + 15) / 16, mt = (mt1 <= 2 && mt2 <= 2) ? 2 : 4;
+    return mt1 <= mt && mt2 <= mt && conv_tile_h(a.x.cs_in, 3) == 16;
+}
+
 // Can this dgrad launch also produce the weight gradient of its conv (ImkConvArgs::wg_partial)?  Mirrors the choices of
 // imk_launch_conv / launch_conv_pipe_any: pipelined kernel, full tiles, every lane owning real channels.
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
@@ -1924,9 +2033,11 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     const bool pipe_ok = g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
     a.pair = pipe_ok && pair_enabled() && a.cout <= 8;   // must mirror imk_conv_pair_layout
     if (a.wpk2 && a.pair && a.cout2 > 8) return IMK_EUNSUPPORTED;
-    if (a.wpk2) {   // fused second stage: only the pipelined kernel implements it (callers check imk_conv_can_chain)
-        if (!pipe_ok || a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cout2 > 16 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
-        return launch_conv_pipe_any(a, stream);
+    if (a.wpk2) {   // fused second stage (callers check imk_conv_can_chain / imk_conv_can_chain_tile)
+        if (a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
+        if (pipe_ok) return a.cout2 > 16 ? IMK_EUNSUPPORTED : launch_conv_pipe_any(a, stream);
+        if (!imk_conv_can_chain_tile(a, a.cout2, a.out != nullptr)) return IMK_EUNSUPPORTED;
+        return launch_conv_mfma(a, stream);
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
     if (a.x.lmode == LM_STEM) return IMK_EUNSUPPORTED;

@@ -87,6 +87,8 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
 bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
+// ... by the per-tile kernel (17-64 channels), which takes the 1x1's regular forward pack as ImkConvArgs::wpk2
+bool imk_conv_can_chain_tile(const ImkConvArgs &first, int cout2, bool store_intermediate);
 // inference: can the input block (u8_c image channels -> ch0) be computed on load by the conv that follows it (LM_STEM)?
 bool imk_conv_stem_fusable(int u8_c, int ch0, int cout_next);
 // "Pair" fragment layout (see conv_pipe_kernel): used by every conv operand with <= 8 output channels that the

@@ -201,8 +201,9 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
     if (fused) *fused = false;
     if (conv2 >= 0) {
         const ImkLayer &l2 = c.p->layers[conv2];
-        if (l2.pk_chain >= 0 && imk_conv_can_chain(a, l2.cout)) {
-            a.wpk2 = reinterpret_cast<const f16 *>(c.packed + l2.pk_chain);
+        const bool pipe_chain = l2.pk_chain >= 0 && imk_conv_can_chain(a, l2.cout);
+        if (pipe_chain || (!x_override && l2.ksize == 1 && imk_conv_can_chain_tile(a, l2.cout, c.train || g_imk_materialize))) {
+            a.wpk2 = pipe_chain ? reinterpret_cast<const f16 *>(c.packed + l2.pk_chain) : c.wfwd(conv2);
             a.bias2 = c.params + l2.off_b;
             a.out2 = c.act(conv2);
             a.cout2 = l2.cout; a.cs_out2 = imk_pad8(l2.cout);
