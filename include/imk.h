@@ -93,7 +93,7 @@ IMK_API int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *mas
  * ---------------------------------------------------------------------------------------------- */
 
 typedef struct imk_unet_cfg {
-    int h, w;        /* input height / width; multiples of 16 (4 poolings) */
+    int h, w;        /* input height / width; multiples of 16 (4 poolings); h * w < 2^24 and w < 2^16, else IMK_EUNSUPPORTED */
     int c_in;        /* image channels (1 or 3)                              */
     int n_out;       /* output maps K (unet.py:63)                           */
     int ch[5];       /* int(16a), int(32a), int(64a), int(128a), int(256a)   (unet.py:49-56) */
@@ -104,7 +104,8 @@ typedef struct imk_unet_plan imk_unet_plan; /* opaque, host memory (U-Net and Ev
 
 /* EvalNet (evalnet.py:24-73), see the section at the end of this file */
 typedef struct imk_evalnet_cfg {
-    int h, w;            /* input height / width: even, >= 64 (6 poolings; odd rows / columns are dropped like Keras does) */
+    int h, w;            /* input height / width: even, >= 64 (6 poolings; odd rows / columns are dropped like Keras does);
+                            h * w < 2^24 and w < 2^16, else IMK_EUNSUPPORTED */
     int ca, cb;          /* channels of input A (image) and input B (mask stack); 1..4 each, cb up to 64 with b_onehot */
     int n_out;           /* units per Dense head: 1 (get_evalnet) or inputB_channels (get_evalnet_miou) */
     int two_heads;       /* 0: one sigmoid head (evalnet.py:45); 1: 'iou' + 'detection' (evalnet.py:70-71) */

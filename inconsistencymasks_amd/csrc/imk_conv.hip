@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // LDS, too), the affine applied to the transposed reads with the lane's channel constants.
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
-                                                        float inv_tx, float inv_pi) {
+                                                        unsigned magic_tx, int grid_q, int grid_r) {
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
     static_assert(WG != 3 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 3x3 dgrad in front of a BatchNorm");
@@ -681,6 +681,35 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int cs_in = a.x.cs_in;
     const int per_img = tiles_x * tiles_y;
     auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
+    // ---- addresses = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset) -------------------------------
+    // Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of the loop cost a 64 x 32-bit multiply
+    // in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
+    // and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of a kernel
+    // whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Now the tile index is divided in scalar
+    // registers (s_mul_hi_u32 by a host-computed magic number), the tile's base address of each tensor is scalar arithmetic,
+    // and a lane adds an offset relative to the tile origin: a constant for the stores and epilogue loads of full tiles, one
+    // clamp (v_med3) per coordinate and one 24-bit multiply-add (full rate) for a staged halo pixel.
+    struct Tile { int b, r, ty0, tx0; };         // r: the tile's index inside image b
+    // (b, r) of the workgroup's tiles advance by the grid size = grid_q images + grid_r tiles (host-computed): no division by
+    // the tiles per image in the loop, and tile rows come from one s_mul_hi_u32 (r * tiles_x < 2^32 for images < 2^24 pixels)
+    auto tile_at = [&](int b, int r) {
+        Tile c;
+        c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
+        const unsigned ru = (unsigned)c.r;
+        const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);
+        c.ty0 = (int)ty * 16;
+        c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
+        return c;
+    };
+    auto tile_next = [&](const Tile &c) {
+        int b = c.b + grid_q, r = c.r + grid_r;
+        if (r >= per_img) { r -= per_img; ++b; }
+        return tile_at(b, r);
+    };
+    constexpr unsigned CSB = NC8 * 16;          // bytes per pixel of the (fp16) input tensor: cs_in = NC8 * 8
+    auto pix_base = [&](const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {   // all scalar; may point in front of the tensor
+        return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
+    };
 
     // packed weights and per-lane LDS offsets of every k-step: once per workgroup
     f16x8 af[MAX_NS];
@@ -767,39 +796,104 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int u8_cin = a.x.cin, u8_nseg = 16 * u8_cin;
     const int u8_t = t < u8_nseg ? t : 0;                 // idle threads repeat segment 0 (loads are unconditional)
     const int u8_row = u8_t / u8_cin, u8_seg = u8_t - u8_row * u8_cin;
-    auto issue = [&](int tile) {
-        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
+    const unsigned u8_off = (unsigned)(u8_row * W * u8_cin + u8_seg * 16);
+    // thread t <-> pixel t of a full tile (WG = 1, 2), in bytes of a tensor with the output's channel stride
+    const unsigned cso_b = (unsigned)a.cs_out * 2u;
+    const unsigned xw_off = (unsigned)((t >> 4) * W + (t & 15)) * cso_b;
+    auto issue = [&](const Tile &tc) {
         if constexpr (U8ROWS) {
-            rowseg = *reinterpret_cast<const uint4 *>((const uint8_t *)a.x.in + ((size_t)(tc.b * H + tc.ty0 + u8_row) * W + tc.tx0) * u8_cin + u8_seg * 16);
+            rowseg = *reinterpret_cast<const uint4 *>(pix_base(a.x.in, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)u8_cin) + u8_off);
             return;
+        }
+        // the halo tile's origin (-1 at the image border) and the window of its rows / columns that lie inside the image
+        const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
+        const int lo_y = oy < 0 ? -oy : 0, hi_y = min(HT - 1, H - 1 - oy);
+        const int lo_x = ox < 0 ? -ox : 0, hi_x = min(WT - 1, W - 1 - ox);
+        const char *b_in = nullptr, *b_in2 = nullptr;
+        unsigned row2_b = 0, w2 = 0;
+        int oyl = 0, oxl = 0, pix0 = 0, nb = 0, hw = 0;
+        if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+            b_in = pix_base(a.x.in, tc.b, H, W, oy, ox, CSB);
+            if constexpr (LM == LM_BNBWD) b_in2 = pix_base(a.x.in2, tc.b, H, W, oy, ox, CSB);
+        } else if constexpr (LM == LM_POOL) {
+            const int H2 = a.x.src_h ? a.x.src_h : 2 * H, W2 = a.x.src_w ? a.x.src_w : 2 * W;
+            b_in = pix_base(a.x.in, tc.b, H2, W2, 2 * oy, 2 * ox, CSB);
+            w2 = (unsigned)W2;
+            row2_b = w2 * CSB;
+        } else if constexpr (LM == LM_UPADD) {
+            oyl = oy >> 1; oxl = ox >> 1;
+            b_in = pix_base(a.x.in, tc.b, H / 2, W / 2, oyl, oxl, CSB);
+            b_in2 = pix_base(a.x.in2, tc.b, H, W, oy, ox, CSB);
+        } else {                                        // uint8 pixels: nb bytes each
+            nb = LM == LM_STEM ? a.x.u8_c : a.x.cin;
+            hw = H * W;
+            pix0 = oy * W + ox;                         // may be negative; pix0 + (a clamped pixel's offset) never is
+            b_in = reinterpret_cast<const char *>(a.x.in) + (long long)tc.b * hw * nb;
         }
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
-            const int y = tc.ty0 + it_py[k] - halo, x = tc.tx0 + it_px[k] - halo;
-            const bool ok = it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
-            raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
+            const int ry = min(max(it_py[k], lo_y), hi_y), rx = min(max(it_px[k], lo_x), hi_x);   // clamped into the image
+            const bool ok = it_lds[k] >= 0 && ry == it_py[k] && rx == it_px[k];
+            if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+                const unsigned o = (__umul24(ry, W) + rx) * CSB + it_c8[k] * 16;
+                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + o);
+                if constexpr (LM == LM_BNBWD) raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in2 + o);
+            } else if constexpr (LM == LM_POOL) {
+                const unsigned o = (__umul24(2 * ry, w2) + 2 * rx) * CSB + it_c8[k] * 16;
+                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + o);
+                raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in + o + CSB);
+                raw[k].v[2] = *reinterpret_cast<const f16x8 *>(b_in + o + row2_b);
+                raw[k].v[3] = *reinterpret_cast<const f16x8 *>(b_in + o + row2_b + CSB);
+            } else if constexpr (LM == LM_UPADD) {
+                const int yl = ((oy + ry) >> 1) - oyl, xl = ((ox + rx) >> 1) - oxl;
+                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + (__umul24(yl, W / 2) + xl) * CSB + it_c8[k] * 16);
+                raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in2 + (__umul24(ry, W) + rx) * CSB + it_c8[k] * 16);
+            } else {
+                // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
+                // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a
+                // few bytes early, so nothing past the image is read (H * W * nb >= 4).
+                typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+                const int pidx = pix0 + (int)(__umul24(ry, W) + rx);         // pixel index inside its image
+                const int rem = __mul24(hw - pidx, nb);                       // bytes from this pixel to the end of the image
+                const int back = rem >= 4 ? 0 : 4 - rem;
+                const uint32_t v = *reinterpret_cast<const u32_unaligned *>(b_in + (unsigned)(__mul24(pidx, nb) - back)) >> (8 * back);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[k].b[j] = (j < nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
+            }
             valid |= (ok ? 1u : 0u) << k;
         }
         if constexpr (WG == 1 || WG == 2) {      // thread t <-> pixel t of the (full) tile
-            const f16 *px = (WG == 1 ? a.mask : a.dystat_z) + ((size_t)(tc.b * H + tc.ty0 + (t >> 4)) * W + tc.tx0 + (t & 15)) * a.cs_out;
+            const char *px = pix_base(WG == 1 ? a.mask : a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) + xw_off;
 #pragma unroll
-            for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 8);
+            for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 16);
         }
         if constexpr (WG == 3) {
+            const char *bz = pix_base(a.dystat_z, tc.b, H, W, oy, ox, cso_b);      // 3x3: the same halo window as the gradient tile
             xvalid = 0;
 #pragma unroll
             for (int k = 0; k < MAX_XI; ++k) {
-                const int y = tc.ty0 + xi_py[k] - 1, x = tc.tx0 + xi_px[k] - 1;
-                const bool ok = xi_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
-                xr[k] = *reinterpret_cast<const f16x8 *>(a.dystat_z + ((size_t)(tc.b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1)) * a.cs_out + xi_c8[k] * 8);
+                const int ry = min(max(xi_py[k], lo_y), hi_y), rx = min(max(xi_px[k], lo_x), hi_x);
+                const bool ok = xi_lds[k] >= 0 && ry == xi_py[k] && rx == xi_px[k];
+                xr[k] = *reinterpret_cast<const f16x8 *>(bz + __umul24(__umul24(ry, W) + rx, cso_b) + xi_c8[k] * 16);
                 xvalid |= (ok ? 1u : 0u) << k;
             }
         }
     };
+    // this lane's output pixels (column block p: tile row tile_row(p), column n) as byte offsets from the tile origin; constant
+    // over full tiles.  o1: tensors with the output's channel stride (out, ReLU mask, BatchNorm output), o2: the chain's output.
+    const unsigned cso2_b = CHAIN ? (unsigned)a.cs_out2 * 2u : 0u;
+    unsigned o1c[P], o2c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const unsigned lp = (unsigned)(tile_row(p) * W + n);
+        o1c[p] = lp * cso_b + co0 * 2;
+        o2c[p] = lp * cso2_b + co0 * 2;
+    }
 
-    int tile = blockIdx.x;
-    issue(tile < n_tiles ? tile : n_tiles - 1);
+    int tile = blockIdx.x;                // < n_tiles: the grid never exceeds the tile count
+    Tile tc = tile_at(tile / per_img, tile % per_img);
+    issue(tc);
     stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
     if constexpr (WG == 3) {              // BatchNorm of the conv's input (LM_RAW leaves the table free)
         if (t < a.cs_out) { s_aff[t] = a.wg_sc[t]; s_aff[16 + t] = a.wg_sh[t]; }
@@ -840,35 +934,46 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 }
             }
         }
-        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
-        const int x = tc.tx0 + n;
         __syncthreads();
         // output pixel of each column block; partial tiles clamp the coordinates used for LOADS (stores are guarded)
-        size_t pix[P];
+        const char *b_o1 = pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, cso_b);
+        const char *b_o2 = CHAIN ? pix_base(a.out2, tc.b, H, W, tc.ty0, tc.tx0, cso2_b) : nullptr;
+        const char *b_mk = (EPI == EP_MASK && WG != 1) ? pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
+        const char *b_zq = (DYSTAT && WG != 2) ? pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
+        unsigned o1[P], o1l[P], o2[P];     // o1l: for loads, lanes without real channels read channel 0
         bool inb[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int y = tc.ty0 + tile_row(p);
-            inb[p] = FULL || (y < H && x < W);
-            pix[p] = (size_t)(tc.b * H + (FULL ? y : min(y, H - 1))) * W + (FULL ? x : min(x, W - 1));
+            if constexpr (FULL) {
+                o1[p] = o1l[p] = o1c[p]; o2[p] = o2c[p]; inb[p] = true;
+            } else {
+                const int my = H - 1 - tc.ty0, mx = W - 1 - tc.tx0, r = tile_row(p);
+                inb[p] = r <= my && n <= mx;
+                const unsigned lp = __umul24(min(r, my), W) + min(n, mx);
+                const unsigned ob = __umul24(lp, cso_b);
+                o1[p] = ob + co0 * 2;
+                o1l[p] = ob + (lane_out ? co0 * 2 : 0);
+                o2[p] = __umul24(lp, cso2_b) + co0 * 2;
+            }
         }
         f16x4 mk[P], zq[P];
         if (EPI == EP_MASK) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if constexpr (WG == 1) mk[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
-                else mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+                else mk[p] = *reinterpret_cast<const f16x4 *>(b_mk + o1l[p]);
             }
         }
         if (DYSTAT) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if constexpr (WG == 2) zq[p] = *reinterpret_cast<const f16x4 *>(s_x + ((tile_row(p) * 16 + n) * XS) * 16 + co0 * 2);
-                else zq[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out ? co0 : 0));
+                else zq[p] = *reinterpret_cast<const f16x4 *>(b_zq + o1l[p]);
             }
         }
         const int next = tile + gridDim.x;
-        issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
+        const Tile tn = next < n_tiles ? tile_next(tc) : tc;
+        issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         if constexpr (WG == 3) {
             // as below, with the 9 taps: dW[tap][ci][co] += x[pixel + tap][ci] * dA[pixel][co]; both tiles carry a halo here
             const int qq = n >> 2, pp = n & 3;
@@ -946,14 +1051,14 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 f16x4 hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hv[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
-                if (CHAIN == 1 && (FULL || inb[p]) && lane_mid) *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + co0) = hv;
+                if (CHAIN == 1 && (FULL || inb[p]) && lane_mid) *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p]) = hv;
                 const f16x8 bf2 = {hv[0], hv[1], hv[2], hv[3], 0, 0, 0, 0};
                 const f32x4 a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2, bf2, f32x4{0, 0, 0, 0}, 0, 0, 0);
                 f16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(a2[r] + bias2[r], 0.f);
                 if ((FULL || inb[p]) && lane_out) {
-                    *reinterpret_cast<f16x4 *>(a.out2 + pix[p] * a.cs_out2 + co0) = v;
+                    *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o2) + o2[p]) = v;
                     if (want_stats)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
@@ -974,7 +1079,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     for (int r = 0; r < 4; ++r) v[r] = (f16)acc[p][r];
                 }
                 if ((FULL || inb[p]) && lane_out) {
-                    *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + co0) = v;
+                    *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p]) = v;
                     if (DYSTAT) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * (float)zq[p][r]; }
@@ -987,6 +1092,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
+        tc = tn;
     }
     if constexpr (WG == 3) {    // [10][256]: 9 taps + bias, reduced over the 4 waves in two rounds of 5 (20 KB of LDS)
         float *s_acc = reinterpret_cast<float *>(smem);
@@ -1793,6 +1899,10 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
+// n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled
+// by the kernels
+static inline unsigned div_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
@@ -1811,7 +1921,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x, 1.0f / (tiles_x * tiles_y));
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -1956,6 +2066,11 @@ static int launch_conv_wide_any(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_WIDE_SEL
 }
 
+// Limits of conv_pipe_kernel's address arithmetic (24-bit multiplies of tile-relative pixel offsets, 32-bit magic division of
+// a tile's index inside its image): images below 2^24 pixels, rows below 2^16.  Plans are refused above that
+// (imk_conv_max_pixels), so the layouts decided at plan time (pair layout, chains) never meet an image that does not fit.
+static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
+
 static bool pipe_enabled() {
     static const bool on = []() { const char *e = getenv("IMK_CONV_PIPE"); return !(e && e[0] == '0'); }();
     return on;
@@ -1976,7 +2091,7 @@ bool imk_conv_stem_fusable(int u8_c, int ch0, int cout_next) {
 
 bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     static const bool off = []() { const char *e = getenv("IMK_CONV_CHAIN"); return e && e[0] == '0'; }();
-    if (off || !pipe_enabled()) return false;
+    if (off || !pipe_enabled() || !pipe_fits(a)) return false;
     if (pair_enabled() && a.cout <= 8 && cout2 > 8) return false;   // the two stages must use the same fragment layout
     return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
@@ -1992,7 +2107,7 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
 bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
     static const int mode = []() { const char *e = getenv("IMK_CONV_CHAIN_TILE"); return e ? atoi(e) : 1; }();
     if (mode == 0) return false;
-    const bool pipe_ok = pipe_enabled() && a.x.cs_in <= 16 && a.cout <= 16;
+    const bool pipe_ok = pipe_enabled() && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16;
     if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;
     if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
     const bool wide = a.x.cs_in <= 32 && a.cout <= 32 && a.x.lmode != LM_POOL;     // conv_wide_kernel's layers
@@ -2005,7 +2120,7 @@ bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
 // imk_launch_conv / launch_conv_pipe_any: pipelined kernel, full tiles, every lane owning real channels.
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_FUSE_WGRAD"); return e && e[0] == '0'; }();
-    if (off || !pipe_enabled()) return false;
+    if (off || !pipe_enabled() || !pipe_fits(a)) return false;
     if (a.wpk2) return false;
     const bool form1 = a.ksize == 1 && a.x.lmode == LM_BNBWD && a.epi == EP_MASK && a.mask && !(a.dystat_z && a.stats_partial);
     const bool form2 = a.x.lmode == LM_RAW && a.epi == EP_PLAIN && a.dystat_z && a.stats_partial;     // 1x1 and 3x3
@@ -2030,7 +2145,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     if (a.x.cs_in > 512) return IMK_EUNSUPPORTED;
     static const bool env_checked = []() { const char *e = getenv("IMK_CONV_PIPE"); if (e && e[0] == '0') g_use_pipe = false; return true; }();
     (void)env_checked;
-    const bool pipe_ok = g_use_pipe && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
+    const bool pipe_ok = g_use_pipe && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
     a.pair = pipe_ok && pair_enabled() && a.cout <= 8;   // must mirror imk_conv_pair_layout
     if (a.wpk2 && a.pair && a.cout2 > 8) return IMK_EUNSUPPORTED;
     if (a.wpk2) {   // fused second stage (callers check imk_conv_can_chain / imk_conv_can_chain_tile)

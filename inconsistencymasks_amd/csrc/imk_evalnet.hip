@@ -155,6 +155,7 @@ bool ecfg_ok(const imk_evalnet_cfg *c) {
 extern "C" int imk_evalnet_plan_create(const imk_evalnet_cfg *cfg, imk_unet_plan **out) {
     IMK_CHECK_ARG(out);
     if (!ecfg_ok(cfg)) return IMK_EINVAL;
+    if ((long long)cfg->h * cfg->w >= imk_conv_max_pixels() || cfg->w >= (1 << 16)) return IMK_EUNSUPPORTED;   // include/imk.h: image size limit
     imk_unet_plan *p = new (std::nothrow) imk_unet_plan();
     if (!p) return IMK_EINVAL;
     p->net = 1;

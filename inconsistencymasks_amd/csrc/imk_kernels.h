@@ -86,6 +86,7 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 
 // weight packing (fp32 HWIO -> fp16 fragment order).  transposed = 1 gives the dgrad operand; transposed = 2 the
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
+inline long long imk_conv_max_pixels() { return 1ll << 24; }   // H * W of a plan (the shallow kernel's 24-bit offset arithmetic)
 bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
 // ... by the per-tile kernel (17-64 channels), which takes the 1x1's regular forward pack as ImkConvArgs::wpk2
 bool imk_conv_can_chain_tile(const ImkConvArgs &first, int cout2, bool store_intermediate);

@@ -166,6 +166,7 @@ bool cfg_ok(const imk_unet_cfg *c) {
 extern "C" int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out) {
     IMK_CHECK_ARG(out);
     if (!cfg_ok(cfg)) return IMK_EINVAL;
+    if ((long long)cfg->h * cfg->w >= imk_conv_max_pixels() || cfg->w >= (1 << 16)) return IMK_EUNSUPPORTED;   // include/imk.h: image size limit
     imk_unet_plan *p = new (std::nothrow) imk_unet_plan();
     if (!p) return IMK_EINVAL;
     p->cfg = *cfg;

@@ -492,3 +492,40 @@ def test_training_run_is_bit_reproducible(UNet):
         return m.params.clone()
     a, b = run(), run()
     assert torch.equal(a, b)
+
+
+_CHAIN_CHILD = r"""
+import hashlib, sys, torch
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd.unet import UNet
+g = torch.Generator(device="cuda").manual_seed(1)
+out = []
+for (h, w, c, k, alpha, act, loss) in [(64, 80, 3, 1, 0.5, "sigmoid", 0), (48, 64, 3, 9, 1.0, "softmax", 1), (48, 80, 1, 2, 1.25, "sigmoid", 0)]:
+    x = torch.randint(0, 256, (6, h, w, c), dtype=torch.uint8, device="cuda", generator=g)
+    y = ((torch.rand((6, h, w, k), device="cuda", generator=g) > 0.6).to(torch.uint8) if loss == 0
+         else torch.randint(0, k, (6, h, w), dtype=torch.uint8, device="cuda", generator=g))
+    m = UNet(h, w, c, k, alpha, act, seed=11)
+    for _ in range(3):
+        m.train_step(x, y, loss, 3e-3, 1e-4)
+    p = m.predict_device(x)
+    out.append(hashlib.sha1(m.params.cpu().numpy().tobytes() + p.cpu().numpy().tobytes()).hexdigest())
+print("SHA", " ".join(out))
+"""
+
+
+def test_chained_per_tile_conv_is_bit_identical_to_two_launches(tmp_path):
+    """conv_mfma_kernel<..., CHAIN> (Conv3x3+ReLU -> Conv1x1+ReLU of the mid / deep blocks in one launch) against the same
+    kernel launched twice: same parameters after 3 training steps and same probabilities, bit for bit, at ragged sizes and
+    at widths 0.5 / 1 / 1.25 (one process each: the switch is read once; the 17-32 channel kernel is off in both so that
+    the second conv runs on the per-tile kernel either way)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "chain_child.py"
+    script.write_text(_CHAIN_CHILD.format(root=root))
+    got = []
+    for mode in ("0", "2"):
+        env = {**os.environ, "IMK_CONV_WIDE": "0", "IMK_CONV_CHAIN_TILE": mode}
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert got[0] == got[1]
