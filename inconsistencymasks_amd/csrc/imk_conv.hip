@@ -622,6 +622,105 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 }
 
 // =====================================================================================================
+// Addresses of the persistent kernels = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset).
+// Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of a tile loop cost a 64 x 32-bit multiply
+// in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
+// and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of kernels
+// whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Instead: (image, tile in image) advance by
+// the grid size without a division, the tile row comes from one s_mul_hi_u32 by a host-computed magic number, the tile's
+// base address of each tensor is scalar arithmetic, and a lane adds an offset relative to the tile origin -- a constant for
+// the stores and epilogue loads of full tiles, one clamp per coordinate and one 24-bit multiply-add (full rate) for a
+// staged halo pixel.  Limits: imk_conv_max_pixels() per image, rows < 2^16 (plans are refused above).
+// =====================================================================================================
+struct PTile { int b, r, ty0, tx0; };            // r: the tile's index inside image b; all four live in scalar registers
+__device__ __forceinline__ PTile ptile_at(int b, int r, int tiles_x, unsigned magic_tx) {
+    PTile c;
+    c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
+    const unsigned ru = (unsigned)c.r;
+    const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);   // r * tiles_x < 2^32
+    c.ty0 = (int)ty * 16;
+    c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
+    return c;
+}
+__device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid_r, int per_img, int tiles_x, unsigned magic_tx) {
+    int b = c.b + grid_q, r = c.r + grid_r;      // the grid size = grid_q images + grid_r tiles (host-computed)
+    if (r >= per_img) { r -= per_img; ++b; }
+    return ptile_at(b, r, tiles_x, magic_tx);
+}
+// base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)
+__device__ __forceinline__ const char *pix_base(const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {
+    return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
+}
+
+// The staged input of one tile: scalar bases of the source tensor(s) at the halo tile's origin (-1 at the image border) and
+// the window of its rows / columns that lie inside the image.
+template <int LM>
+struct PSrc {
+    const char *b_in, *b_in2;
+    unsigned row2_b, w2;
+    int oy, ox, oyl, oxl, pix0, nb, hw, lo_y, hi_y, lo_x, hi_x;
+};
+template <int LM, unsigned CSB>                    // CSB: bytes per pixel of the fp16 input tensor
+__device__ __forceinline__ PSrc<LM> psrc_of(const ImkInput &in, const PTile &tc, int halo, int HT, int WT, int H, int W) {
+    PSrc<LM> s{};
+    const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
+    s.oy = oy; s.ox = ox;
+    s.lo_y = oy < 0 ? -oy : 0; s.hi_y = min(HT - 1, H - 1 - oy);
+    s.lo_x = ox < 0 ? -ox : 0; s.hi_x = min(WT - 1, W - 1 - ox);
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+        s.b_in = pix_base(in.in, tc.b, H, W, oy, ox, CSB);
+        if constexpr (LM == LM_BNBWD) s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, CSB);
+    } else if constexpr (LM == LM_POOL) {
+        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
+        s.b_in = pix_base(in.in, tc.b, H2, W2, 2 * oy, 2 * ox, CSB);
+        s.w2 = (unsigned)W2;
+        s.row2_b = s.w2 * CSB;
+    } else if constexpr (LM == LM_UPADD) {
+        s.oyl = oy >> 1; s.oxl = ox >> 1;
+        s.b_in = pix_base(in.in, tc.b, H / 2, W / 2, s.oyl, s.oxl, CSB);
+        s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, CSB);
+    } else {                                        // uint8 pixels: nb bytes each
+        s.nb = LM == LM_STEM ? in.u8_c : in.cin;
+        s.hw = H * W;
+        s.pix0 = oy * W + ox;                       // may be negative; pix0 + (a clamped pixel's offset) never is
+        s.b_in = reinterpret_cast<const char *>(in.in) + (long long)tc.b * s.hw * s.nb;
+    }
+    return s;
+}
+// Chunk c8 of the halo tile's pixel (py, px), clamped into the image (unconditional load); returns whether it was inside.
+template <int LM, unsigned CSB>
+__device__ __forceinline__ bool psrc_load(const PSrc<LM> &s, int py, int px, int c8, int W, RawChunk<LM> &r) {
+    const int ry = min(max(py, s.lo_y), s.hi_y), rx = min(max(px, s.lo_x), s.hi_x);
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+        const unsigned o = (__umul24(ry, W) + rx) * CSB + c8 * 16;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
+        if constexpr (LM == LM_BNBWD) r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + o);
+    } else if constexpr (LM == LM_POOL) {
+        const unsigned o = (__umul24(2 * ry, s.w2) + 2 * rx) * CSB + c8 * 16;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
+        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in + o + CSB);
+        r.v[2] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b);
+        r.v[3] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b + CSB);
+    } else if constexpr (LM == LM_UPADD) {
+        const int yl = ((s.oy + ry) >> 1) - s.oyl, xl = ((s.ox + rx) >> 1) - s.oxl;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + (__umul24(yl, W / 2) + xl) * CSB + c8 * 16);
+        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + (__umul24(ry, W) + rx) * CSB + c8 * 16);
+    } else {
+        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
+        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
+        // bytes early, so nothing past the image is read (H * W * nb >= 4).
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        const int pidx = s.pix0 + (int)(__umul24(ry, W) + rx);           // pixel index inside its image
+        const int rem = __mul24(s.hw - pidx, s.nb);                       // bytes from this pixel to the end of the image
+        const int back = rem >= 4 ? 0 : 4 - rem;
+        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(s.b_in + (unsigned)(__mul24(pidx, s.nb) - back)) >> (8 * back);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < s.nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
+    }
+    return ry == py && rx == px;
+}
+
+// =====================================================================================================
 // forward / dgrad, persistent + register-prefetch pipelined variant for the wide, shallow layers
 // (<= 16 input channels, <= 16 output channels: levels 0/1 at alpha <= 1, where 80 % of the bytes are).
 // Those layers are pure streaming (a 16x16x8 tile is 4 KB in, 4 KB out, 12 MFMAs), so what limits them
@@ -681,35 +780,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int cs_in = a.x.cs_in;
     const int per_img = tiles_x * tiles_y;
     auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
-    // ---- addresses = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset) -------------------------------
-    // Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of the loop cost a 64 x 32-bit multiply
-    // in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
-    // and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of a kernel
-    // whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Now the tile index is divided in scalar
-    // registers (s_mul_hi_u32 by a host-computed magic number), the tile's base address of each tensor is scalar arithmetic,
-    // and a lane adds an offset relative to the tile origin: a constant for the stores and epilogue loads of full tiles, one
-    // clamp (v_med3) per coordinate and one 24-bit multiply-add (full rate) for a staged halo pixel.
-    struct Tile { int b, r, ty0, tx0; };         // r: the tile's index inside image b
-    // (b, r) of the workgroup's tiles advance by the grid size = grid_q images + grid_r tiles (host-computed): no division by
-    // the tiles per image in the loop, and tile rows come from one s_mul_hi_u32 (r * tiles_x < 2^32 for images < 2^24 pixels)
-    auto tile_at = [&](int b, int r) {
-        Tile c;
-        c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
-        const unsigned ru = (unsigned)c.r;
-        const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);
-        c.ty0 = (int)ty * 16;
-        c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
-        return c;
-    };
-    auto tile_next = [&](const Tile &c) {
-        int b = c.b + grid_q, r = c.r + grid_r;
-        if (r >= per_img) { r -= per_img; ++b; }
-        return tile_at(b, r);
-    };
     constexpr unsigned CSB = NC8 * 16;          // bytes per pixel of the (fp16) input tensor: cs_in = NC8 * 8
-    auto pix_base = [&](const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {   // all scalar; may point in front of the tensor
-        return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
-    };
 
     // packed weights and per-lane LDS offsets of every k-step: once per workgroup
     f16x8 af[MAX_NS];
@@ -800,68 +871,17 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     // thread t <-> pixel t of a full tile (WG = 1, 2), in bytes of a tensor with the output's channel stride
     const unsigned cso_b = (unsigned)a.cs_out * 2u;
     const unsigned xw_off = (unsigned)((t >> 4) * W + (t & 15)) * cso_b;
-    auto issue = [&](const Tile &tc) {
+    auto issue = [&](const PTile &tc) {
         if constexpr (U8ROWS) {
             rowseg = *reinterpret_cast<const uint4 *>(pix_base(a.x.in, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)u8_cin) + u8_off);
             return;
         }
-        // the halo tile's origin (-1 at the image border) and the window of its rows / columns that lie inside the image
-        const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
-        const int lo_y = oy < 0 ? -oy : 0, hi_y = min(HT - 1, H - 1 - oy);
-        const int lo_x = ox < 0 ? -ox : 0, hi_x = min(WT - 1, W - 1 - ox);
-        const char *b_in = nullptr, *b_in2 = nullptr;
-        unsigned row2_b = 0, w2 = 0;
-        int oyl = 0, oxl = 0, pix0 = 0, nb = 0, hw = 0;
-        if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-            b_in = pix_base(a.x.in, tc.b, H, W, oy, ox, CSB);
-            if constexpr (LM == LM_BNBWD) b_in2 = pix_base(a.x.in2, tc.b, H, W, oy, ox, CSB);
-        } else if constexpr (LM == LM_POOL) {
-            const int H2 = a.x.src_h ? a.x.src_h : 2 * H, W2 = a.x.src_w ? a.x.src_w : 2 * W;
-            b_in = pix_base(a.x.in, tc.b, H2, W2, 2 * oy, 2 * ox, CSB);
-            w2 = (unsigned)W2;
-            row2_b = w2 * CSB;
-        } else if constexpr (LM == LM_UPADD) {
-            oyl = oy >> 1; oxl = ox >> 1;
-            b_in = pix_base(a.x.in, tc.b, H / 2, W / 2, oyl, oxl, CSB);
-            b_in2 = pix_base(a.x.in2, tc.b, H, W, oy, ox, CSB);
-        } else {                                        // uint8 pixels: nb bytes each
-            nb = LM == LM_STEM ? a.x.u8_c : a.x.cin;
-            hw = H * W;
-            pix0 = oy * W + ox;                         // may be negative; pix0 + (a clamped pixel's offset) never is
-            b_in = reinterpret_cast<const char *>(a.x.in) + (long long)tc.b * hw * nb;
-        }
+        const PSrc<LM> src = psrc_of<LM, CSB>(a.x, tc, halo, HT, WT, H, W);
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
-            const int ry = min(max(it_py[k], lo_y), hi_y), rx = min(max(it_px[k], lo_x), hi_x);   // clamped into the image
-            const bool ok = it_lds[k] >= 0 && ry == it_py[k] && rx == it_px[k];
-            if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-                const unsigned o = (__umul24(ry, W) + rx) * CSB + it_c8[k] * 16;
-                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + o);
-                if constexpr (LM == LM_BNBWD) raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in2 + o);
-            } else if constexpr (LM == LM_POOL) {
-                const unsigned o = (__umul24(2 * ry, w2) + 2 * rx) * CSB + it_c8[k] * 16;
-                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + o);
-                raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in + o + CSB);
-                raw[k].v[2] = *reinterpret_cast<const f16x8 *>(b_in + o + row2_b);
-                raw[k].v[3] = *reinterpret_cast<const f16x8 *>(b_in + o + row2_b + CSB);
-            } else if constexpr (LM == LM_UPADD) {
-                const int yl = ((oy + ry) >> 1) - oyl, xl = ((ox + rx) >> 1) - oxl;
-                raw[k].v[0] = *reinterpret_cast<const f16x8 *>(b_in + (__umul24(yl, W / 2) + xl) * CSB + it_c8[k] * 16);
-                raw[k].v[1] = *reinterpret_cast<const f16x8 *>(b_in2 + (__umul24(ry, W) + rx) * CSB + it_c8[k] * 16);
-            } else {
-                // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
-                // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a
-                // few bytes early, so nothing past the image is read (H * W * nb >= 4).
-                typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-                const int pidx = pix0 + (int)(__umul24(ry, W) + rx);         // pixel index inside its image
-                const int rem = __mul24(hw - pidx, nb);                       // bytes from this pixel to the end of the image
-                const int back = rem >= 4 ? 0 : 4 - rem;
-                const uint32_t v = *reinterpret_cast<const u32_unaligned *>(b_in + (unsigned)(__mul24(pidx, nb) - back)) >> (8 * back);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) raw[k].b[j] = (j < nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
-            }
-            valid |= (ok ? 1u : 0u) << k;
+            const bool in_img = psrc_load<LM, CSB>(src, it_py[k], it_px[k], it_c8[k], W, raw[k]);
+            valid |= ((it_lds[k] >= 0 && in_img) ? 1u : 0u) << k;
         }
         if constexpr (WG == 1 || WG == 2) {      // thread t <-> pixel t of the (full) tile
             const char *px = pix_base(WG == 1 ? a.mask : a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) + xw_off;
@@ -869,11 +889,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             for (int q = 0; q < NCX; ++q) xr[q] = *reinterpret_cast<const f16x8 *>(px + q * 16);
         }
         if constexpr (WG == 3) {
-            const char *bz = pix_base(a.dystat_z, tc.b, H, W, oy, ox, cso_b);      // 3x3: the same halo window as the gradient tile
+            const char *bz = pix_base(a.dystat_z, tc.b, H, W, src.oy, src.ox, cso_b);      // 3x3: the same halo window as the gradient tile
             xvalid = 0;
 #pragma unroll
             for (int k = 0; k < MAX_XI; ++k) {
-                const int ry = min(max(xi_py[k], lo_y), hi_y), rx = min(max(xi_px[k], lo_x), hi_x);
+                const int ry = min(max(xi_py[k], src.lo_y), src.hi_y), rx = min(max(xi_px[k], src.lo_x), src.hi_x);
                 const bool ok = xi_lds[k] >= 0 && ry == xi_py[k] && rx == xi_px[k];
                 xr[k] = *reinterpret_cast<const f16x8 *>(bz + __umul24(__umul24(ry, W) + rx, cso_b) + xi_c8[k] * 16);
                 xvalid |= (ok ? 1u : 0u) << k;
@@ -892,7 +912,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     }
 
     int tile = blockIdx.x;                // < n_tiles: the grid never exceeds the tile count
-    Tile tc = tile_at(tile / per_img, tile % per_img);
+    PTile tc = ptile_at(tile / per_img, tile % per_img, tiles_x, magic_tx);
     issue(tc);
     stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
     if constexpr (WG == 3) {              // BatchNorm of the conv's input (LM_RAW leaves the table free)
@@ -972,7 +992,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             }
         }
         const int next = tile + gridDim.x;
-        const Tile tn = next < n_tiles ? tile_next(tc) : tc;
+        const PTile tn = next < n_tiles ? ptile_next(tc, grid_q, grid_r, per_img, tiles_x, magic_tx) : tc;
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         if constexpr (WG == 3) {
             // as below, with the 9 taps: dW[tap][ci][co] += x[pixel + tap][ci] * dA[pixel][co]; both tiles carry a halo here
@@ -1162,7 +1182,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // =====================================================================================================
 template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL>
 __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
-                                                        float inv_tx, float inv_pi) {
+                                                        unsigned magic_tx, int grid_q, int grid_r) {
     constexpr int P = 4;
     constexpr int PS = NC8 | 1;
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -1237,20 +1257,26 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
         for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
     RawChunk<LM> raw[MAX_ITEMS];
     unsigned valid = 0;
-    auto issue = [&](int tile) {
-        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
+    constexpr unsigned CSB = NC8 * 16;          // bytes per pixel of the (fp16) input tensor
+    auto issue = [&](const PTile &tc) {         // addresses: see PTile / PSrc above conv_pipe_kernel
+        const PSrc<LM> src = psrc_of<LM, CSB>(a.x, tc, halo, HT, WT, H, W);
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
-            const int y = tc.ty0 + it_py[k] - halo, x = tc.tx0 + it_px[k] - halo;
-            const bool ok = it_lds[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
-            raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, it_c8[k], raw[k]);
-            valid |= (ok ? 1u : 0u) << k;
+            const bool in_img = psrc_load<LM, CSB>(src, it_py[k], it_px[k], it_c8[k], W, raw[k]);
+            valid |= ((it_lds[k] >= 0 && in_img) ? 1u : 0u) << k;
         }
     };
+    // this lane's output pixels (tile row wave * 4 + p, column n) as byte offsets from the tile origin (channel 0): constant
+    // over full tiles
+    const unsigned cso_b = (unsigned)a.cs_out * 2u;
+    unsigned o1c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) o1c[p] = (unsigned)((wave * 4 + p) * W + n) * cso_b;
 
-    int tile = blockIdx.x;
-    issue(tile < n_tiles ? tile : n_tiles - 1);
+    int tile = blockIdx.x;                // < n_tiles: the grid never exceeds the tile count
+    PTile tc = ptile_at(tile / per_img, tile % per_img, tiles_x, magic_tx);
+    issue(tc);
     stage_affine_table(a.x, s_aff);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in
     __syncthreads();                      // affine table and weights visible
@@ -1263,32 +1289,38 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                 *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
             }
         }
-        const TileCoord tc = tile_coord_fast(tile, tiles_x, per_img, inv_tx, inv_pi);
-        const int x = tc.tx0 + n;
         __syncthreads();
-        size_t pix[P];
+        const char *b_o1 = pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, cso_b);
+        const char *b_mk = EPI == EP_MASK ? pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
+        const char *b_zq = DYSTAT ? pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
+        unsigned o1[P];
         bool inb[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int y = tc.ty0 + wave * 4 + p;
-            inb[p] = FULL || (y < H && x < W);
-            pix[p] = (size_t)(tc.b * H + (FULL ? y : min(y, H - 1))) * W + (FULL ? x : min(x, W - 1));
+            if constexpr (FULL) {
+                o1[p] = o1c[p]; inb[p] = true;
+            } else {        // partial tiles clamp the coordinates used for LOADS (stores are guarded)
+                const int my = H - 1 - tc.ty0, mx = W - 1 - tc.tx0, r = wave * 4 + p;
+                inb[p] = r <= my && n <= mx;
+                o1[p] = __umul24(__umul24(min(r, my), W) + min(n, mx), cso_b);
+            }
         }
         f16x4 mk[MT][P], zq[MT][P];
         if (EPI == EP_MASK) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int p = 0; p < P; ++p) mk[m][p] = *reinterpret_cast<const f16x4 *>(a.mask + pix[p] * a.cs_out + (lane_out[m] ? 16 * m + 4 * g : 0));
+                for (int p = 0; p < P; ++p) mk[m][p] = *reinterpret_cast<const f16x4 *>(b_mk + o1[p] + (lane_out[m] ? 32 * m + 8 * g : 0));
         }
         if (DYSTAT) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int p = 0; p < P; ++p) zq[m][p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + pix[p] * a.cs_out + (lane_out[m] ? 16 * m + 4 * g : 0));
+                for (int p = 0; p < P; ++p) zq[m][p] = *reinterpret_cast<const f16x4 *>(b_zq + o1[p] + (lane_out[m] ? 32 * m + 8 * g : 0));
         }
         const int next = tile + gridDim.x;
-        issue(next < n_tiles ? next : tile);      // in flight during the MFMAs, the epilogue and its stores
+        const PTile tn = next < n_tiles ? ptile_next(tc, grid_q, grid_r, per_img, tiles_x, magic_tx) : tc;
+        issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         f32x4 acc[MT][P];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1324,7 +1356,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                     for (int r = 0; r < 4; ++r) v[r] = (f16)acc[m][p][r];
                 }
                 if ((FULL || inb[p]) && lane_out[m]) {
-                    *reinterpret_cast<f16x4 *>(a.out + pix[p] * a.cs_out + 16 * m + 4 * g) = v;
+                    *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p] + 32 * m + 8 * g) = v;
                     if (DYSTAT) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m][r] += f; s2[m][r] += f * (float)zq[m][p][r]; }
@@ -1336,6 +1368,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
             }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
+        tc = tn;
     }
     if (want_stats) {      // one partial row per workgroup
 #pragma unroll
@@ -1899,6 +1932,11 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
     return IMK_OK;
 }
 
+// Limits of conv_pipe_kernel's address arithmetic (24-bit multiplies of tile-relative pixel offsets, 32-bit magic division of
+// a tile's index inside its image): images below 2^24 pixels, rows below 2^16.  Plans are refused above that
+// (imk_conv_max_pixels), so the layouts decided at plan time (pair layout, chains) never meet an image that does not fit.
+static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
+
 // n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled
 // by the kernels
 static inline unsigned div_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
@@ -2009,7 +2047,7 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, 1.0f / tiles_x, 1.0f / (tiles_x * tiles_y));
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -2043,7 +2081,7 @@ static int launch_conv_wide_v(const ImkConvArgs &a, hipStream_t stream) {
 // 17-32 channels on at least one side, at most 32 on both: the wide persistent kernel (see conv_wide_kernel)
 static bool conv_wide_ok(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_CONV_WIDE"); return e && e[0] == '0'; }();
-    if (off || a.wpk2 || a.x.cs_in > 32 || a.cout > 32) return false;
+    if (off || a.wpk2 || a.x.cs_in > 32 || a.cout > 32 || !pipe_fits(a)) return false;
     if (a.x.lmode == LM_POOL || a.x.lmode == LM_STEM) return false;
     if (a.x.lmode == LM_U8 && a.x.cin > 4) return false;
     return true;
@@ -2065,11 +2103,6 @@ static int launch_conv_wide_any(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_WIDE_MT
 #undef IMK_WIDE_SEL
 }
-
-// Limits of conv_pipe_kernel's address arithmetic (24-bit multiplies of tile-relative pixel offsets, 32-bit magic division of
-// a tile's index inside its image): images below 2^24 pixels, rows below 2^16.  Plans are refused above that
-// (imk_conv_max_pixels), so the layouts decided at plan time (pair layout, chains) never meet an image that does not fit.
-static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
 
 static bool pipe_enabled() {
     static const bool on = []() { const char *e = getenv("IMK_CONV_PIPE"); return !(e && e[0] == '0'); }();
