@@ -262,12 +262,115 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
 }
 
 // =====================================================================================================
+// Addresses of the conv kernels = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset).
+// Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of a tile loop cost a 64 x 32-bit multiply
+// in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
+// and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of kernels
+// whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Instead: (image, tile in image) advance by
+// the grid size without a division, the tile row comes from one s_mul_hi_u32 by a host-computed magic number, the tile's
+// base address of each tensor is scalar arithmetic, and a lane adds an offset relative to the tile origin -- a constant for
+// the stores and epilogue loads of full tiles, one clamp per coordinate and one 24-bit multiply-add (full rate) for a
+// staged halo pixel.  Limits: imk_conv_max_pixels() per image, rows < 2^16 (plans are refused above).
+// =====================================================================================================
+struct PTile { int b, r, ty0, tx0; };            // r: the tile's index inside image b; all four live in scalar registers
+__device__ __forceinline__ PTile ptile_at(int b, int r, int tiles_x, unsigned magic_tx) {
+    PTile c;
+    c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
+    const unsigned ru = (unsigned)c.r;
+    const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);   // r * tiles_x < 2^32
+    c.ty0 = (int)ty * 16;
+    c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
+    return c;
+}
+__device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid_r, int per_img, int tiles_x, unsigned magic_tx) {
+    int b = c.b + grid_q, r = c.r + grid_r;      // the grid size = grid_q images + grid_r tiles (host-computed)
+    if (r >= per_img) { r -= per_img; ++b; }
+    return ptile_at(b, r, tiles_x, magic_tx);
+}
+// base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)
+__device__ __forceinline__ const char *pix_base(const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {
+    return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
+}
+
+// The staged input of one tile: scalar bases of the source tensor(s) at the halo tile's origin (-1 at the image border) and
+// the window of its rows / columns that lie inside the image.
+template <int LM>
+struct PSrc {
+    const char *b_in, *b_in2;
+    unsigned row2_b, w2, csb;
+    int oy, ox, oyl, oxl, pix0, nb, hw, lo_y, hi_y, lo_x, hi_x;
+};
+// CSB: bytes per pixel of the fp16 input tensor when the kernel knows them at compile time, 0 = in.cs_in * 2 at run time
+template <int LM, unsigned CSB>
+__device__ __forceinline__ PSrc<LM> psrc_of(const ImkInput &in, const PTile &tc, int halo, int HT, int WT, int H, int W) {
+    PSrc<LM> s{};
+    const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
+    const unsigned csb = CSB ? CSB : (unsigned)in.cs_in * 2u;
+    s.csb = csb;
+    s.oy = oy; s.ox = ox;
+    s.lo_y = oy < 0 ? -oy : 0; s.hi_y = min(HT - 1, H - 1 - oy);
+    s.lo_x = ox < 0 ? -ox : 0; s.hi_x = min(WT - 1, W - 1 - ox);
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+        s.b_in = pix_base(in.in, tc.b, H, W, oy, ox, csb);
+        if constexpr (LM == LM_BNBWD) s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, csb);
+    } else if constexpr (LM == LM_POOL) {
+        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
+        s.b_in = pix_base(in.in, tc.b, H2, W2, 2 * oy, 2 * ox, csb);
+        s.w2 = (unsigned)W2;
+        s.row2_b = s.w2 * csb;
+    } else if constexpr (LM == LM_UPADD) {
+        s.oyl = oy >> 1; s.oxl = ox >> 1;
+        s.b_in = pix_base(in.in, tc.b, H / 2, W / 2, s.oyl, s.oxl, csb);
+        s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, csb);
+    } else {                                        // uint8 pixels: nb bytes each
+        s.nb = LM == LM_STEM ? in.u8_c : in.cin;
+        s.hw = H * W;
+        s.pix0 = oy * W + ox;                       // may be negative; pix0 + (a clamped pixel's offset) never is
+        s.b_in = reinterpret_cast<const char *>(in.in) + (long long)tc.b * s.hw * s.nb;
+    }
+    return s;
+}
+// Chunk c8 of the halo tile's pixel (py, px), clamped into the image (unconditional load); returns whether it was inside.
+template <int LM, unsigned CSB>
+__device__ __forceinline__ bool psrc_load(const PSrc<LM> &s, int py, int px, int c8, int W, RawChunk<LM> &r) {
+    const int ry = min(max(py, s.lo_y), s.hi_y), rx = min(max(px, s.lo_x), s.hi_x);
+    auto bytes = [&](unsigned pixels) { return CSB ? pixels * CSB : __umul24(pixels, s.csb); };   // tile-relative: < 2^24
+    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
+        const unsigned o = bytes(__umul24(ry, W) + rx) + c8 * 16;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
+        if constexpr (LM == LM_BNBWD) r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + o);
+    } else if constexpr (LM == LM_POOL) {
+        const unsigned o = bytes(__umul24(2 * ry, s.w2) + 2 * rx) + c8 * 16;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
+        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.csb);
+        r.v[2] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b);
+        r.v[3] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b + s.csb);
+    } else if constexpr (LM == LM_UPADD) {
+        const int yl = ((s.oy + ry) >> 1) - s.oyl, xl = ((s.ox + rx) >> 1) - s.oxl;
+        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + bytes(__umul24(yl, W / 2) + xl) + c8 * 16);
+        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + bytes(__umul24(ry, W) + rx) + c8 * 16);
+    } else {
+        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
+        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
+        // bytes early, so nothing past the image is read (H * W * nb >= 4).
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        const int pidx = s.pix0 + (int)(__umul24(ry, W) + rx);           // pixel index inside its image
+        const int rem = __mul24(s.hw - pidx, s.nb);                       // bytes from this pixel to the end of the image
+        const int back = rem >= 4 ? 0 : 4 - rem;
+        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(s.b_in + (unsigned)(__mul24(pidx, s.nb) - back)) >> (8 * back);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[j] = (j < s.nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
+    }
+    return ry == py && rx == px;
+}
+
+// =====================================================================================================
 // forward / dgrad
 // =====================================================================================================
 // Channel passes: the K dimension is walked in n_pass passes of nc8p chunks (imk_pass_chunks above), each pass staging
 // its channel slice of the tile and of the packed weights; any width up to 512 channels runs this way.
 // k order = (pass, tap, chunk in pass) -- see pack_conv_batched_kernel.
-struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp; };
+struct ImkConvGeom { int tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp; unsigned magic_tx, magic_pi; };   // magic_pi 0: plain division
 // LDS offset of a chained launch's second weight set: behind the first stage's regions and the output tile that reuses them
 __host__ __device__ inline size_t imk_chain_w2_offset(size_t stage1_bytes, size_t out_bytes) {
     return ((stage1_bytes > out_bytes ? stage1_bytes : out_bytes) + 15) & ~(size_t)15;
@@ -294,8 +397,12 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     f16 *s_w2 = reinterpret_cast<f16 *>(smem + imk_chain_w2_offset((size_t)HT * WT * ps * 16 + 4 * (size_t)a.x.cs_in * sizeof(float) +
                                                                    (size_t)MT * nsp * 1024, (size_t)TH * 16 * (MT * 16 + 8) * sizeof(f16)));
     const int t = threadIdx.x;
-    const TileCoord tc = tile_coord(bx, tiles_x, tiles_y, TH);
     const int H = a.H, W = a.W;
+    // addresses: scalar base of the tile + 32-bit lane offsets (PTile / PSrc above); TH = 16 rows per tile
+    const int per_img = tiles_x * tiles_y;
+    const int tb = gm.magic_pi ? (int)(((unsigned long long)(unsigned)bx * gm.magic_pi) >> 32) : bx / per_img;
+    const PTile tc = ptile_at(tb, bx - tb * per_img, tiles_x, gm.magic_tx);
+    const PSrc<LM> src = psrc_of<LM, 0>(a.x, tc, halo, HT, WT, H, W);
     const int ns_total = n_pass * nsp;
 
     IMK_STAMP_BEGIN(conv, 10000 + LM * 1000 + MT * 100 + n_pass * 10 + ks3);
@@ -373,11 +480,9 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
                     const int pix = (ii * mg_c) >> 16;            // ii / nc8_cur, exact for these ranges (see mg_c)
                     const int c8 = ii - pix * nc8_cur;
                     const int py = (pix * mg_w) >> 16, px = pix - py * WT;   // pix / WT
-                    const int y = tc.ty0 + py - halo, x = tc.tx0 + px - halo;
                     dst[u] = i < n_items ? (pix * ps + c8) * 16 : -1;
                     c8s[u] = c8_lo + c8;
-                    if (y >= 0 && y < H && x >= 0 && x < W) ok |= 1u << u;
-                    raw_load<LM>(a.x, tc.b, min(max(y, 0), H - 1), min(max(x, 0), W - 1), H, W, c8s[u], r[u]);
+                    if (psrc_load<LM, 0>(src, py, px, c8s[u], W, r[u])) ok |= 1u << u;
                 }
                 if (aff_pending) { __syncthreads(); aff_pending = false; }   // affine table (uniform branch)
 #pragma unroll
@@ -456,6 +561,7 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     // and leaves as 16-byte chunks, MT * 32 contiguous bytes per pixel.  The ReLU masks and BN outputs that the gradient
     // epilogues read are all requested up front (one latency, not one per (m, p)).
     const int x = tc.tx0 + n;
+    const int my = H - 1 - tc.ty0, mx = W - 1 - tc.tx0;            // last row / column of the image, relative to the tile
     float s1[MT][4], s2[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -487,11 +593,10 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
             if (EPI == EP_MASK || STAT == 2) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    const int y = tc.ty0 + wave * P + p;
-                    const bool live = co0 < cs_o && y < H && x < W;
-                    const size_t o = live ? ((size_t)(tc.b * H + y) * W + x) * cs_o + co0 : 0;   // dead lanes: any valid address
-                    if (EPI == EP_MASK) mk[p] = *reinterpret_cast<const f16x4 *>(a.mask + o);
-                    if (STAT == 2) zz[p] = *reinterpret_cast<const f16x4 *>(a.dystat_z + o);
+                    // dead lanes (pixels outside the image, padding channels) read a clamped, valid address
+                    const unsigned o = __umul24(__umul24(min(wave * P + p, my), W) + min(n, mx), (unsigned)cs_o * 2u) + (co0 < cs_o ? co0 * 2 : 0);
+                    if (EPI == EP_MASK) mk[p] = *reinterpret_cast<const f16x4 *>(pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)cs_o * 2u) + o);
+                    if (STAT == 2) zz[p] = *reinterpret_cast<const f16x4 *>(pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)cs_o * 2u) + o);
                 }
             }
 #pragma unroll
@@ -521,12 +626,12 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
     auto copy_out = [&](f16 *out, int cs_o) {
         const int cpp = MT * 2;                                // chunks per pixel
         const int n_live = min(cpp, (cs_o - ct0 * 16) / 8);    // cs_o is a multiple of 8
+        char *ob = const_cast<char *>(pix_base(out, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)cs_o * 2u)) + ct0 * 32;
         for (int i = t; i < TH * 16 * cpp; i += NT) {
-            const int pixl = i / cpp, ch = i - pixl * cpp;
+            const int pixl = i / cpp, ch = i - pixl * cpp;       // cpp = MT * 2: a power of two
             const int py = pixl >> 4, px = pixl & 15;
-            const int y = tc.ty0 + py, xx = tc.tx0 + px;
-            if (ch < n_live && y < H && xx < W)
-                *reinterpret_cast<f16x8 *>(out + ((size_t)(tc.b * H + y) * W + xx) * cs_o + ct0 * 16 + ch * 8) =
+            if (ch < n_live && py <= my && px <= mx)
+                *reinterpret_cast<f16x8 *>(ob + __umul24(__umul24(py, W) + px, (unsigned)cs_o * 2u) + ch * 16) =
                     *reinterpret_cast<const f16x8 *>(s_out + pixl * OPITCH + ch * 8);
         }
     };
@@ -619,105 +724,6 @@ __device__ __forceinline__ void conv_mfma_body(const ImkConvArgs &a, const ImkCo
 template <int TH, int MT, int LM, bool CHAIN = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGeom gm) {
     conv_mfma_body<TH, MT, LM, CHAIN>(a, gm, blockIdx.x, blockIdx.y);
-}
-
-// =====================================================================================================
-// Addresses of the persistent kernels = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset).
-// Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of a tile loop cost a 64 x 32-bit multiply
-// in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
-// and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of kernels
-// whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Instead: (image, tile in image) advance by
-// the grid size without a division, the tile row comes from one s_mul_hi_u32 by a host-computed magic number, the tile's
-// base address of each tensor is scalar arithmetic, and a lane adds an offset relative to the tile origin -- a constant for
-// the stores and epilogue loads of full tiles, one clamp per coordinate and one 24-bit multiply-add (full rate) for a
-// staged halo pixel.  Limits: imk_conv_max_pixels() per image, rows < 2^16 (plans are refused above).
-// =====================================================================================================
-struct PTile { int b, r, ty0, tx0; };            // r: the tile's index inside image b; all four live in scalar registers
-__device__ __forceinline__ PTile ptile_at(int b, int r, int tiles_x, unsigned magic_tx) {
-    PTile c;
-    c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
-    const unsigned ru = (unsigned)c.r;
-    const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);   // r * tiles_x < 2^32
-    c.ty0 = (int)ty * 16;
-    c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
-    return c;
-}
-__device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid_r, int per_img, int tiles_x, unsigned magic_tx) {
-    int b = c.b + grid_q, r = c.r + grid_r;      // the grid size = grid_q images + grid_r tiles (host-computed)
-    if (r >= per_img) { r -= per_img; ++b; }
-    return ptile_at(b, r, tiles_x, magic_tx);
-}
-// base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)
-__device__ __forceinline__ const char *pix_base(const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {
-    return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
-}
-
-// The staged input of one tile: scalar bases of the source tensor(s) at the halo tile's origin (-1 at the image border) and
-// the window of its rows / columns that lie inside the image.
-template <int LM>
-struct PSrc {
-    const char *b_in, *b_in2;
-    unsigned row2_b, w2;
-    int oy, ox, oyl, oxl, pix0, nb, hw, lo_y, hi_y, lo_x, hi_x;
-};
-template <int LM, unsigned CSB>                    // CSB: bytes per pixel of the fp16 input tensor
-__device__ __forceinline__ PSrc<LM> psrc_of(const ImkInput &in, const PTile &tc, int halo, int HT, int WT, int H, int W) {
-    PSrc<LM> s{};
-    const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
-    s.oy = oy; s.ox = ox;
-    s.lo_y = oy < 0 ? -oy : 0; s.hi_y = min(HT - 1, H - 1 - oy);
-    s.lo_x = ox < 0 ? -ox : 0; s.hi_x = min(WT - 1, W - 1 - ox);
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-        s.b_in = pix_base(in.in, tc.b, H, W, oy, ox, CSB);
-        if constexpr (LM == LM_BNBWD) s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, CSB);
-    } else if constexpr (LM == LM_POOL) {
-        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
-        s.b_in = pix_base(in.in, tc.b, H2, W2, 2 * oy, 2 * ox, CSB);
-        s.w2 = (unsigned)W2;
-        s.row2_b = s.w2 * CSB;
-    } else if constexpr (LM == LM_UPADD) {
-        s.oyl = oy >> 1; s.oxl = ox >> 1;
-        s.b_in = pix_base(in.in, tc.b, H / 2, W / 2, s.oyl, s.oxl, CSB);
-        s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, CSB);
-    } else {                                        // uint8 pixels: nb bytes each
-        s.nb = LM == LM_STEM ? in.u8_c : in.cin;
-        s.hw = H * W;
-        s.pix0 = oy * W + ox;                       // may be negative; pix0 + (a clamped pixel's offset) never is
-        s.b_in = reinterpret_cast<const char *>(in.in) + (long long)tc.b * s.hw * s.nb;
-    }
-    return s;
-}
-// Chunk c8 of the halo tile's pixel (py, px), clamped into the image (unconditional load); returns whether it was inside.
-template <int LM, unsigned CSB>
-__device__ __forceinline__ bool psrc_load(const PSrc<LM> &s, int py, int px, int c8, int W, RawChunk<LM> &r) {
-    const int ry = min(max(py, s.lo_y), s.hi_y), rx = min(max(px, s.lo_x), s.hi_x);
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-        const unsigned o = (__umul24(ry, W) + rx) * CSB + c8 * 16;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
-        if constexpr (LM == LM_BNBWD) r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + o);
-    } else if constexpr (LM == LM_POOL) {
-        const unsigned o = (__umul24(2 * ry, s.w2) + 2 * rx) * CSB + c8 * 16;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
-        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in + o + CSB);
-        r.v[2] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b);
-        r.v[3] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b + CSB);
-    } else if constexpr (LM == LM_UPADD) {
-        const int yl = ((s.oy + ry) >> 1) - s.oyl, xl = ((s.ox + rx) >> 1) - s.oxl;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + (__umul24(yl, W / 2) + xl) * CSB + c8 * 16);
-        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + (__umul24(ry, W) + rx) * CSB + c8 * 16);
-    } else {
-        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
-        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
-        // bytes early, so nothing past the image is read (H * W * nb >= 4).
-        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-        const int pidx = s.pix0 + (int)(__umul24(ry, W) + rx);           // pixel index inside its image
-        const int rem = __mul24(s.hw - pidx, s.nb);                       // bytes from this pixel to the end of the image
-        const int back = rem >= 4 ? 0 : 4 - rem;
-        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(s.b_in + (unsigned)(__mul24(pidx, s.nb) - back)) >> (8 * back);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < s.nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
-    }
-    return ry == py && rx == px;
 }
 
 // =====================================================================================================
@@ -1841,6 +1847,10 @@ extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
 }
 
 // Launch geometry of the per-tile kernel for one conv.
+// n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled
+// by the kernels
+static inline unsigned div_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+
 struct ConvLaunch { ImkConvGeom gm; int th, mt; int gx, gy; size_t lds; };
 
 static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
@@ -1879,7 +1889,10 @@ static int plan_conv_mfma(const ImkConvArgs &a, ConvLaunch &L) {
     }
     if (lds < out_bytes) lds = out_bytes;
     if (lds > 160 * 1024) return IMK_EUNSUPPORTED;
-    L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp};
+    if (!((long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16))) return IMK_EUNSUPPORTED;   // tile-address arithmetic (PTile / PSrc)
+    const long long per_img = (long long)tiles_x * tiles_y;
+    L.gm = ImkConvGeom{tiles_x, tiles_y, mt_total, nc8, nc8p, n_pass, ps, nsp, div_magic(tiles_x),
+                       (per_img > 1 && (long long)n_sp * per_img < (1ll << 32)) ? div_magic((int)per_img) : 0u};
     L.th = TH; L.mt = mt; L.gx = n_sp; L.gy = imk_cdiv(mt_total, mt); L.lds = lds;
     return IMK_OK;
 }
@@ -1937,9 +1950,6 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 // (imk_conv_max_pixels), so the layouts decided at plan time (pair layout, chains) never meet an image that does not fit.
 static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
 
-// n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled
-// by the kernels
-static inline unsigned div_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
 
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
