@@ -7,7 +7,11 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libimk.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-fvisibility=hidden"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs.  gfx950 has one unified register file; with the default
+# heuristic the conv kernels kept their accumulators in AGPRs and paid a v_accvgpr_read/write per accumulator register
+# and tile (38 k of them in imk_conv.hip, 13 % of the VALU instructions of the shallow kernel's loop).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-fvisibility=hidden",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(target, deps):
