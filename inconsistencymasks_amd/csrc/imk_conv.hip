@@ -760,23 +760,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // WG = 2: the same for a 1x1 conv that READS a BatchNorm output (the U-Net's output layer; LM_RAW, EP_PLAIN, DYSTAT):
 // x = fp16(z * sc + sh) with z the tensor the BN-gradient statistics need anyway -- staged raw (the epilogue's z comes from
 // LDS, too), the affine applied to the transposed reads with the lane's channel constants.
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
+// LDS of conv_pipe_kernel without the PRE stage's extra tile: tile, affine table, statistics, u8 rows, fused-wgrad x tile
+// (+ slack: its transposed reads reach 16 bytes past a pixel); at least the fused 3x3 weight gradient's final reduction
+constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
+    size_t b = (size_t)18 * 18 * (nc8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +
+               (wg ? (size_t)(wg == 3 ? 18 * 18 : 256) * ((pair ? 1 : 2) | 1) * 16 + 64 : 0);
+    if (wg == 3 && b < 4 * 5 * 256 * sizeof(float)) b = 4 * 5 * 256 * sizeof(float);
+    return (b + 15) & ~(size_t)15;
+}
+
+// PRE (inference): the conv's input is itself a Conv1x1 + ReLU + BatchNorm of the tensor `a.x` describes (the input block in
+// front of the first encoder conv, unet.py:4-9; the decoder's Conv1x1 on upsample + skip, unet.py:32-35) and is computed here,
+// per tile incl. halo, on the matrix cores: `a.x` (uint8 image or up+add, PRE = its chunks per pixel) is staged into a second
+// LDS tile, one MFMA per 32 (pair layout) / 16 pixels with the 1x1's REGULAR packed weights gives its channels, the lanes add
+// bias, ReLU, round to fp16, apply the BatchNorm, zero what lies outside the image and write the 3x3's input tile.  The
+// intermediate tensor is neither written nor read, and every value is bit-identical to the two-launch path (same MFMA, same
+// operand layout per pixel).
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, int grid_q, int grid_r) {
+    static_assert(PRE == 0 || (WG == 0 && EPI == EP_RELU && !DYSTAT && (LM == LM_U8 || LM == LM_UPADD)), "pre-stage: inference forward only");
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
     static_assert(WG != 3 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 3x3 dgrad in front of a BatchNorm");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
-    constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
+    constexpr int NCI = PRE ? PRE : NC8;        // chunks per pixel of the STAGED tensor (PRE: the 1x1's input)
+    constexpr int PSI = NCI | 1;
+    constexpr int MAX_ITEMS = (18 * 18 * NCI + 255) / 256;
     constexpr int MAX_NS = PAIR ? (9 * NC8 + 1) / 2 : (9 * NC8 + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
     const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
-    const int n_items = HT * WT * NC8;
+    const int n_items = HT * WT * NCI;
     const int nq = (ks3 ? 9 : 1) * NC8, ns = PAIR ? (nq + 1) / 2 : (nq + 3) / 4;
     uint8_t *s_tile = smem;
+    uint8_t *s_t0 = smem + pipe_lds_base(NC8, PAIR, WG);                          // PRE: the staged input of the 1x1, [pixel][PSI]
+    float *s_pre = reinterpret_cast<float *>(s_t0 + 18 * 18 * PSI * 16);          // PRE: [bias | scale | shift][16]
+    uint8_t *s_stage = PRE ? s_t0 : s_tile;
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);
     float *s_red = s_aff + 8 * 16;              // [4 waves][2][16] (the affine table has up to 7 rows of 16: LM_STEM)
     const int t = threadIdx.x;
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int cs_in = a.x.cs_in;
     const int per_img = tiles_x * tiles_y;
     auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
-    constexpr unsigned CSB = NC8 * 16;          // bytes per pixel of the (fp16) input tensor: cs_in = NC8 * 8
+    constexpr unsigned CSB = NCI * 16;          // bytes per pixel of the (fp16) input tensor: cs_in = NCI * 8
 
     // packed weights and per-lane LDS offsets of every k-step: once per workgroup
     f16x8 af[MAX_NS];
@@ -812,11 +834,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     for (int k = 0; k < MAX_ITEMS; ++k) {
         const int i = t + 256 * k;
         const bool live = i < n_items;
-        const int pix = (live ? i : t % n_items) / NC8;
-        it_c8[k] = (live ? i : t % n_items) - pix * NC8;
+        const int pix = (live ? i : t % n_items) / NCI;
+        it_c8[k] = (live ? i : t % n_items) - pix * NCI;
         it_py[k] = pix / WT;
         it_px[k] = pix - it_py[k] * WT;
-        it_lds[k] = live ? (pix * PS + it_c8[k]) * 16 : -1;
+        it_lds[k] = live ? (pix * PSI + it_c8[k]) * 16 : -1;
     }
     float bias[4] = {0, 0, 0, 0}, bias2[4] = {0, 0, 0, 0};
     const int co0 = PAIR ? 4 * (g & 1) : 4 * g;
@@ -830,6 +852,30 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         for (int r = 0; r < 4; ++r) bias2[r] = (co0 + r < a.cout2) ? a.bias2[co0 + r] : 0.f;
     }
     const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);
+    // PRE: the 1x1's weight fragment (one k-step: its input has at most 16 channels), its constants in LDS, and the pixels
+    // this lane's accumulator rows belong to in each of the wave's NJ MFMAs (pair layout: 2 x 16 pixels per MFMA)
+    constexpr int NJ = PAIR ? 3 : 6;            // 4 waves x NJ x (32 | 16) = 384 >= 18 x 18 pixels
+    f16x8 af_pre = {0, 0, 0, 0, 0, 0, 0, 0};
+    int pre_pix[PRE ? NJ : 1], pre_yx[PRE ? NJ : 1];
+    const int pre_c8 = PAIR ? (g & 1) : g;      // the chunk of the staged pixel this lane group feeds (zero weights beyond NCI)
+    const int pre_cb = PAIR ? 4 * (g & 1) : 4 * g;   // this lane's 4 output channels
+    if constexpr (PRE) {
+        af_pre = *reinterpret_cast<const f16x8 *>(a.pre_wpk + (size_t)lane * 8);
+        if (t < 16) {
+            s_pre[t] = t < a.pre_cout ? a.pre_bias[t] : 0.f;
+            s_pre[16 + t] = t < NC8 * 8 ? a.pre_sc[t] : 0.f;
+            s_pre[32 + t] = t < NC8 * 8 ? a.pre_sh[t] : 0.f;
+        }
+        const int n_pix = HT * WT;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int grp = wave * NJ + j;
+            const int px = min(PAIR ? (grp * 2 + (g >> 1)) * 16 + n : grp * 16 + n, n_pix - 1);   // past the end: the last pixel again
+            const int py = px / WT;
+            pre_pix[j] = px;
+            pre_yx[j] = (py << 8) | (px - py * WT);
+        }
+    }
     // FULL also promises that every lane owns real channels (PAIR, or 16-channel outputs): no guard around any store
     const bool lane_out = FULL || co0 < (CHAIN ? a.cs_out2 : a.cs_out);   // this lane's 4 channels exist in the output tensor
     const bool lane_mid = FULL || co0 < a.cs_out;                          // ... in the chain's intermediate
@@ -840,7 +886,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     // uint8 image, full 16 x 16 tiles of a 1x1 conv (the stem): a tile row is 16 * cin contiguous bytes = cin aligned
     // 16-byte segments, so 16 * cin threads fetch the whole tile with one wide load each (instead of cin byte loads
     // per pixel and thread); the bytes go through LDS to the pixel that owns them.
-    constexpr bool U8ROWS = (LM == LM_U8) && FULL;
+    constexpr bool U8ROWS = (LM == LM_U8) && FULL && !PRE;
     uint8_t *s_u8 = reinterpret_cast<uint8_t *>(s_red + 4 * 2 * 16);   // [16 rows][cin * 16 bytes], cin <= 4
     // WG: x tile [256 px][XS chunks] behind it, and the two persistent accumulators of the weight / bias gradient
     constexpr int NCX = PAIR ? 1 : 2, XS = NCX | 1;     // x = the dgrad's OUTPUT channels: 8 (pair layout) or 16
@@ -942,7 +988,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 if (it_lds[k] >= 0) {
                     f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div);
                     if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    *reinterpret_cast<f16x8 *>(s_tile + it_lds[k]) = v;
+                    *reinterpret_cast<f16x8 *>(s_stage + it_lds[k]) = v;
                 }
             }
             if constexpr (WG == 1 || WG == 2) {
@@ -1000,6 +1046,29 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         const int next = tile + gridDim.x;
         const PTile tn = next < n_tiles ? ptile_next(tc, grid_q, grid_r, per_img, tiles_x, magic_tx) : tc;
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
+        if constexpr (PRE) {
+            // rows / columns of the halo tile that lie inside the image (the 3x3 pads its INPUT with zeros, not the 1x1's)
+            const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
+            const int lo_y = oy < 0 ? -oy : 0, hi_y = min(HT - 1, H - 1 - oy), lo_x = ox < 0 ? -ox : 0, hi_x = min(WT - 1, W - 1 - ox);
+            const f32x4 pb = *reinterpret_cast<const f32x4 *>(s_pre + pre_cb), psc = *reinterpret_cast<const f32x4 *>(s_pre + 16 + pre_cb),
+                        psh = *reinterpret_cast<const f32x4 *>(s_pre + 32 + pre_cb);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f16x8 bfp = *reinterpret_cast<const f16x8 *>(s_t0 + (pre_pix[j] * PSI + (pre_c8 < NCI ? pre_c8 : 0)) * 16);
+                const f32x4 pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_pre, bfp, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                const int py = pre_yx[j] >> 8, px = pre_yx[j] & 255;
+                const bool inside = py >= lo_y && py <= hi_y && px >= lo_x && px <= hi_x;
+                f16x4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f16 z = (f16)fmaxf(pa[r] + pb[r], 0.f);              // the 1x1's stored output
+                    w[r] = inside ? (f16)((float)z * psc[r] + psh[r]) : (f16)0.f;
+                }
+                if (pre_cb < NC8 * 8)
+                    *reinterpret_cast<f16x4 *>(s_tile + (pre_pix[j] * PS + (pre_cb >> 3)) * 16 + (pre_cb & 7) * 2) = w;
+            }
+            __syncthreads();      // the 3x3's input tile is complete
+        }
         if constexpr (WG == 3) {
             // as below, with the 9 taps: dW[tap][ci][co] += x[pixel + tap][ci] * dA[pixel][co]; both tiles carry a halo here
             const int qq = n >> 2, pp = n & 3;
@@ -1951,13 +2020,11 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
 
 
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0>
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +   // tile, affine table, statistics, u8 rows
-                 (WG ? (size_t)(WG == 3 ? 18 * 18 : 256) * ((PAIR ? 1 : 2) | 1) * 16 + 64 : 0);              // fused wgrad: the x tile (+ slack: its transposed reads reach 16 bytes past a pixel)
-    if (WG == 3 && lds < 4 * 5 * 256 * sizeof(float)) lds = 4 * 5 * 256 * sizeof(float);                    // ... and its final reduction
-    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG>;
+    const size_t lds = pipe_lds_base(NC8, PAIR, WG) + (PRE ? (size_t)18 * 18 * (PRE | 1) * 16 + 3 * 16 * sizeof(float) : 0);
+    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE>;
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 4;
@@ -1979,6 +2046,14 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
 // without the BN-gradient statistics): input is a raw gradient or a BN backward on load; never chained.
 template <int NC8, bool PAIR, bool FULL>
 static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
+    if (a.pre_wpk) {        // 1x1 first stage + 3x3 + chained 1x1 (inference); instantiated for the pair layout (imk_conv_can_prestage)
+        if constexpr (PAIR && NC8 == 1) {
+            if (a.epi != EP_RELU || !a.wpk2 || a.out || a.x.lmode != LM_UPADD || a.x.cs_in != 8) return IMK_EUNSUPPORTED;
+            return launch_conv_pipe_k<LM_UPADD, 1, 2, true, EP_RELU, false, FULL, 0, 1>(a, stream);
+        } else {
+            return IMK_EUNSUPPORTED;
+        }
+    }
     if (a.epi == EP_RELU) {
         const int chain = a.wpk2 ? (a.out ? 1 : 2) : 0;
 #define IMK_PIPE_FWD(LM)                                                                              \
@@ -2031,9 +2106,9 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
 
 static int launch_conv_pipe_any(const ImkConvArgs &a, hipStream_t stream) {
     const bool all_ch = a.pair || (a.cs_out == 16 && (!a.wpk2 || a.cs_out2 == 16));
-    const bool u8_ok = a.x.lmode != LM_U8 || (a.ksize == 1 && ((uintptr_t)a.x.in & 15) == 0);   // FULL + u8: row-segment loads
+    const bool u8_ok = a.x.lmode != LM_U8 || a.pre_wpk || (a.ksize == 1 && ((uintptr_t)a.x.in & 15) == 0);   // FULL + u8: row-segment loads
     const bool full = (a.H % 16 == 0) && (a.W % TW == 0) && all_ch && u8_ok;
-    const bool nc1 = a.x.cs_in == 8;
+    const bool nc1 = (a.pre_wpk ? imk_pad8(a.pre_cout) : a.x.cs_in) == 8;      // chunks per pixel of THIS conv's input
 #define IMK_PIPE_SEL(NC8)                                                                                   \
     (a.pair ? (full ? launch_conv_pipe_v<NC8, true, true>(a, stream) : launch_conv_pipe_v<NC8, true, false>(a, stream)) \
             : (full ? launch_conv_pipe_v<NC8, false, true>(a, stream) : launch_conv_pipe_v<NC8, false, false>(a, stream)))
@@ -2139,6 +2214,20 @@ bool imk_conv_can_chain(const ImkConvArgs &a, int cout2) {
     return a.epi == EP_RELU && a.x.cs_in <= 16 && a.cout <= 16 && cout2 <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
 }
 
+// conv_pipe_kernel<..., PRE>: `main` is a chained 3x3 launch of the shallow kernel without a stored intermediate (inference);
+// the 1x1 in front of it reads a uint8 image or upsample + skip with at most 16 channels and uses the same weight layout.
+bool imk_conv_can_prestage(const ImkConvArgs &a, int lm_pre, int cin_pre, int cout_pre) {
+    static const bool off = []() { const char *e = getenv("IMK_CONV_PRESTAGE"); return e && e[0] == '0'; }();
+    if (off || !pipe_enabled() || !pipe_fits(a)) return false;
+    if (a.epi != EP_RELU || a.ksize != 3 || !a.wpk2 || a.out) return false;
+    // Measured (inference call of 128 images, ms without / with): ISIC (8 channels, pair layout) 0.538 / 0.503 -- the decoder's
+    // full- and half-resolution blocks 117.9 -> 104.5 us and 61.0 -> 53.8 us; SUIM (16 channels, plain layout: 170 VGPRs, two
+    // waves per SIMD) 1.260 / 1.269; the input block this way 0.507 against 0.503 for the LM_STEM form.  So: up + add in front
+    // of pair-layout convs only (both stages <= 8 channels).
+    if (lm_pre != LM_UPADD || imk_pad8(cin_pre) != 8 || cout_pre > 8 || a.cout > 8 || a.cout2 > 8) return false;
+    return imk_conv_pair_layout(cin_pre, cout_pre, false) && imk_conv_pair_layout(cout_pre, a.cout, false);
+}
+
 // The per-tile kernel's chain (conv_mfma_kernel<..., CHAIN>): a 3x3 conv with 17-64 output channels that pools or reads a
 // BatchNorm output, followed by a 1x1 with at most as many 16-channel tiles -- the mid / deep blocks.  The second conv uses
 // its regular forward pack.  Bit-identical to the two per-tile launches.  Measured (ms per training step B = 32 | inference
@@ -2188,8 +2277,10 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     if (a.x.cs_in > 512) return IMK_EUNSUPPORTED;
     static const bool env_checked = []() { const char *e = getenv("IMK_CONV_PIPE"); if (e && e[0] == '0') g_use_pipe = false; return true; }();
     (void)env_checked;
-    const bool pipe_ok = g_use_pipe && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4);
+    const bool pipe_ok = g_use_pipe && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16 && (a.x.lmode != LM_U8 || a.x.cin <= 4) &&
+                         (!a.pre_wpk || imk_pad8(a.pre_cout) <= 16);
     a.pair = pipe_ok && pair_enabled() && a.cout <= 8;   // must mirror imk_conv_pair_layout
+    if (a.pre_wpk && !(pipe_ok && a.wpk2 && a.pre_bias && a.pre_sc && a.pre_sh && a.pre_cout > 0)) return IMK_EUNSUPPORTED;
     if (a.wpk2 && a.pair && a.cout2 > 8) return IMK_EUNSUPPORTED;
     if (a.wpk2) {   // fused second stage (callers check imk_conv_can_chain / imk_conv_can_chain_tile)
         if (a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;

@@ -61,6 +61,13 @@ struct ImkConvArgs {
     // dgrad IS the conv's input x): the same launch also produces the conv's weight / bias gradient partials
     // dW[ci][co] = sum_px x[px][ci] * dA[px][co] -- both operands are in LDS anyway -- one row [2][256] per workgroup
     // (stats_rows receives the row count); see imk_conv_can_fuse_wgrad.
+    // optional fused FIRST stage (inference, conv_pipe_kernel<..., PRE>): the conv's input is fp16(relu(Wp . x + pre_bias)) passed
+    // through a BatchNorm (pre_sc, pre_sh; zero padding outside the image), Wp a 1x1 conv with at most 16 input channels on the
+    // tensor `x` describes (uint8 image or upsample + skip).  pre_wpk = that conv's regular forward pack (same pair / plain
+    // layout as this conv's), pre_cout = its output channels = this conv's input channels.  See imk_conv_can_prestage.
+    const f16 *pre_wpk;
+    const float *pre_bias, *pre_sc, *pre_sh;
+    int pre_cout;
     float *wg_partial;
     // second form (the U-Net's output layer: 1x1 conv on a BatchNorm output, dgrad = LM_RAW / EP_PLAIN with the BN-gradient
     // statistics): x = fp16(dystat_z * wg_sc + wg_sh), the BatchNorm being applied to the transposed LDS reads
@@ -88,6 +95,8 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 // "chain" operand of a 1x1 conv applied to an accumulator tile (k-slot (g, j<4) <-> input channel 4g + j).
 inline long long imk_conv_max_pixels() { return 1ll << 24; }   // H * W of a plan (the shallow kernel's 24-bit offset arithmetic)
 bool imk_conv_can_chain(const ImkConvArgs &first, int cout2);
+// can the 1x1 conv (cin_pre -> cout_pre channels, input mode lm_pre) run as the first stage of this (chained) 3x3 launch?
+bool imk_conv_can_prestage(const ImkConvArgs &main, int lm_pre, int cin_pre, int cout_pre);
 // ... by the per-tile kernel (17-64 channels), which takes the 1x1's regular forward pack as ImkConvArgs::wpk2
 bool imk_conv_can_chain_tile(const ImkConvArgs &first, int cout2, bool store_intermediate);
 // inference: can the input block (u8_c image channels -> ch0) be computed on load by the conv that follows it (LM_STEM)?

@@ -234,6 +234,40 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
     return rc;
 }
 
+// Inference: Conv1x1+ReLU -> BN -> Conv3x3+ReLU -> Conv1x1+ReLU in ONE launch (conv_pipe_kernel<..., PRE>): `pre` is a decoder
+// block's Conv1x1 on upsample + skip (unet.py:32-35; the input block in front of the first encoder block has its own form,
+// LM_STEM).  Neither pre's output nor the 3x3's leaves the chip.  Returns IMK_EUNSUPPORTED (nothing launched) where that does not apply.
+inline int run_conv_pre_pair(Ctx &c, int pre, int c3, int c1) {
+    if (c.train || g_imk_materialize) return IMK_EUNSUPPORTED;
+    const ImkLayer &lp = c.p->layers[pre], &l = c.p->layers[c3], &l2 = c.p->layers[c1];
+    if (lp.ksize != 1 || lp.bn_after < 0 || l.src != pre || l.src_bn != lp.bn_after || l.lmode != LM_AFFINE || l2.pk_chain < 0)
+        return IMK_EUNSUPPORTED;
+    const Dim d = res_dim(c.p->cfg, l.res);
+    ImkConvArgs a{};
+    a.x = conv_input(c, pre);
+    a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize;
+    a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
+    a.wpk = c.wfwd(c3);
+    a.bias = c.params + l.off_b;
+    a.out = nullptr;
+    a.epi = EP_RELU;
+    a.wpk2 = reinterpret_cast<const f16 *>(c.packed + l2.pk_chain);
+    a.bias2 = c.params + l2.off_b;
+    a.out2 = c.act(c1);
+    a.cout2 = l2.cout; a.cs_out2 = imk_pad8(l2.cout);
+    {   // the chain itself must be possible with THIS conv's own input (what imk_conv_can_chain checks)
+        ImkConvArgs plain = a;
+        plain.x = conv_input(c, c3);
+        if (!imk_conv_can_chain(plain, l2.cout)) return IMK_EUNSUPPORTED;
+    }
+    if (!imk_conv_can_prestage(a, lp.lmode, lp.cin, lp.cout)) return IMK_EUNSUPPORTED;
+    a.pre_wpk = c.wfwd(pre);
+    a.pre_bias = c.params + lp.off_b;
+    a.pre_sc = c.bn_scale(lp.bn_after); a.pre_sh = c.bn_shift(lp.bn_after);
+    a.pre_cout = lp.cout;
+    return imk_launch_conv(a, c.stream);
+}
+
 // Conv3x3+ReLU -> Conv1x1+ReLU of a block: one kernel where the channel counts allow it, else two
 inline int run_conv_pair(Ctx &c, int c3, int c1, float *params_rw) {
     bool f = false;

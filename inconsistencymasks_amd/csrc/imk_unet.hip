@@ -140,7 +140,12 @@ int run_forward(Ctx &c, const Topo &t, float *probs, float *params_rw) {
     if (!stem_fused) { RUN(t.in_c); RUN_PAIR(t.e_c3[0], t.e_c1[0]); }
     for (int i = 1; i < 4; ++i) RUN_PAIR(t.e_c3[i], t.e_c1[i]);
     RUN_PAIR(t.b_c3, t.b_c1);
-    for (int j = 0; j < 4; ++j) { RUN(t.d_ca[j]); RUN_PAIR(t.d_c3[j], t.d_c1[j]); }
+    for (int j = 0; j < 4; ++j) {
+        rc = run_conv_pre_pair(c, t.d_ca[j], t.d_c3[j], t.d_c1[j]);      // inference, shallow levels: one launch per decoder block
+        if (rc == IMK_OK) continue;
+        if (rc != IMK_EUNSUPPORTED) return rc;
+        RUN(t.d_ca[j]); RUN_PAIR(t.d_c3[j], t.d_c1[j]);
+    }
 #undef RUN_PAIR
 #undef RUN
     if (!probs) return IMK_OK;   // training: the caller runs the fused head + loss kernel
