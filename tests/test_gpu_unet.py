@@ -529,3 +529,20 @@ def test_chained_per_tile_conv_is_bit_identical_to_two_launches(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         got.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
     assert got[0] == got[1]
+
+
+def test_decoder_first_stage_is_bit_identical_to_its_own_launch(tmp_path):
+    """conv_pipe_kernel<..., PRE> (inference: a shallow decoder block's Conv1x1 on upsample + skip computed on the matrix
+    cores inside the block's 3x3 launch) against the two launches: same probabilities, bit for bit (alpha = 0.5 widths, where
+    the pair layout applies; ragged and full-tile sizes)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "pre_child.py"
+    script.write_text(_CHAIN_CHILD.format(root=root).replace("(48, 64, 3, 9, 1.0, \"softmax\", 1)", "(128, 96, 1, 3, 0.5, \"softmax\", 1)"))
+    got = []
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, str(script)], env={**os.environ, "IMK_CONV_PRESTAGE": mode}, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert got[0] == got[1]
