@@ -339,10 +339,18 @@ def main():
     pool_y[U:, 0] = m_lab[..., 0]                                   # {0, 255} like the written mask files
     lab_idx = torch.arange(U, U + x_lab.shape[0], device=dev)
 
+    def infer_batches(n):
+        """batches of --infer-batch images; a last batch under a quarter of that is spread over the others instead (at 8 ranks a
+        shard is 292 images: one call, not 256 + 36 -- the deep levels of a forward cost the same for 36 images as for 256)"""
+        k, b = -(-n // args.infer_batch), args.infer_batch
+        if k > 1 and n - (k - 1) * b < b // 4:
+            k -= 1
+            b = -(-n // k)
+        return [(i, min(i + b, n)) for i in range(0, n, b)]
+
     def im_stage(x, into_pool=True):
         ps, ims = [], []
-        for i in range(0, x.shape[0], args.infer_batch):
-            j = min(i + args.infer_batch, x.shape[0])
+        for i, j in infer_batches(x.shape[0]):
             r = ens.run(x[i:j], 0.5, False, True, True, out={"img_out": pool_x[i:j], "masks": pool_y[i:j]} if into_pool else None)
             ps.append(r["pred_size"][:, 0]); ims.append(r["im_size"][:, 0])
         ps, ims = torch.cat(ps), torch.cat(ims)
