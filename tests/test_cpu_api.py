@@ -87,6 +87,12 @@ def test_plan_rejects_bad_config(built_lib):
         Plan(250, 256, 3, 1, 0.5, "sigmoid")      # not a multiple of 16
     with pytest.raises(ValueError):
         Plan(256, 256, 3, 1, 0.5, "tanh")
+    # include/imk.h: images of 2^24 pixels or more are refused (the conv kernels' 24-bit tile-offset arithmetic) ...
+    with pytest.raises(ImkError, match="-2"):
+        Plan(4096, 4096, 3, 1, 0.5, "sigmoid")
+    with pytest.raises(ImkError, match="-2"):
+        Plan(16, 65536, 3, 1, 0.5, "sigmoid")
+    Plan(4096, 4080, 3, 1, 0.5, "sigmoid")        # ... one row less is a plan
 
 
 def test_shard_list_partitions():
