@@ -257,7 +257,7 @@ extern "C" int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, voi
         OK(b.wgrad_dgrad(t.t_c1[s], c.dA(t.t_c3[s]), c.act(t.t_c3[s])));
         OK(b.wgrad_dgrad(t.t_c3[s], c.dy(t.in_bn[s]), nullptr, t.in_bn[s]));
         OK(b.bn_bwd(t.in_bn[s], 0, nullptr, nullptr));
-        OK(b.wgrad(t.in_c[s]));
+        OK(b.wgrad(t.in_c[s], nullptr, s == 0));      // the very last one stays on the main stream (Bwd::wgrad)
     }
     OK(b.finish_wgrads());
 #undef OK

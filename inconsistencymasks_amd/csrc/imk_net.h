@@ -379,7 +379,9 @@ struct Bwd {
         if (rc) return rc;
         return wgrad_job(conv, a);
     }
-    int wgrad(int conv, const f16 *dA_override = nullptr) {
+    // last = the backward pass's final weight gradient (the input block's): nothing is left to overlap with, so it stays
+    // queued for finish_wgrads, which launches it on the main stream -- no fork and no join in the step's tail
+    int wgrad(int conv, const f16 *dA_override = nullptr, bool last = false) {
         const ImkLayer &l = c.p->layers[conv];
         const Dim d = res_dim(c.p->cfg, l.res);
         const bool small = (long long)c.B * d.h * d.w <= side_max_pixels;
@@ -388,7 +390,7 @@ struct Bwd {
             pending[n_pending++] = Pending{conv, dA_override};
             // full-resolution layers: fork at once -- their kernels are long (the bubble is small against them) and the
             // last block's weight gradients would otherwise all start after the main chain has ended
-            return l.res == 0 ? flush_wgrads() : IMK_OK;
+            return (l.res == 0 && !last) ? flush_wgrads() : IMK_OK;
         }
         return launch_wgrad(conv, dA_override, c.stream);
     }

@@ -460,7 +460,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.flush_wgrads());
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
-    OK(b.wgrad(t.in_c));
+    OK(b.wgrad(t.in_c, nullptr, true));
     OK(b.finish_wgrads());
     if (!loss_done) OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, stream));
 #undef OK
