@@ -1484,16 +1484,20 @@ struct ImkWgradGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco; };
 // branch the compiler protects the reuse of its destination registers with `s_waitcnt vmcnt(0)` in front of EVERY load of
 // the next tile, i.e. the seven loads of a prefetch went out one memory latency after the other (cycle stamps: 3.6-4.3 k
 // of a workgroup's 8 k cycles per tile).
-template <int LM, bool BNB>
+// KS3: 3x3 conv (9 tap accumulators + the one of the bias gradient) or 1x1 (2): the 1x1 form needs 32 registers and 32 KB of
+// LDS less -- these kernels share the chip with the backward chain, whose next launch can only start where registers and LDS
+// are left
+template <int LM, bool BNB, bool KS3>
 __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const ImkWgradGeom &gm, int bx, int by, int nbx, int nby) {
     const int tiles_x = gm.tiles_x, tiles_y = gm.tiles_y, n_tiles = gm.n_tiles, cit_n = gm.cit_n, cot_n = gm.cot_n;
     const int nc8_in = gm.nci, nc8_out = gm.nco;
     (void)tiles_y; (void)cit_n;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int ks3 = (a.ksize == 3);
+    constexpr int ks3 = KS3 ? 1 : 0;
+    constexpr int NACC = KS3 ? 10 : 2;          // taps + bias
     const int halo = ks3 ? 1 : 0;
     const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
-    const int T = ks3 ? 9 : 1;
+    constexpr int T = KS3 ? 9 : 1;
     f16 *s_x = reinterpret_cast<f16 *>(smem);
     f16 *s_d = s_x + 18 * 18 * WG_STRIDE_H;
     float *s_aff = reinterpret_cast<float *>(s_d + 256 * WG_STRIDE_H);
@@ -1509,9 +1513,9 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
     if (bnbwd)
         for (int i = t; i < 3 * a.cs_out; i += 256) s_coef[i] = a.dA_coef[i];
 
-    f32x4 acc[10];
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
     f16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (f16)(i16 == 0 ? 1.0f : 0.0f);
@@ -1624,8 +1628,8 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
             for (int e = 0; e < 4; ++e) { bf[e] = (f16)b0[e]; bf[4 + e] = (f16)b1[e]; }
             const f16 *pa = s_x + (row * WT + xx) * WG_STRIDE_H + 4 * pp;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap < T) {
+            for (int tap = 0; tap < T; ++tap) {
+                {
                     const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap % 3 : 0;
                     const f16 *p = pa + (ty * WT + tx) * WG_STRIDE_H;
                     const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, p));
@@ -1636,29 +1640,27 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
                     acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[tap], 0, 0, 0);
                 }
             }
-            acc[9] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bf, acc[9], 0, 0, 0);  // column sums -> bias grad
+            acc[NACC - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bf, acc[NACC - 1], 0, 0, 0);  // column sums -> bias grad
         }
         __syncthreads();   // tile reads done before the next tile overwrites LDS
         tile = next;
     }
     // ---- reduce the 4 waves' accumulators through LDS, write this workgroup's partial ----------------
-    float *s_acc = reinterpret_cast<float *>(smem);  // [4][10][256]
+    float *s_acc = reinterpret_cast<float *>(smem);  // [4][NACC][256]
 #pragma unroll
-    for (int i = 0; i < 10; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_acc[(wave * 10 + i) * 256 + r * 64 + lane] = acc[i][r];
+        for (int r = 0; r < 4; ++r) s_acc[(wave * NACC + i) * 256 + r * 64 + lane] = acc[i][r];
     __syncthreads();
     float *dst = a.partial + ((size_t)bx * nby + pair) * (T + 1) * 256;
-    for (int i = 0; i <= T; ++i) {
-        const int src = (i == T) ? 9 : i;
-        dst[i * 256 + t] = s_acc[(0 * 10 + src) * 256 + t] + s_acc[(1 * 10 + src) * 256 + t] +
-                           s_acc[(2 * 10 + src) * 256 + t] + s_acc[(3 * 10 + src) * 256 + t];
-    }
+    for (int i = 0; i <= T; ++i)      // row T = the bias gradient
+        dst[i * 256 + t] = s_acc[(0 * NACC + i) * 256 + t] + s_acc[(1 * NACC + i) * 256 + t] +
+                           s_acc[(2 * NACC + i) * 256 + t] + s_acc[(3 * NACC + i) * 256 + t];
 }
 
-template <int LM, bool BNB>
+template <int LM, bool BNB, bool KS3>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgradGeom gm) {
-    wgrad_mfma_body<LM, BNB>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    wgrad_mfma_body<LM, BNB, KS3>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 constexpr int WG_RED_CHUNK = 16;   // splits summed per stage-1 chunk of the weight-gradient reduction
@@ -2325,7 +2327,7 @@ static int plan_wgrad(const ImkWgradArgs &a, WgradLaunch &L) {
     const int cit_n = (a.x.cs_in + 15) / 16, cot_n = (a.cs_out + 15) / 16;
     const int tiles_x = imk_cdiv(a.W, TW), tiles_y = imk_cdiv(a.H, 16);
     size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + (4 * (size_t)a.x.cs_in + 3 * (size_t)a.cs_out) * sizeof(float);
-    const size_t red = 4 * 10 * 256 * sizeof(float);
+    const size_t red = 4 * (size_t)(a.ksize == 3 ? 10 : 2) * 256 * sizeof(float);     // the four waves' accumulators at the end
     if (lds < red) lds = red;
     L.gm = ImkWgradGeom{tiles_x, tiles_y, a.B * tiles_x * tiles_y, cit_n, cot_n, a.x.cs_in / 8, a.cs_out / 8};
     L.gx = a.n_split; L.gy = cit_n * cot_n; L.lds = lds;
@@ -2353,8 +2355,10 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     const dim3 grid(L.gx, L.gy);
     ImkProfScope prof(PF_WGRAD, wgrad_algorithmic_bytes(a, L), stream);
     switch (a.x.lmode) {
-#define IMK_WG(LM) do { if (a.dA_z) wgrad_mfma_kernel<LM, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
-                        else wgrad_mfma_kernel<LM, false><<<grid, 256, L.lds, stream>>>(a, L.gm); } while (0)
+#define IMK_WG(LM) do { if (a.ksize == 3) { if (a.dA_z) wgrad_mfma_kernel<LM, true, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
+                                           else wgrad_mfma_kernel<LM, false, true><<<grid, 256, L.lds, stream>>>(a, L.gm); } \
+                        else { if (a.dA_z) wgrad_mfma_kernel<LM, true, false><<<grid, 256, L.lds, stream>>>(a, L.gm); \
+                               else wgrad_mfma_kernel<LM, false, false><<<grid, 256, L.lds, stream>>>(a, L.gm); } } while (0)
         case LM_RAW: IMK_WG(LM_RAW); break;
         case LM_AFFINE: IMK_WG(LM_AFFINE); break;
         case LM_POOL: IMK_WG(LM_POOL); break;
