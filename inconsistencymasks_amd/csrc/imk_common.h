@@ -81,6 +81,7 @@ struct ImkProfScope {
             stamp_row_[0] = (unsigned long long)(kid);                                                                \
             stamp_row_[1] = (unsigned long long)gridDim.x * gridDim.y;                                                \
             stamp_row_[2] = __builtin_amdgcn_s_memrealtime();                                                         \
+            for (int z_ = 4; z_ < IMK_STAMP_COLS; ++z_) stamp_row_[z_] = 0;   /* the row's previous user may have had more stamps */ \
             stamp_row_[3] = __builtin_amdgcn_s_memtime();                                                             \
         }                                                                                                             \
     }

@@ -802,6 +802,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);
     float *s_red = s_aff + 8 * 16;              // [4 waves][2][16] (the affine table has up to 7 rows of 16: LM_STEM)
     const int t = threadIdx.x;
+    IMK_STAMP_BEGIN(conv, 40000 + LM * 1000 + WG * 100 + CHAIN * 10 + (DYSTAT ? 1 : 0));
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int set = PAIR ? (g >> 1) : 0;        // PAIR: which of the block's two tile rows this lane feeds and owns
     const int H = a.H, W = a.W;
@@ -1243,6 +1244,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             }
         }
     }
+    IMK_STAMP_END(1);
 }
 
 // =====================================================================================================
@@ -1273,6 +1275,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
     float *s_red = s_aff + 4 * 32;                                             // [4 waves][2][16 * MT]
     f16 *s_w = reinterpret_cast<f16 *>(s_red + 4 * 2 * 16 * MT);               // [MT][ns][512]
     const int t = threadIdx.x;
+    IMK_STAMP_BEGIN(conv, 50000 + LM * 1000 + MT * 10 + (DYSTAT ? 1 : 0));
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int H = a.H, W = a.W;
     const int cs_in = a.x.cs_in;
@@ -1466,6 +1469,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
             }
         }
     }
+    IMK_STAMP_END(1);
 }
 
 // =====================================================================================================
@@ -1507,6 +1511,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
     const int H = a.H, W = a.W;
     const int lane = t & 63, wave = t >> 6, g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
 
+    IMK_STAMP_BEGIN(conv, 30000 + LM * 10 + (BNB ? 1 : 0));
     stage_affine_table(a.x, s_aff);
     float *s_coef = s_aff + 4 * a.x.cs_in;          // [A | B | C] of the dA-side BatchNorm backward (optional)
     constexpr bool bnbwd = BNB;
@@ -1656,6 +1661,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
     for (int i = 0; i <= T; ++i)      // row T = the bias gradient
         dst[i * 256 + t] = s_acc[(0 * NACC + i) * 256 + t] + s_acc[(1 * NACC + i) * 256 + t] +
                            s_acc[(2 * NACC + i) * 256 + t] + s_acc[(3 * NACC + i) * 256 + t];
+    IMK_STAMP_END(1);
 }
 
 template <int LM, bool BNB, bool KS3>

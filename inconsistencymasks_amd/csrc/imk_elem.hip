@@ -135,6 +135,7 @@ __device__ __forceinline__ void prep_block_reduce(const float (&s1)[8], const fl
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
+    IMK_STAMP_BEGIN(elem, 10 + MODE);
     // thread -> (pixel slot, chunk): 256 threads = (256 / nc8p) pixel slots x nc8p chunk lanes, nc8p = nc8 rounded up
     // to a power of two <= 256 (lanes with chunk >= nc8 idle).  No division in the hot loop.
     const int nc8 = a.cs / 8;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
         }
     }
     prep_block_reduce(s1, s2, slot, slots, sh, c8, nc8, a.cs, a.partial);
+    IMK_STAMP_END(1);
 }
 
 // MODE 1 (encoder outputs: skip gradient + max-pool scatter), one 2x2 pooling window per thread and iteration: the four
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
 // be a channel slice of a wider tensor, go_cs).
 template <bool DIRECT>
 __global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
+    IMK_STAMP_BEGIN(elem, 20);
     const int nc8 = a.cs / 8;
     int sh = 0;
     while ((1 << sh) < nc8) ++sh;
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
         }
     }
     prep_block_reduce(s1, s2, slot, slots, sh, c8, nc8, a.cs, a.partial);
+    IMK_STAMP_END(1);
 }
 
 // pass 2: per-channel coefficients  dz = A*dy + Bc*z + Cc  and the gamma/beta gradients

@@ -62,11 +62,24 @@ for rt, tu, r in rows:
     if int(r[15]) > rt:
         num += st[-1] - st[0]; den += int(r[15]) - rt
 mhz = num / den * 100.0
+print(f"shader clock ~{mhz:.0f} MHz; {len(rows)} stamped launches; after the grid size: us from kernel entry at each stamp")
+# kernel ids: 1 bn_finalize, 2 bn_bwd_coef, 10+m bn_bwd_prep<m>, 20 bn_bwd_prep_pool, 1xxxx conv_mfma, 3xxxx wgrad_mfma (side
+# stream except the step's last one), 4xxxx conv_pipe, 5xxxx conv_wide.  "idle" = time between the end of the previous MAIN-chain
+# kernel's first workgroup and this kernel's entry (head+loss, AdamW, the re-pack and the split reductions carry no stamps).
 prev_end = None
+idle_sum = 0.0
 for rt, tu, r in rows:
     st = [int(v) for v in r[3:15] if int(v)]
     rel = [(v - st[0]) / mhz for v in st]
-    gap = "" if prev_end is None else f"{(rt - prev_end) / 100.0:7.1f}"
-    prev_end = rt + int(rel[-1] * 100)
-    print(f"{(rt - rows[0][0]) / 100.0:9.1f} us  since-prev-end {gap:>7}  {tu}:{int(r[0]):6d} grid {int(r[1]):5d}  " +
+    kid = int(r[0])
+    side = tu == "conv" and 30000 <= kid < 40000
+    t_us = (rt - rows[0][0]) / 100.0
+    idle = ""
+    if not side:
+        if prev_end is not None:
+            idle = f"{t_us - prev_end:7.1f}"
+            if t_us - prev_end > 0: idle_sum += t_us - prev_end
+        prev_end = t_us + rel[-1]
+    print(f"{t_us:9.1f} us  {'side' if side else 'MAIN'} idle-before {idle:>7}  {tu}:{kid:6d} grid {int(r[1]):5d}  " +
           " ".join(f"{v:6.2f}" for v in rel[1:]))
+print(f"sum of main-chain idle (incl. unstamped kernels' run time): {idle_sum:.1f} us")
