@@ -4,6 +4,7 @@
 // gradients on a side stream, BatchNorm backward).  The network files add the topology and the order of the launches.
 // Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -359,6 +360,13 @@ struct Bwd {
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
         a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
         a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
+        // The pooled-input 3x3 form of the kernel holds 162 VGPRs: three workgroups per CU would leave the backward chain's next
+        // kernel no registers to start in (see wgrad_mfma_body: KS3), so it runs with two
+        if (l.ksize == 3 && l.lmode == LM_POOL) {
+            static const int pool_wgs = []() { const char *e = getenv("IMK_WGRAD_POOL_WGS"); return e ? atoi(e) : 512; }();
+            const int n_pairs = ((imk_pad8(l.cin) + 15) / 16) * ((imk_pad8(l.cout) + 15) / 16);
+            a.n_split = std::max(1, std::min(a.n_split, pool_wgs / n_pairs));
+        }
     }
     int wgrad_job(int conv, const ImkWgradArgs &a) {
         const ImkLayer &l = c.p->layers[conv];
