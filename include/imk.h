@@ -294,9 +294,10 @@ IMK_API int imk_debug_single_stream(int on);
  *   7  wgrad_mfma_kernel      8  bn_bwd_prep(_pool)_kernel       9  bn_bwd_coef_kernel     10  bn_finalize_kernel
  *   11 wgf_stage1 + wgf_stage2 (one bracket)                     12 head_kernel            13  head_loss_kernel
  *   14 loss_finalize / adamw / pack_conv_batched / bn_fold_batched                         15  im_binary_* / im_multi_kernel
+ *   16 conv_gemm_kernel (wide layers, forward / dgrad)           17 wgrad_gemm_kernel (wide layers, weight gradient)
  * Process-global and not thread-safe; for benchmarking only (two hipEventRecord per sampled launch while enabled).
  * ---------------------------------------------------------------------------------------------- */
-#define IMK_PROF_VARIANTS 16
+#define IMK_PROF_VARIANTS 18
 IMK_API int imk_prof_enable(int on);
 IMK_API int imk_prof_collect(int64_t *count, double *ms, double *bytes);
 

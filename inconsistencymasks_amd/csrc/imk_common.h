@@ -40,7 +40,9 @@ enum ImkProfFamily {
     PF_HEAD_LOSS = 13,   // head_loss_kernel
     PF_STEP_TAIL = 14,   // loss_finalize_kernel, adamw_kernel, pack_conv_batched_kernel, bn_fold_batched_kernel
     PF_IM = 15,          // im_binary_vec / im_binary_generic / im_multi_kernel
-    PF_COUNT = 16
+    PF_CONV_GEMM = 16,   // conv_gemm_kernel (imk_gemm.hip: forward / dgrad of the wide layers)
+    PF_WGRAD_GEMM = 17,  // wgrad_gemm_kernel
+    PF_COUNT = 18
 };
 // Returns a slot >= 0 when this launch is sampled (an event was recorded on `stream`), else -1.
 int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream);

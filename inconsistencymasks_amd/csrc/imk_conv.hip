@@ -22,347 +22,12 @@
 #include "imk_kernels.h"
 #include "imk_elem.h"
 
-typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
-#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T *)(p))
+#include "imk_stage.h"
 
 IMK_STAMP_TABLE(conv)
 
 namespace {
 
-constexpr int TW = 16;  // tile width = one MFMA pixel group per tile row
-
-struct TileCoord { int b, ty0, tx0; };
-
-__device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles_y, int th) {
-    TileCoord c;
-    const int per_img = tiles_x * tiles_y;
-    c.b = tile / per_img;
-    const int r = tile - c.b * per_img;
-    const int ty = r / tiles_x;
-    c.ty0 = ty * th;
-    c.tx0 = (r - ty * tiles_x) * TW;
-    return c;
-}
-
-// Chunks (of 8 channels) per K pass.  The per-tile kernel walks the input channels in passes of at most IMK_PASS_CAP
-// chunks, each pass staging its channel slice of the tile and of the packed weights into LDS (k order = pass, tap,
-// chunk in pass).  Short passes keep the LDS footprint near 60 KB whatever the layer width, so 2-3 workgroups share a
-// CU and one's staging overlaps another's MFMAs: measured per inference call of 128 images (alpha = 1 nets) with caps
-// 32 / 8 / 4 / 2: SUIM 1.97 / 1.74 / 1.64 / 1.82 ms, Cityscapes 3.68 / - / 2.93 / 3.17 ms; ISIC (alpha 0.5) 0.71 / 0.71 /
-// 0.70 / 0.73 ms.
-__host__ __device__ inline int imk_cdiv_d(int a, int b) { return (a + b - 1) / b; }
-#ifndef IMK_PASS_CAP
-#define IMK_PASS_CAP 4
-#endif
-__host__ __device__ inline int imk_pass_chunks(int nc8) {
-    if (nc8 <= IMK_PASS_CAP) return nc8;
-    const int n_pass = imk_cdiv_d(nc8, IMK_PASS_CAP);
-    return imk_cdiv_d(nc8, n_pass);
-}
-
-// n / d for n < 2^23 via a float reciprocal (exact after one correction step): ~6 VALU ops instead of ~35
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float inv_d) {
-    unsigned q = (unsigned)((float)n * inv_d);
-    const int r = (int)n - (int)(q * d);
-    if (r < 0) --q; else if (r >= (int)d) ++q;
-    return q;
-}
-
-__device__ __forceinline__ TileCoord tile_coord_fast(int tile, int tiles_x, int per_img, float inv_tx, float inv_pi) {
-    TileCoord c;
-    c.b = (int)fast_div((unsigned)tile, (unsigned)per_img, inv_pi);
-    const int r = tile - c.b * per_img;
-    const int ty = (int)fast_div((unsigned)r, (unsigned)tiles_x, inv_tx);
-    c.ty0 = ty * 16;
-    c.tx0 = (r - ty * tiles_x) * TW;
-    return c;
-}
-
-__device__ __forceinline__ f16x8 affine8(f16x8 z, const float *sc, const float *sh) {
-    f16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)z[j] * sc[j] + sh[j]);
-    return o;
-}
-
-// One 8-channel chunk of the conv's input at conv-resolution pixel (y, x) (must be inside the image).
-// s_aff: LDS table [sc | sh | sc2 | sh2], each cs_in floats.
-__device__ __forceinline__ f16x8 load_chunk(const ImkInput &in, int b, int y, int x, int H, int W, int c8,
-                                            const float *s_aff) {
-    const int cs = in.cs_in;
-    switch (in.lmode) {
-        case LM_RAW: {
-            const f16 *p = (const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-            return *(const f16x8 *)p;
-        }
-        case LM_AFFINE: {
-            const f16 *p = (const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-            return affine8(*(const f16x8 *)p, s_aff + c8 * 8, s_aff + cs + c8 * 8);
-        }
-        case LM_POOL: {
-            const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
-            const f16 *p = (const f16 *)in.in + ((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
-            const f16x8 z00 = *(const f16x8 *)p, z01 = *(const f16x8 *)(p + cs);
-            const f16x8 z10 = *(const f16x8 *)(p + (size_t)W2 * cs), z11 = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
-            const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = (float)z00[j] * sc[j] + sh[j], bq = (float)z01[j] * sc[j] + sh[j];
-                const float c = (float)z10[j] * sc[j] + sh[j], d = (float)z11[j] * sc[j] + sh[j];
-                o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-            }
-            return o;
-        }
-        case LM_UPADD: {
-            const int Hl = H / 2, Wl = W / 2;
-            const f16 *pl = (const f16 *)in.in + ((size_t)(b * Hl + (y >> 1)) * Wl + (x >> 1)) * cs + c8 * 8;
-            const f16 *ps = (const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-            const f16x8 lo = affine8(*(const f16x8 *)pl, s_aff + c8 * 8, s_aff + cs + c8 * 8);
-            const f16x8 sk = affine8(*(const f16x8 *)ps, s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
-            return o;
-        }
-        case LM_BNBWD: {
-            const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-            const f16x8 dy = *(const f16x8 *)((const f16 *)in.in + o), z = *(const f16x8 *)((const f16 *)in.in2 + o);
-            const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
-            f16x8 o8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float zf = (float)z[j];
-                o8[j] = zf > 0.f ? (f16)(A[j] * (float)dy[j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
-            }
-            return o8;
-        }
-        default: {  // LM_U8: cin <= 8 bytes per pixel, single chunk
-            const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * in.cin;
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)(j < in.cin ? (float)p[j] / in.u8_div : 0.0f);
-            return o;
-        }
-    }
-}
-
-__device__ __forceinline__ void stage_affine_table(const ImkInput &in, float *s_aff) {
-    const int cs = in.cs_in;
-    if (in.lmode == LM_AFFINE || in.lmode == LM_POOL || in.lmode == LM_UPADD)
-        for (int i = threadIdx.x; i < cs; i += 256) { s_aff[i] = in.sc[i]; s_aff[cs + i] = in.sh[i]; }
-    if (in.lmode == LM_UPADD)
-        for (int i = threadIdx.x; i < cs; i += 256) { s_aff[2 * cs + i] = in.sc2[i]; s_aff[3 * cs + i] = in.sh2[i]; }
-    if (in.lmode == LM_BNBWD)
-        for (int i = threadIdx.x; i < 3 * cs; i += 256) s_aff[i] = in.sc[i];
-    if (in.lmode == LM_STEM) {   // [sc | sh | W[0] | W[1] | W[2] | W[3] | bias], cs floats each; weights as the fp16 values the stem kernel uses
-        for (int i = threadIdx.x; i < cs; i += 256) {
-            const bool real = i < in.cin;
-            s_aff[i] = in.sc[i]; s_aff[cs + i] = in.sh[i];
-            for (int c = 0; c < 4; ++c) s_aff[(2 + c) * cs + i] = (real && c < in.u8_c) ? (float)(f16)in.sc2[c * in.cin + i] : 0.f;
-            s_aff[6 * cs + i] = real ? in.sh2[i] : 0.f;
-        }
-    }
-}
-
-// ---- two-phase input staging: raw global loads into registers, transform later ------------------------------------
-template <int LM> struct RawChunk { f16x8 v[LM == LM_POOL ? 4 : ((LM == LM_UPADD || LM == LM_BNBWD) ? 2 : 1)]; };
-template <> struct RawChunk<LM_U8> { uint32_t b[4]; };
-template <> struct RawChunk<LM_STEM> { uint32_t b[4]; };
-
-template <int LM>
-__device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x, int H, int W, int c8, RawChunk<LM> &r) {
-    const int cs = in.cs_in;
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE) {
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
-    } else if constexpr (LM == LM_POOL) {
-        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
-        const f16 *p = (const f16 *)in.in + ((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
-        r.v[0] = *(const f16x8 *)p;
-        r.v[1] = *(const f16x8 *)(p + cs);
-        r.v[2] = *(const f16x8 *)(p + (size_t)W2 * cs);
-        r.v[3] = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
-    } else if constexpr (LM == LM_UPADD) {
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * cs + c8 * 8);
-        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + ((size_t)(b * H + y) * W + x) * cs + c8 * 8);
-    } else if constexpr (LM == LM_BNBWD) {
-        const size_t o = ((size_t)(b * H + y) * W + x) * cs + c8 * 8;
-        r.v[0] = *(const f16x8 *)((const f16 *)in.in + o);
-        r.v[1] = *(const f16x8 *)((const f16 *)in.in2 + o);
-    } else {
-        const int nb = LM == LM_STEM ? in.u8_c : in.cin;     // bytes per pixel
-        const uint8_t *p = (const uint8_t *)in.in + ((size_t)(b * H + y) * W + x) * nb;
-        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
-        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
-        // bytes early, so nothing past the image is read (H * W * nb >= 4).
-        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-        const int rem = (H * W - (y * W + x)) * nb;          // bytes from this pixel to the end of its image
-        const int back = rem >= 4 ? 0 : 4 - rem;
-        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(p - back) >> (8 * back);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
-    }
-}
-
-template <int LM>
-__device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin,
-                                               float u8_div) {
-    if constexpr (LM == LM_RAW) {
-        return r.v[0];
-    } else if constexpr (LM == LM_AFFINE) {
-        return affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
-    } else if constexpr (LM == LM_POOL) {
-        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = (float)r.v[0][j] * sc[j] + sh[j], bq = (float)r.v[1][j] * sc[j] + sh[j];
-            const float c = (float)r.v[2][j] * sc[j] + sh[j], d = (float)r.v[3][j] * sc[j] + sh[j];
-            o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-        }
-        return o;
-    } else if constexpr (LM == LM_UPADD) {
-        const f16x8 lo = affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
-        const f16x8 sk = affine8(r.v[1], s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)lo[j] + (float)sk[j]);
-        return o;
-    } else if constexpr (LM == LM_BNBWD) {
-        const float *A = s_aff + c8 * 8, *Bc = s_aff + cs + c8 * 8, *Cc = s_aff + 2 * cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float zf = (float)r.v[1][j];
-            o[j] = zf > 0.f ? (f16)(A[j] * (float)r.v[0][j] + Bc[j] * zf + Cc[j]) : (f16)0.f;
-        }
-        return o;
-    } else if constexpr (LM == LM_STEM) {
-        // x * (1/255) rounds to the same fp16 as x / 255 for all 256 byte values (checked exhaustively)
-        float xin[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xin[c] = (float)(f16)((float)r.b[c] * (1.0f / 255.0f));
-        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8, *bias = s_aff + 6 * cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc = fmaf(s_aff[(2 + c) * cs + c8 * 8 + j], xin[c], acc);   // absent channels: zero weights
-            const f16 z = (f16)fmaxf(acc + bias[j], 0.f);                                            // the stem's stored output
-            o[j] = (f16)((float)z * sc[j] + sh[j]);
-        }
-        return o;
-    } else {
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((j < 4 && j < cin) ? (float)r.b[j] / u8_div : 0.0f);
-        return o;
-    }
-}
-
-// =====================================================================================================
-// Addresses of the conv kernels = (64-bit SCALAR base of the tile) + (32-bit unsigned per-lane byte offset).
-// Written as ((b * H + y) * W + x) * cs in size_t per access, every load and store of a tile loop cost a 64 x 32-bit multiply
-// in vector registers (v_mad_i64_i32, 2 v_mul_lo_u32, v_mad_u64_u32: quarter-rate instructions, ~18 issue slots per access)
-// and the tile coordinates two float-reciprocal divisions on uniform values -- about a third of the VALU time of kernels
-// whose VALU is ~70 % busy (SQ_ACTIVE_INST_VALU, profiles/r02_sq_counters.csv).  Instead: (image, tile in image) advance by
-// the grid size without a division, the tile row comes from one s_mul_hi_u32 by a host-computed magic number, the tile's
-// base address of each tensor is scalar arithmetic, and a lane adds an offset relative to the tile origin -- a constant for
-// the stores and epilogue loads of full tiles, one clamp per coordinate and one 24-bit multiply-add (full rate) for a
-// staged halo pixel.  Limits: imk_conv_max_pixels() per image, rows < 2^16 (plans are refused above).
-// =====================================================================================================
-struct PTile { int b, r, ty0, tx0; };            // r: the tile's index inside image b; all four live in scalar registers
-__device__ __forceinline__ PTile ptile_at(int b, int r, int tiles_x, unsigned magic_tx) {
-    PTile c;
-    c.b = __builtin_amdgcn_readfirstlane(b); c.r = __builtin_amdgcn_readfirstlane(r);
-    const unsigned ru = (unsigned)c.r;
-    const unsigned ty = tiles_x == 1 ? ru : (unsigned)(((unsigned long long)ru * magic_tx) >> 32);   // r * tiles_x < 2^32
-    c.ty0 = (int)ty * 16;
-    c.tx0 = (int)(ru - ty * (unsigned)tiles_x) * TW;
-    return c;
-}
-__device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid_r, int per_img, int tiles_x, unsigned magic_tx) {
-    int b = c.b + grid_q, r = c.r + grid_r;      // the grid size = grid_q images + grid_r tiles (host-computed)
-    if (r >= per_img) { r -= per_img; ++b; }
-    return ptile_at(b, r, tiles_x, magic_tx);
-}
-// base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)
-__device__ __forceinline__ const char *pix_base(const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {
-    return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
-}
-
-// The staged input of one tile: scalar bases of the source tensor(s) at the halo tile's origin (-1 at the image border) and
-// the window of its rows / columns that lie inside the image.
-template <int LM>
-struct PSrc {
-    const char *b_in, *b_in2;
-    unsigned row2_b, w2, csb;
-    int oy, ox, oyl, oxl, pix0, nb, hw, lo_y, hi_y, lo_x, hi_x;
-};
-// CSB: bytes per pixel of the fp16 input tensor when the kernel knows them at compile time, 0 = in.cs_in * 2 at run time
-template <int LM, unsigned CSB>
-__device__ __forceinline__ PSrc<LM> psrc_of(const ImkInput &in, const PTile &tc, int halo, int HT, int WT, int H, int W) {
-    PSrc<LM> s{};
-    const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
-    const unsigned csb = CSB ? CSB : (unsigned)in.cs_in * 2u;
-    s.csb = csb;
-    s.oy = oy; s.ox = ox;
-    s.lo_y = oy < 0 ? -oy : 0; s.hi_y = min(HT - 1, H - 1 - oy);
-    s.lo_x = ox < 0 ? -ox : 0; s.hi_x = min(WT - 1, W - 1 - ox);
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-        s.b_in = pix_base(in.in, tc.b, H, W, oy, ox, csb);
-        if constexpr (LM == LM_BNBWD) s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, csb);
-    } else if constexpr (LM == LM_POOL) {
-        const int H2 = in.src_h ? in.src_h : 2 * H, W2 = in.src_w ? in.src_w : 2 * W;
-        s.b_in = pix_base(in.in, tc.b, H2, W2, 2 * oy, 2 * ox, csb);
-        s.w2 = (unsigned)W2;
-        s.row2_b = s.w2 * csb;
-    } else if constexpr (LM == LM_UPADD) {
-        s.oyl = oy >> 1; s.oxl = ox >> 1;
-        s.b_in = pix_base(in.in, tc.b, H / 2, W / 2, s.oyl, s.oxl, csb);
-        s.b_in2 = pix_base(in.in2, tc.b, H, W, oy, ox, csb);
-    } else {                                        // uint8 pixels: nb bytes each
-        s.nb = LM == LM_STEM ? in.u8_c : in.cin;
-        s.hw = H * W;
-        s.pix0 = oy * W + ox;                       // may be negative; pix0 + (a clamped pixel's offset) never is
-        s.b_in = reinterpret_cast<const char *>(in.in) + (long long)tc.b * s.hw * s.nb;
-    }
-    return s;
-}
-// Chunk c8 of the halo tile's pixel (py, px), clamped into the image (unconditional load); returns whether it was inside.
-template <int LM, unsigned CSB>
-__device__ __forceinline__ bool psrc_load(const PSrc<LM> &s, int py, int px, int c8, int W, RawChunk<LM> &r) {
-    const int ry = min(max(py, s.lo_y), s.hi_y), rx = min(max(px, s.lo_x), s.hi_x);
-    auto bytes = [&](unsigned pixels) { return CSB ? pixels * CSB : __umul24(pixels, s.csb); };   // tile-relative: < 2^24
-    if constexpr (LM == LM_RAW || LM == LM_AFFINE || LM == LM_BNBWD) {
-        const unsigned o = bytes(__umul24(ry, W) + rx) + c8 * 16;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
-        if constexpr (LM == LM_BNBWD) r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + o);
-    } else if constexpr (LM == LM_POOL) {
-        const unsigned o = bytes(__umul24(2 * ry, s.w2) + 2 * rx) + c8 * 16;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + o);
-        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.csb);
-        r.v[2] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b);
-        r.v[3] = *reinterpret_cast<const f16x8 *>(s.b_in + o + s.row2_b + s.csb);
-    } else if constexpr (LM == LM_UPADD) {
-        const int yl = ((s.oy + ry) >> 1) - s.oyl, xl = ((s.ox + rx) >> 1) - s.oxl;
-        r.v[0] = *reinterpret_cast<const f16x8 *>(s.b_in + bytes(__umul24(yl, W / 2) + xl) + c8 * 16);
-        r.v[1] = *reinterpret_cast<const f16x8 *>(s.b_in2 + bytes(__umul24(ry, W) + rx) + c8 * 16);
-    } else {
-        // One unaligned dword instead of nb byte loads (RGB images: the byte loads made the stem's weight gradient
-        // issue-bound), branch-free like every load of the prefetches: the last pixels of an image take their dword a few
-        // bytes early, so nothing past the image is read (H * W * nb >= 4).
-        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-        const int pidx = s.pix0 + (int)(__umul24(ry, W) + rx);           // pixel index inside its image
-        const int rem = __mul24(s.hw - pidx, s.nb);                       // bytes from this pixel to the end of the image
-        const int back = rem >= 4 ? 0 : 4 - rem;
-        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(s.b_in + (unsigned)(__mul24(pidx, s.nb) - back)) >> (8 * back);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = (j < s.nb) ? ((v >> (8 * j)) & 0xffu) : 0u;
-    }
-    return ry == py && rx == px;
-}
 
 // =====================================================================================================
 // forward / dgrad
@@ -1475,8 +1140,6 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
 // =====================================================================================================
 // wgrad
 // =====================================================================================================
-constexpr int WG_STRIDE_H = 16;  // halfs per pixel in the wgrad LDS slices: 16 channels = 32 B, unpadded on purpose -- a 32-lane half
-                                 // of a transposed read covers 8 CONSECUTIVE pixels = one contiguous 256-B bank row (conflict-free)
 
 // LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
 // tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
@@ -1669,7 +1332,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgra
     wgrad_mfma_body<LM, BNB, KS3>(a, gm, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
-constexpr int WG_RED_CHUNK = 16;   // splits summed per stage-1 chunk of the weight-gradient reduction
 
 // ---- batched, deterministic reduction of all layers' weight-gradient partials -----------------------------
 __device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx, bool stage1) {
@@ -1857,7 +1519,9 @@ static inline int conv_tile_h(int cs_in, int ksize) {
 }
 
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
-    return B * imk_cdiv(H, conv_tile_h(cs_in, ksize)) * imk_cdiv(W, TW);
+    const int per_tile = B * imk_cdiv(H, conv_tile_h(cs_in, ksize)) * imk_cdiv(W, TW);
+    const int gemm = imk_conv_gemm_num_tiles(B, H, W);    // the GEMM-class kernel's rows (8 x 16 tiles), whichever kernel runs
+    return per_tile > gemm ? per_tile : gemm;
 }
 
 // ---- optional per-launch event timing (bench.py roofline) ---------------------------------------------
@@ -1876,23 +1540,6 @@ hipEvent_t prof_event() {
     return e;
 }
 
-double conv_algorithmic_bytes(const ImkConvArgs &a) {
-    const double px = (double)a.B * a.H * a.W;
-    double in_b;
-    switch (a.x.lmode) {
-        case LM_POOL: in_b = 4.0 * px * a.x.cs_in * 2; break;                     // reads the 2H x 2W tensor
-        case LM_UPADD: in_b = px * a.x.cs_in * 2 + 0.25 * px * a.x.cs_in * 2; break;  // skip + low-res tensor
-        case LM_BNBWD: in_b = 2.0 * px * a.x.cs_in * 2; break;                        // dy and z
-        case LM_U8: in_b = px * a.x.cin; break;
-        case LM_STEM: in_b = px * a.x.u8_c; break;
-        default: in_b = px * a.x.cs_in * 2;
-    }
-    double out_b = (a.wpk2 && !a.out) ? 0.0 : px * a.cs_out * 2;
-    if (a.wpk2) out_b += px * a.cs_out2 * 2;
-    if (a.epi == EP_MASK) out_b += px * a.cs_out * 2;
-    if (a.epi != EP_RELU && a.dystat_z) out_b += px * a.cs_out * 2;
-    return in_b + out_b;
-}
 }  // namespace
 
 extern "C" int imk_prof_enable(int on) { g_prof_period = on < 0 ? 0 : on; return IMK_OK; }
@@ -1992,7 +1639,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         kern<<<grid, 256, L.lds, stream>>>(a, L.gm);
         return IMK_OK;
     };
-    ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), imk_conv_algorithmic_bytes(a), stream);
     if (a.wpk2) {   // Conv3x3+ReLU -> Conv1x1+ReLU in one launch: encoder blocks pool on load, decoder blocks read a BatchNorm output
         if (L.gy != 1 || L.th != 16) return IMK_EUNSUPPORTED;
         if (a.x.lmode == LM_POOL) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4, LM_POOL, true>) : launch(conv_mfma_kernel<16, 2, LM_POOL, true>);
@@ -2043,7 +1690,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream);
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -2139,7 +1786,7 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    ImkProfScope prof(PF_CONV_PIPE, conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream);
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -2299,6 +1946,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
     if (a.x.lmode == LM_STEM) return IMK_EUNSUPPORTED;
     if (conv_wide_ok(a)) return launch_conv_wide_any(a, stream);
+    if (imk_conv_gemm_ok(a)) return imk_launch_conv_gemm(a, stream);
     return launch_conv_mfma(a, stream);
 }
 
@@ -2319,6 +1967,13 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
     // a 1x1 conv between narrow layers may get its weight gradient from its dgrad launch: one row per workgroup of that
     if (imk_pad8(cin) <= 16 && imk_pad8(cout) <= 16 && ns < (size_t)imk_conv_fused_wgrad_rows_max())
         ns = (size_t)imk_conv_fused_wgrad_rows_max();
+    // wide layers: the GEMM-class kernel's split count (whichever kernel runs: the size must not depend on a switch)
+    if (imk_pad8(cin) > 32 || imk_pad8(cout) > 32) {
+        for (int lm : {(int)LM_RAW, (int)LM_POOL}) {     // the split count depends on the load mode (pooling: smaller groups)
+            const size_t ng = (size_t)imk_wgrad_gemm_splits(lm, B, H, W, ksize, imk_pad8(cin), imk_pad8(cout));
+            if (ns < ng) ns = ng;
+        }
+    }
     return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch
 }
 
@@ -2355,6 +2010,7 @@ static double wgrad_algorithmic_bytes(const ImkWgradArgs &a, const WgradLaunch &
 }
 
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
+    if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, a.ksize, a.x.cs_in, a.cs_out)) return imk_launch_wgrad_gemm(a, stream);
     WgradLaunch L{};
     int rc = plan_wgrad(a, L);
     if (rc) return rc;

@@ -74,6 +74,28 @@ struct ImkConvArgs {
     const float *wg_sc, *wg_sh;
 };
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
+// GEMM-class kernel for the wide layers (imk_gemm.hip): which launches it takes, its launcher, its statistics rows
+bool imk_conv_gemm_ok(const ImkConvArgs &a);
+int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream);
+int imk_conv_gemm_num_tiles(int B, int H, int W);
+// algorithmic bytes of a conv launch: its input tensor(s) as the load mode reads them + every tensor it writes / re-reads
+inline double imk_conv_algorithmic_bytes(const ImkConvArgs &a) {
+    const double px = (double)a.B * a.H * a.W;
+    double in_b;
+    switch (a.x.lmode) {
+        case LM_POOL: in_b = 4.0 * px * a.x.cs_in * 2; break;                     // reads the 2H x 2W tensor
+        case LM_UPADD: in_b = px * a.x.cs_in * 2 + 0.25 * px * a.x.cs_in * 2; break;  // skip + low-res tensor
+        case LM_BNBWD: in_b = 2.0 * px * a.x.cs_in * 2; break;                        // dy and z
+        case LM_U8: in_b = px * a.x.cin; break;
+        case LM_STEM: in_b = px * a.x.u8_c; break;
+        default: in_b = px * a.x.cs_in * 2;
+    }
+    double out_b = (a.wpk2 && !a.out) ? 0.0 : px * a.cs_out * 2;
+    if (a.wpk2) out_b += px * a.cs_out2 * 2;
+    if (a.epi == EP_MASK) out_b += px * a.cs_out * 2;
+    if (a.epi != EP_RELU && a.dystat_z) out_b += px * a.cs_out * 2;
+    return in_b + out_b;
+}
 int imk_conv_fused_wgrad_rows_max();   // capacity the partial buffer needs: rows (workgroups) of the largest such launch
 int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize);  // rows of stats_partial
 int imk_launch_conv(const ImkConvArgs &a, hipStream_t stream);
@@ -88,6 +110,10 @@ struct ImkWgradArgs {
     int n_split;
 };
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout);
+// GEMM-class weight-gradient kernel of the wide layers (imk_gemm.hip).  bnb: the gradient operand is a BatchNorm backward on load
+bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out);
+int imk_wgrad_gemm_splits(int lmode, int B, int H, int W, int ksize, int cs_in, int cs_out);   // = ImkWgradArgs::n_split of such a launch
+int imk_launch_wgrad_gemm(const ImkWgradArgs &a, hipStream_t stream);
 size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout);
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream);
 

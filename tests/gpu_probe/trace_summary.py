@@ -10,7 +10,7 @@ for r in csv.DictReader(open(f)):
                  r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
 # start of a forward: the uint8 stem (training) or the first encoder conv with the input block on load (inference, LM_STEM = 6)
-stems = [i for i, r in enumerate(rows) if r[2].startswith("conv_pipe_kernel<4") or r[2].startswith("conv_pipe_kernel<6")]
+stems = [i for i, r in enumerate(rows) if re.match(r"conv_(pipe|wide)_kernel<\(ImkLoadMode\)[46]|conv_(pipe|wide)_kernel<[46]", r[2])]   # wide: alpha > 1
 folds = [i for i, r in enumerate(rows) if r[2].startswith("pack_conv_batched_kernel")]   # end of an optimizer step
 heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2]]                          # end of an inference call
 def show(seg, title):
