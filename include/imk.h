@@ -300,6 +300,9 @@ IMK_API int imk_debug_single_stream(int on);
 #define IMK_PROF_VARIANTS 18
 IMK_API int imk_prof_enable(int on);
 IMK_API int imk_prof_collect(int64_t *count, double *ms, double *bytes);
+/* the same, plus the summed FLOPs (2 x multiply-adds, logical channel counts) of the sampled conv / weight-gradient launches
+ * (0 for the families that are not convolutions); flops may be NULL */
+IMK_API int imk_prof_collect_ex(int64_t *count, double *ms, double *bytes, double *flops);
 
 #ifdef __cplusplus
 }

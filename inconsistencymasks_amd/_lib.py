@@ -80,6 +80,8 @@ SIGNATURES = {
     "imk_debug_single_stream": (c_int, [c_int]),
     "imk_prof_enable": (c_int, [c_int]),
     "imk_prof_collect": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "imk_prof_collect_ex": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]),
     "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_float, c_float, c_float, c_void_p]),
 }

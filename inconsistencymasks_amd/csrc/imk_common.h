@@ -45,12 +45,12 @@ enum ImkProfFamily {
     PF_COUNT = 18
 };
 // Returns a slot >= 0 when this launch is sampled (an event was recorded on `stream`), else -1.
-int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream);
+int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream, double flops = 0.0);
 void imk_prof_end(int slot, hipStream_t stream);
 struct ImkProfScope {
     int slot;
     hipStream_t stream;
-    ImkProfScope(int family, double bytes, hipStream_t s) : slot(imk_prof_begin(family, bytes, s)), stream(s) {}
+    ImkProfScope(int family, double bytes, hipStream_t s, double flops = 0.0) : slot(imk_prof_begin(family, bytes, s, flops)), stream(s) {}
     ~ImkProfScope() { if (slot >= 0) imk_prof_end(slot, stream); }
     ImkProfScope(const ImkProfScope &) = delete;
     ImkProfScope &operator=(const ImkProfScope &) = delete;

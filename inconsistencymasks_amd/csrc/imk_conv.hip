@@ -1527,7 +1527,7 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 // ---- optional per-launch event timing (bench.py roofline) ---------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int variant; double bytes; };
+struct ProfRec { hipEvent_t e0, e1; int variant; double bytes, flops; };
 int g_prof_period = 0;   // 0 = off, k = time every k-th hooked launch
 long g_prof_counter = 0;
 std::vector<ProfRec> g_prof;       // recorded launches since the last collect
@@ -1544,9 +1544,9 @@ hipEvent_t prof_event() {
 
 extern "C" int imk_prof_enable(int on) { g_prof_period = on < 0 ? 0 : on; return IMK_OK; }
 
-int imk_prof_begin(int family, double bytes, hipStream_t stream) {
+int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops) {
     if (g_prof_period <= 0 || (g_prof_counter++ % g_prof_period) != 0) return -1;
-    ProfRec pr{prof_event(), prof_event(), family, bytes};
+    ProfRec pr{prof_event(), prof_event(), family, bytes, flops};
     if (hipEventRecord(pr.e0, stream) != hipSuccess) { g_ev_pool.push_back(pr.e0); g_ev_pool.push_back(pr.e1); return -1; }
     g_prof.push_back(pr);
     return (int)g_prof.size() - 1;
@@ -1555,20 +1555,22 @@ void imk_prof_end(int slot, hipStream_t stream) {
     if (slot >= 0 && slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
-extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) {
+extern "C" int imk_prof_collect_ex(int64_t *count, double *ms, double *bytes, double *flops) {
     IMK_CHECK_ARG(count && ms && bytes);
     static_assert(IMK_PROF_VARIANTS == PF_COUNT, "include/imk.h and imk_common.h disagree");
-    for (int v = 0; v < IMK_PROF_VARIANTS; ++v) { count[v] = 0; ms[v] = 0; bytes[v] = 0; }
+    for (int v = 0; v < IMK_PROF_VARIANTS; ++v) { count[v] = 0; ms[v] = 0; bytes[v] = 0; if (flops) flops[v] = 0; }
     for (auto &r : g_prof) {
         float t = 0.f;
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
             count[r.variant] += 1; ms[r.variant] += t; bytes[r.variant] += r.bytes;
+            if (flops) flops[r.variant] += r.flops;
         }
         g_ev_pool.push_back(r.e0); g_ev_pool.push_back(r.e1);
     }
     g_prof.clear();
     return IMK_OK;
 }
+extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) { return imk_prof_collect_ex(count, ms, bytes, nullptr); }
 
 // Launch geometry of the per-tile kernel for one conv.
 // n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled
@@ -1639,7 +1641,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
         kern<<<grid, 256, L.lds, stream>>>(a, L.gm);
         return IMK_OK;
     };
-    ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), imk_conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     if (a.wpk2) {   // Conv3x3+ReLU -> Conv1x1+ReLU in one launch: encoder blocks pool on load, decoder blocks read a BatchNorm output
         if (L.gy != 1 || L.th != 16) return IMK_EUNSUPPORTED;
         if (a.x.lmode == LM_POOL) rc = L.mt == 4 ? launch(conv_mfma_kernel<16, 4, LM_POOL, true>) : launch(conv_mfma_kernel<16, 2, LM_POOL, true>);
@@ -1690,7 +1692,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -1786,7 +1788,7 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -1894,6 +1896,14 @@ bool imk_conv_can_prestage(const ImkConvArgs &a, int lm_pre, int cin_pre, int co
 bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
     static const int mode = []() { const char *e = getenv("IMK_CONV_CHAIN_TILE"); return e ? atoi(e) : 1; }();
     if (mode == 0) return false;
+    // Where the GEMM-class kernel would take the 3x3 (imk_gemm.hip): IMK_GEMM_OVER_CHAIN = 0 chain anyway, 1 two launches when
+    // the intermediate is stored anyway (training), 2 always two launches
+    static const int over = []() { const char *e = getenv("IMK_GEMM_OVER_CHAIN"); return e ? atoi(e) : 1; }();
+    if (over == 2 || (over == 1 && store_mid)) {
+        ImkConvArgs plain = a;
+        plain.wpk2 = nullptr;
+        if (imk_conv_gemm_ok(plain)) return false;
+    }
     const bool pipe_ok = pipe_enabled() && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16;
     if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;
     if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
@@ -1968,7 +1978,7 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
     if (imk_pad8(cin) <= 16 && imk_pad8(cout) <= 16 && ns < (size_t)imk_conv_fused_wgrad_rows_max())
         ns = (size_t)imk_conv_fused_wgrad_rows_max();
     // wide layers: the GEMM-class kernel's split count (whichever kernel runs: the size must not depend on a switch)
-    if (imk_pad8(cin) > 32 || imk_pad8(cout) > 32) {
+    if (imk_wgrad_gemm_wide(imk_pad8(cin), imk_pad8(cout), (long long)B * H * W)) {
         for (int lm : {(int)LM_RAW, (int)LM_POOL}) {     // the split count depends on the load mode (pooling: smaller groups)
             const size_t ng = (size_t)imk_wgrad_gemm_splits(lm, B, H, W, ksize, imk_pad8(cin), imk_pad8(cout));
             if (ns < ng) ns = ng;
@@ -2010,12 +2020,12 @@ static double wgrad_algorithmic_bytes(const ImkWgradArgs &a, const WgradLaunch &
 }
 
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
-    if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, a.ksize, a.x.cs_in, a.cs_out)) return imk_launch_wgrad_gemm(a, stream);
+    if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, a.ksize, a.x.cs_in, a.cs_out, (long long)a.B * a.H * a.W)) return imk_launch_wgrad_gemm(a, stream);
     WgradLaunch L{};
     int rc = plan_wgrad(a, L);
     if (rc) return rc;
     const dim3 grid(L.gx, L.gy);
-    ImkProfScope prof(PF_WGRAD, wgrad_algorithmic_bytes(a, L), stream);
+    ImkProfScope prof(PF_WGRAD, wgrad_algorithmic_bytes(a, L), stream, imk_wgrad_flops(a));
     switch (a.x.lmode) {
 #define IMK_WG(LM) do { if (a.ksize == 3) { if (a.dA_z) wgrad_mfma_kernel<LM, true, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
                                            else wgrad_mfma_kernel<LM, false, true><<<grid, 256, L.lds, stream>>>(a, L.gm); } \

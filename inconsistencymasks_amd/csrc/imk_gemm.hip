@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGe
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { af[e] = (f16)a0[e]; af[4 + e] = (f16)a1[e]; }
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[o][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[o], acc[o][tap], 0, 0, 0);
+                    for (int o = 0; o < 4; ++o)
+                        if (o < nfo) acc[o][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[o], acc[o][tap], 0, 0, 0);   // uniform
                 }
                 if (do_bias) {                       // column sums of dA -> the bias gradient: A = ones in row o
 #pragma unroll
@@ -558,7 +559,7 @@ int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream) {
     size_t lds = 0;
     int rc = plan_conv_gemm(a, gm, pn, lds, grid);
     if (rc) return rc;
-    ImkProfScope prof(PF_CONV_GEMM, imk_conv_algorithmic_bytes(a), stream);
+    ImkProfScope prof(PF_CONV_GEMM, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     const bool ks3 = a.ksize == 3;
 #define IMK_GEMM_LM(LM) (ks3 ? launch_conv_gemm_k<LM, true>(a, gm, pn, lds, grid, stream) : launch_conv_gemm_k<LM, false>(a, gm, pn, lds, grid, stream))
     switch (a.x.lmode) {
@@ -601,9 +602,13 @@ void plan_wgrad_gemm(int lmode, int B, int H, int W, int ksize, int cs_in, int c
     gm.tiles_x = imk_cdiv(W, TW); gm.tiles_y = imk_cdiv(H, tr);
     gm.n_tiles = B * gm.tiles_x * gm.tiles_y;
     static const int target = []() { const char *e = getenv("IMK_WGRAD_GEMM_WGS"); return e ? atoi(e) : 512; }();
+    // Every workgroup ends by writing its accumulators (148 KB at 64 x 64 channels x 9 taps): with few tiles per workgroup those
+    // partials -- and the split reduction that reads them back -- outweigh the operands, so a workgroup gets at least
+    // IMK_WGRAD_GEMM_TILES pixel tiles (the deep levels then run on fewer workgroups than the chip has slots: they are short)
+    static const int min_tiles = []() { const char *e = getenv("IMK_WGRAD_GEMM_TILES"); return e ? atoi(e) : 8; }();
     int ns = target / (gm.gi_n * gm.go_n);
+    if (ns > gm.n_tiles / min_tiles) ns = gm.n_tiles / min_tiles;
     if (ns < 1) ns = 1;
-    if (ns > gm.n_tiles) ns = gm.n_tiles;
     P.n_split = ns;
     const size_t npx = (size_t)(tr + 2 * halo) * (TW + 2 * halo), npd = (size_t)tr * 16;
     P.lds = (P.nfi_t * npx + 4 * npd) * WG_STRIDE_H * sizeof(f16) + (4 * (size_t)cs_in + 3 * (size_t)cs_out) * sizeof(float);
@@ -626,9 +631,24 @@ int launch_wgrad_gemm_k(const ImkWgradArgs &a, const WgGemmPlan &P, hipStream_t 
 }  // namespace
 
 // wide layers: more than 32 channels on a side (the forward's rule), and a combination that is instantiated
-bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out) {
+// Which layers: more than 32 channels on a side; exactly 32 only with >= 2 M pixels (full resolution at alpha = 2: Cityscapes
+// step 6.20 -> 5.98 ms; at half resolution -- alpha = 1 -- the 16 x 16-channel kernel of imk_conv.hip is faster: 2.64 vs 2.69 ms).
+// IMK_WGRAD_GEMM_MIN overrides the channel threshold for every size.
+bool imk_wgrad_gemm_wide(int cs_in, int cs_out, long long pixels) {
+    static const int v = []() { const char *e = getenv("IMK_WGRAD_GEMM_MIN"); return e ? atoi(e) : 0; }();
+    const int c = cs_in > cs_out ? cs_in : cs_out;
+    if (v > 0) return c >= v;
+    return c > 32 || (c == 32 && pixels >= (2ll << 20));
+}
+bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out, long long pixels) {
     if (!wgemm_env_on()) return false;
-    if (cs_in <= 32 && cs_out <= 32) return false;
+    if (!imk_wgrad_gemm_wide(cs_in, cs_out, pixels)) return false;
+    // Few 16 x 16 channel pairs AND few pixels (the deep levels at alpha = 0.5): the per-pair kernel of imk_conv.hip already
+    // spreads such a layer over 768 workgroups with little re-reading, and this one would run on 16-64 (ISIC step 1.014 vs 1.050 ms);
+    // with many pairs (alpha >= 1: 64-512 pairs at the same pixel counts) it re-reads both operands per pair and this kernel wins
+    static const int min_pairs = []() { const char *e = getenv("IMK_WGRAD_GEMM_PAIRS"); return e ? atoi(e) : 17; }();
+    static const long long min_pix = []() { const char *e = getenv("IMK_WGRAD_GEMM_PIX"); return e ? atoll(e) : 100000; }();
+    if (((cs_in + 15) / 16) * ((cs_out + 15) / 16) < min_pairs && pixels < min_pix) return false;
     return wgrad_gemm_combo(lmode, bnb, ksize);
 }
 
@@ -654,7 +674,7 @@ int imk_launch_wgrad_gemm(const ImkWgradArgs &a, hipStream_t stream) {
     }
     const int T = a.ksize == 3 ? 9 : 1;
     const double bytes = in_b + px * a.cs_out * 2 * (bnb ? 2 : 1) + (double)a.n_split * P.gm.cit_n * P.gm.cot_n * (T + 1) * 1024;
-    ImkProfScope prof(PF_WGRAD_GEMM, bytes, stream);
+    ImkProfScope prof(PF_WGRAD_GEMM, bytes, stream, imk_wgrad_flops(a));
     int rc = IMK_EUNSUPPORTED;
     if (a.ksize == 3 && !bnb) {
         if (a.x.lmode == LM_POOL) rc = launch_wgrad_gemm_k<LM_POOL, false, true>(a, P, stream);

@@ -73,6 +73,15 @@ struct ImkConvArgs {
     // statistics): x = fp16(dystat_z * wg_sc + wg_sh), the BatchNorm being applied to the transposed LDS reads
     const float *wg_sc, *wg_sh;
 };
+// multiply-adds x 2 of a conv launch (logical channel counts; + the chained 1x1, + the first-stage 1x1)
+inline double imk_conv_flops(const ImkConvArgs &a) {
+    const double px = (double)a.B * a.H * a.W;
+    const int cin_main = a.pre_wpk ? a.pre_cout : a.x.cin;
+    double f = 2.0 * px * (a.ksize == 3 ? 9 : 1) * cin_main * a.cout;
+    if (a.wpk2) f += 2.0 * px * a.cout * a.cout2;
+    if (a.pre_wpk) f += 2.0 * px * a.x.cin * a.pre_cout;
+    return f;
+}
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
 // GEMM-class kernel for the wide layers (imk_gemm.hip): which launches it takes, its launcher, its statistics rows
 bool imk_conv_gemm_ok(const ImkConvArgs &a);
@@ -109,9 +118,13 @@ struct ImkWgradArgs {
     float *partial;        // [n_split][n_pairs][taps+1][256] fp32 scratch
     int n_split;
 };
+inline double imk_wgrad_flops(const ImkWgradArgs &a) {   // 2 * pixels * taps * cin * cout (logical channels), as the forward conv
+    return 2.0 * a.B * a.H * a.W * (a.ksize == 3 ? 9 : 1) * (double)a.x.cin * a.cout;
+}
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout);
 // GEMM-class weight-gradient kernel of the wide layers (imk_gemm.hip).  bnb: the gradient operand is a BatchNorm backward on load
-bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out);
+bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out, long long pixels);
+bool imk_wgrad_gemm_wide(int cs_in, int cs_out, long long pixels);   // the size rule alone (workspace sizing)
 int imk_wgrad_gemm_splits(int lmode, int B, int H, int W, int ksize, int cs_in, int cs_out);   // = ImkWgradArgs::n_split of such a launch
 int imk_launch_wgrad_gemm(const ImkWgradArgs &a, hipStream_t stream);
 size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cout);

@@ -360,7 +360,7 @@ struct Bwd {
         a.B = c.B; a.H = d.h; a.W = d.w; a.ksize = l.ksize; a.cout = l.cout; a.cs_out = imk_pad8(l.cout);
         a.partial = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
         a.n_split = imk_wgrad_splits(c.B, d.h, d.w, l.cin, l.cout);
-        if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, l.ksize, a.x.cs_in, a.cs_out)) {   // wide layers: the GEMM-class kernel
+        if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, l.ksize, a.x.cs_in, a.cs_out, (long long)c.B * d.h * d.w)) {   // wide layers: the GEMM-class kernel
             a.n_split = imk_wgrad_gemm_splits(a.x.lmode, c.B, d.h, d.w, l.ksize, a.x.cs_in, a.cs_out);
             return;
         }
