@@ -29,6 +29,13 @@ int imk_loss_blocks(long long n_pix);
 int imk_launch_head_loss(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                          int K, int softmax, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats,
                          f16 *dlogit, float *loss_partial, hipStream_t stream);
+// softmax heads, training: head + loss + gradient of the last BatchNorm's output (+ its statistics) + the output layer's
+// weight / bias gradient partials in ONE pass (imk_headf.hip); rows = workgroups = rows of every partial buffer it writes
+bool imk_head_cce_fused_ok(int cs, int K, long long n_pix, int rows_cap);
+int imk_head_cce_fused_rows(long long n_pix);
+int imk_launch_head_cce_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                              int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
+                              float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream);
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, float *stats, hipStream_t stream);
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,

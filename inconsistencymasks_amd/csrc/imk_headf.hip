@@ -1,0 +1,317 @@
+// Training step of a SOFTMAX output layer in one pass (multi-class heads: SUIM 9 outputs, Cityscapes 35): what
+// head_loss_kernel (imk_elem.hip) + the head's dgrad launch + its weight-gradient launch did in three -- the fp32
+// 1x1 conv on the last BatchNorm's output (unet.py:63, dtype float32), softmax, categorical cross-entropy
+// (functions.py:303: CategoricalCrossentropy on the softmax activation's logits), d(loss * scale)/d(logits), the
+// gradient w.r.t. that BatchNorm's output with its BatchNorm-backward statistics, and the output layer's weight / bias
+// gradient partials -- reading the last activation ONCE and never storing the [pixels, K] logit gradient.
+// At 35 classes the three launches were 15 % of a Cityscapes training step (fp32 dot products on the vector units, the
+// logit gradient written once and read twice: 80 bytes per pixel each way).
+//
+// All products run on the matrix cores, laid out so that no value changes lanes between the stages:
+//   logits^T [class][pixel] = W^T . x^T + b     v_mfma_f32_16x16x4_f32 (exact fp32 fma chains, as the reference's fp32 head):
+//       A = W^T (rows = classes of a 16-class tile), B = x^T: lane (pixel p = lane & 15, g = lane >> 4) supplies the channels
+//       16 ct + 4 g + r it loaded itself (two 8-byte loads per pixel at 32 channels) and receives the classes 16 kt + 4 g + r
+//       of ITS pixel: softmax max / sum = registers + two shuffles over the 4 lanes of a pixel;
+//   dy^T [channel][pixel] = W . dlogit^T        v_mfma_f32_16x16x32_f16: the contraction runs over the classes = the ROW index
+//       of the logits tile, so the fp16 logit gradients are the B operand as they stand (k-slot (g, j) <-> class
+//       16 (2 s + (j >> 2)) + 4 g + (j & 3); the A fragments of W are built in that order), and the result lands on the
+//       channels 16 ct + 4 g + r of the lane's pixel: exactly the z values it holds for the BatchNorm-backward statistics;
+//   dW [channel][class] = x^T . dlogit          contraction over pixels (lanes): x and dlogit go through a wave-private LDS
+//       image [tile][pixel][16] and come back with transposed reads (the weight-gradient kernels' pattern).
+// Fixed reduction orders everywhere (per-wave accumulators -> per-workgroup partial rows): bit-reproducible.
+#include "imk_stage.h"
+
+namespace {
+
+struct HeadCceArgs {
+    const f16 *z;                 // [n_pix][CS] last decoder activation (pre-BatchNorm)
+    const float *sc, *sh;         // its BatchNorm scale / shift (batch statistics) [CS]
+    const float *w, *bias;        // output layer: kernel [cin][K] fp32, bias [K]
+    int cin, K;
+    long long n_pix;
+    const uint8_t *y;             // class ids [n_pix]
+    const ImkCtl *ctl;
+    float *stats;
+    f16 *dy;                      // [n_pix][CS] gradient w.r.t. the BatchNorm output
+    float *loss_partial;          // [grid]
+    float *dystat_partial;        // [grid][2 * CS]: sum dy, sum dy * z per channel
+    float *wg_partial;            // [grid][NCT * cot_n][2][256]: weight-gradient partials in wgf_stage1's layout
+    int cot_n;                    // 16-class tiles of the weight-gradient layout = ceil(pad8(K) / 16)
+};
+
+template <int CS, int KT>
+__global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
+    constexpr int NCT = CS / 16;                 // 16-channel tiles
+    constexpr int NS = (KT + 1) / 2;             // 32-class k-steps of the dgrad
+    constexpr int KT2 = 2 * NS;                  // class tiles incl. the zero tile that completes the last k-step
+    constexpr int H16 = WG_STRIDE_H;
+    // wave-private LDS image of 64 pixels: x slices [NCT][64][16] and dlogit slices [KT][64][16] (fp16); reused at the end
+    constexpr int IMG_H = (NCT + KT) * 64 * H16;                     // halfs per wave
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, p16 = lane & 15, g = lane >> 4, qq = p16 >> 2, pp = p16 & 3;
+    f16 *s_x = reinterpret_cast<f16 *>(smem) + wave * IMG_H;
+    f16 *s_g = s_x + NCT * 64 * H16;
+    const int K = a.K, cin = a.cin;
+    const float S = a.ctl->loss_scale;
+    if (blockIdx.x == 0 && t == 0) { a.stats[1] = 0.f; a.stats[2] = S; a.stats[3] = (float)a.ctl->step; }   // as head_loss_kernel
+    const float gs = S / (float)a.n_pix;
+
+    // ---- operands that live in registers for the whole kernel ----------------------------------------------------------
+    // logits: A[class row p16][k-slot g] of k-step (ct, r) = W[c = 16 ct + 4 g + r][16 kt + p16]
+    float wa[KT][NCT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * g + r, k = 16 * kt + p16;
+                wa[kt][ct][r] = (c < cin && k < K) ? a.w[(size_t)c * K + k] : 0.f;
+            }
+    // dgrad: A[channel row p16][k-slot (g, j)] of k-step s = fp16(W[16 ct + p16][class 16 (2 s + (j >> 2)) + 4 g + (j & 3)])
+    f16x8 wd[NCT][NS];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * ct + p16, k = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);
+                wd[ct][s][j] = (f16)((c < cin && k < K) ? a.w[(size_t)c * K + k] : 0.f);
+            }
+    float bias_r[KT][4], sc_r[NCT][4], sh_r[NCT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; bias_r[kt][r] = k < K ? a.bias[k] : 0.f; }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int c = 16 * ct + 4 * g + r; sc_r[ct][r] = a.sc[c]; sh_r[ct][r] = a.sh[c]; }
+
+    f32x4 accw[NCT][KT], accb = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) accw[ct][kt] = f32x4{0, 0, 0, 0};
+    float s1[NCT][4], s2[NCT][4], loss = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ct][r] = s2[ct][r] = 0.f;
+
+    // ---- 64 pixels (4 units of 16) per wave and iteration ----------------------------------------------------------------
+    const long long n_grp = (a.n_pix + 63) / 64;
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_grp; grp += (long long)gridDim.x * 4) {
+        f16x4 zr[4][NCT];
+        int yv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // all loads of the group first
+            const long long px = grp * 64 + u * 16 + p16;
+            ok[u] = px < a.n_pix;
+            const long long pc = ok[u] ? px : a.n_pix - 1;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) zr[u][ct] = *reinterpret_cast<const f16x4 *>(a.z + pc * CS + 16 * ct + 4 * g);
+            yv[u] = a.y[pc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // x = fp16(z * sc + sh): the head's input, as head_kernel / head_loss_kernel form it
+            f16x4 xh[NCT];
+            float xf[NCT][4];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xh[ct][r] = (f16)((float)zr[u][ct][r] * sc_r[ct][r] + sh_r[ct][r]);
+                    xf[ct][r] = (float)xh[ct][r];
+                }
+            // logits of the lane's pixel: classes 16 kt + 4 g + r
+            f32x4 lg[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                lg[kt] = f32x4{bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lg[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kt][ct][r], xf[ct][r], lg[kt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * kt + 4 * g + r >= K) lg[kt][r] = -INFINITY;     // padding classes
+                    mx = fmaxf(mx, lg[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lg[kt][r] = expf(lg[kt][r] - mx); sum += lg[kt][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            f16x4 gh[KT2];
+#pragma unroll
+            for (int kt = 0; kt < KT2; ++kt) gh[kt] = f16x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kt + 4 * g + r;
+                    const float pk = lg[kt][r] * inv;
+                    const bool hit = k == yv[u];
+                    if (hit && ok[u]) loss += -logf(fmaxf(pk, 1.17549435e-38f));
+                    gh[kt][r] = (k < K && ok[u]) ? (f16)(gs * (pk - (hit ? 1.0f : 0.0f))) : (f16)0.f;
+                }
+            // dy^T = W . dlogit^T (fp16 operands, fp32 accumulation), rounded to fp16 like the dgrad launch it replaces
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x4 d = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    f16x8 bf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { bf[j] = gh[2 * s][j]; bf[4 + j] = gh[2 * s + 1][j]; }
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[ct][s], bf, d, 0, 0, 0);
+                }
+                f16x4 dh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dh[r] = (f16)d[r];
+                    const float f = ok[u] ? (float)dh[r] : 0.f;
+                    s1[ct][r] += f;
+                    s2[ct][r] += f * (float)zr[u][ct][r];
+                }
+                if (ok[u]) *reinterpret_cast<f16x4 *>(a.dy + (grp * 64 + u * 16 + p16) * CS + 16 * ct + 4 * g) = dh;
+            }
+            // LDS image for the weight gradient: pixel u * 16 + p16, this lane's 4 channels / 4 classes of every tile
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f16x4 xs = xh[ct];
+                if (!ok[u]) xs = f16x4{0, 0, 0, 0};
+                *reinterpret_cast<f16x4 *>(s_x + (ct * 64 + u * 16 + p16) * H16 + 4 * g) = xs;
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f16x4 *>(s_g + (kt * 64 + u * 16 + p16) * H16 + 4 * g) = gh[kt];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // dW[channel][class] += x^T . dlogit over the 64 pixels: two k-steps of 32 (units 2 kk, 2 kk + 1); k-slot <-> pixel map
+        // of wgrad_mfma_kernel (a 32-lane half reads 8 consecutive pixels of one unit = one 256-byte bank row)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int row = 2 * kk + (g >> 1), xx = 4 * (g & 1) + qq;
+            f16x8 af[NCT], bf[KT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f16 *pa = s_x + (ct * 64 + row * 16 + xx) * H16 + 4 * pp;
+                const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa));
+                const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa + 8 * H16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af[ct][e] = (f16)a0[e]; af[ct][4 + e] = (f16)a1[e]; }
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const f16 *pb = s_g + (kt * 64 + row * 16 + xx) * H16 + 4 * pp;
+                const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
+                const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 8 * H16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bf[kt][e] = (f16)b0[e]; bf[kt][4 + e] = (f16)b1[e]; }
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) accw[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ct], bf[kt], accw[ct][kt], 0, 0, 0);
+                f16x8 e;                              // column sums -> bias gradient: A = ones in row kt
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (f16)(p16 == kt ? 1.0f : 0.0f);
+                accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(e, bf[kt], accb, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- per-workgroup partials: loss, BatchNorm-backward statistics, weight gradient ------------------------------------
+    __syncthreads();                                  // the LDS images are free
+    float *s_red = reinterpret_cast<float *>(smem);   // [4 waves][(NCT * KT + 1) * 256] accumulators, then [4][2 * CS + 1]
+    constexpr int NA = NCT * KT + 1;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * NA) + ct * KT + kt) * 256 + r * 64 + lane] = accw[ct][kt][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[((wave * NA) + NCT * KT) * 256 + r * 64 + lane] = accb[r];
+    float *s_st = s_red + 4 * NA * 256;
+    loss = wave_sum<64>(loss);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v1 = wave_sum<16>(s1[ct][r]), v2 = wave_sum<16>(s2[ct][r]);
+            if (p16 == 0) {
+                s_st[wave * (2 * CS + 1) + 16 * ct + 4 * g + r] = v1;
+                s_st[wave * (2 * CS + 1) + CS + 16 * ct + 4 * g + r] = v2;
+            }
+        }
+    if (lane == 0) s_st[wave * (2 * CS + 1) + 2 * CS] = loss;
+    __syncthreads();
+    if (t < 2 * CS) a.dystat_partial[(size_t)blockIdx.x * 2 * CS + t] =
+        (s_st[t] + s_st[(2 * CS + 1) + t]) + (s_st[2 * (2 * CS + 1) + t] + s_st[3 * (2 * CS + 1) + t]);
+    if (t == 0) a.loss_partial[blockIdx.x] = (s_st[2 * CS] + s_st[(2 * CS + 1) + 2 * CS]) + (s_st[2 * (2 * CS + 1) + 2 * CS] + s_st[3 * (2 * CS + 1) + 2 * CS]);
+    // weight-gradient partial rows of this workgroup: [pair = ct * cot_n + kt][tap 0 | bias row][256]
+    float *wp = a.wg_partial + (size_t)blockIdx.x * NCT * a.cot_n * 2 * 256;
+    for (int i = t; i < NCT * a.cot_n * 2 * 256; i += 256) {
+        const int e = i & 255, blk = i >> 8, tap = blk & 1, pair = blk >> 1;
+        const int ct = pair / a.cot_n, kt = pair - ct * a.cot_n;
+        float v = 0.f;
+        if (kt < KT) {
+            if (tap == 0) {
+                const int idx = (ct * KT + kt) * 256 + e;
+                v = (s_red[idx] + s_red[NA * 256 + idx]) + (s_red[2 * NA * 256 + idx] + s_red[3 * NA * 256 + idx]);
+            } else if (ct == 0 && e < 16) {           // bias gradient of class 16 kt + e: row kt of accb = register kt of lanes 0-15
+                const int idx = NCT * KT * 256 + kt * 64 + e;
+                v = (s_red[idx] + s_red[NA * 256 + idx]) + (s_red[2 * NA * 256 + idx] + s_red[3 * NA * 256 + idx]);
+            }
+        }
+        wp[i] = v;
+    }
+}
+
+}  // namespace
+
+// Softmax heads with 16 or 32 (padded) input channels and up to 64 classes.  `rows_cap`: capacity (rows) of dystat_partial.
+bool imk_head_cce_fused_ok(int cs, int K, long long n_pix, int rows_cap) {
+    static const bool off = []() { const char *e = getenv("IMK_HEAD_FUSE"); return e && e[0] == '0'; }();
+    if (off || (cs != 16 && cs != 32) || K < 2 || K > 64) return false;
+    return imk_loss_blocks(n_pix) <= rows_cap;
+}
+
+int imk_head_cce_fused_rows(long long n_pix) { return imk_loss_blocks(n_pix); }
+
+int imk_launch_head_cce_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                              int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
+                              float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream) {
+    HeadCceArgs a{z, sc, sh, w, bias, cin, K, n_pix, y, ctl, stats, dy, loss_partial, dystat_partial, wg_partial,
+                  (imk_pad8(K) + 15) / 16};
+    const int kt = (K + 15) / 16, nct = cs / 16;
+    const int grid = imk_loss_blocks(n_pix);
+    const size_t img = (size_t)4 * (nct + kt) * 64 * WG_STRIDE_H * sizeof(f16);
+    const size_t red = ((size_t)4 * (nct * kt + 1) * 256 + 4 * (2 * cs + 1)) * sizeof(float);
+    const size_t lds = img > red ? img : red;
+    ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + 1 + cs * 2), stream, 6.0 * n_pix * cin * K);
+#define IMK_HF(CSV, KTV) head_cce_fused_kernel<CSV, KTV><<<grid, 256, lds, stream>>>(a)
+#define IMK_HF_KT(CSV) do { if (kt == 1) IMK_HF(CSV, 1); else if (kt == 2) IMK_HF(CSV, 2); else if (kt == 3) IMK_HF(CSV, 3); else IMK_HF(CSV, 4); } while (0)
+    if (cs == 16) IMK_HF_KT(16); else if (cs == 32) IMK_HF_KT(32); else return IMK_EUNSUPPORTED;
+#undef IMK_HF_KT
+#undef IMK_HF
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}

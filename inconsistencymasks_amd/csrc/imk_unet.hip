@@ -375,12 +375,16 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     // head + loss + d(loss*scale)/d(logits) in one pass over the last activation
     f16 *dlogit = reinterpret_cast<f16 *>(c.base + c.ws.dlogit);
     float *loss_partial = reinterpret_cast<float *>(c.base + c.ws.loss_partial);
-    {
-        const ImkLayer &o = plan->layers[t.out];
-        const int bn = t.d_bnb[3];
-        OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(bn), c.bn_shift(bn), params + o.off_w, params + o.off_b, o.cin,
-                                imk_pad8(o.cin), o.cout, cf.act_out, n_pix, y, sv.ctl, stats, dlogit, loss_partial, stream));
-    }
+    const ImkLayer &ol = plan->layers[t.out];
+    const int obn = t.d_bnb[3];
+    // softmax heads: the loss, the gradient of the last BatchNorm's output (with its statistics) and the output layer's weight
+    // gradient come out of ONE kernel that reads the last activation once (imk_headf.hip); sigmoid heads: head_loss_kernel,
+    // then the output layer's dgrad (+ fused weight gradient where the pipelined kernel covers the shape)
+    const bool head_one_pass = cf.act_out == 1 &&
+                               imk_head_cce_fused_ok(imk_pad8(ol.cin), ol.cout, n_pix, c.ws.L[obn].n_bwd_rows);
+    if (!head_one_pass)
+        OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b, ol.cin,
+                                imk_pad8(ol.cin), ol.cout, cf.act_out, n_pix, y, sv.ctl, stats, dlogit, loss_partial, stream));
 
     ensure_side_streams(plan);
     // The weight-gradient kernels run on a side stream, forked after the kernel that produced their gradient operand and
@@ -391,45 +395,47 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
     Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !g_imk_single_stream) ? n_side_env : 0, side_px};
-    // head: its "dA" is dlogit.  Its dgrad (dlogit -> dy of the last BatchNorm, with that BN's gradient statistics) reads
-    // exactly the operands of its weight gradient (dlogit, and z = the last decoder activation, whose BatchNorm output is
-    // the head's input): where the pipelined kernel covers the shape, one launch produces both.
-    ImkConvArgs ha{};
-    {
-        const ImkLayer &l = plan->layers[t.out];
-        const int bn = t.d_bnb[3];
-        ha.x.in = dlogit; ha.x.lmode = LM_RAW; ha.x.cin = l.cout; ha.x.cs_in = imk_pad8(l.cout);
-        ha.B = batch; ha.H = cf.h; ha.W = cf.w; ha.ksize = 1; ha.cout = l.cin; ha.cs_out = imk_pad8(l.cin);
-        ha.wpk = c.wbwd(t.out); ha.out = c.dy(bn); ha.epi = EP_PLAIN;
-        ha.dystat_z = c.act(t.d_c1[3]);
-        ha.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[bn].bwd_partial);
-    }
-    const bool head_fused = imk_conv_can_fuse_wgrad(ha);
-    if (!head_fused) OK(b.wgrad(t.out, dlogit));
-    // the loss value only needs head_loss_kernel's partials: its reduction rides on the side stream, behind the head's
-    // weight gradient, instead of sitting at the end of the step
     bool loss_done = false;
-    auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than head_loss_kernel)
+    auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than the head's kernel)
         if (loss_done || b.n_side <= 0 || b.n_fork <= 0) return IMK_OK;
         loss_done = true;
         return imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, plan->side[(b.n_fork - 1) % b.n_side]);
     };
-    OK(loss_on_side());
-    {
-        const ImkLayer &l = plan->layers[t.out];
-        const int bn = t.d_bnb[3];
+    if (head_one_pass) {
+        const int rows = imk_head_cce_fused_rows(n_pix);
+        float *wgp = reinterpret_cast<float *>(c.base + c.ws.L[t.out].wg_partial);
+        OK(imk_launch_head_cce_fused(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b,
+                                     ol.cin, imk_pad8(ol.cin), ol.cout, n_pix, y, sv.ctl, stats, c.dy(obn), loss_partial,
+                                     reinterpret_cast<float *>(c.base + c.ws.L[obn].bwd_partial), wgp, stream));
+        b.dy_rows[obn] = rows;
+        OK(imk_wgf_add_job(b.jobs, wgp, rows, ol.ksize, ol.cin, ol.cout, grads + ol.off_w, grads + ol.off_b));
+    } else {
+        // head: its "dA" is dlogit.  Its dgrad (dlogit -> dy of the last BatchNorm, with that BN's gradient statistics) reads
+        // exactly the operands of its weight gradient (dlogit, and z = the last decoder activation, whose BatchNorm output is
+        // the head's input): where the pipelined kernel covers the shape, one launch produces both.
+        ImkConvArgs ha{};
+        ha.x.in = dlogit; ha.x.lmode = LM_RAW; ha.x.cin = ol.cout; ha.x.cs_in = imk_pad8(ol.cout);
+        ha.B = batch; ha.H = cf.h; ha.W = cf.w; ha.ksize = 1; ha.cout = ol.cin; ha.cs_out = imk_pad8(ol.cin);
+        ha.wpk = c.wbwd(t.out); ha.out = c.dy(obn); ha.epi = EP_PLAIN;
+        ha.dystat_z = c.act(t.d_c1[3]);
+        ha.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[obn].bwd_partial);
+        const bool head_fused = imk_conv_can_fuse_wgrad(ha);
+        if (!head_fused) OK(b.wgrad(t.out, dlogit));
+        // the loss value only needs head_loss_kernel's partials: its reduction rides on the side stream, behind the head's
+        // weight gradient, instead of sitting at the end of the step
+        OK(loss_on_side());
         int rows = 0;
         ha.stats_rows = &rows;
         if (head_fused) {
             ha.wg_partial = reinterpret_cast<float *>(c.base + c.ws.L[t.out].wg_partial);
-            ha.wg_sc = c.bn_scale(bn); ha.wg_sh = c.bn_shift(bn);
+            ha.wg_sc = c.bn_scale(obn); ha.wg_sh = c.bn_shift(obn);
         }
         OK(imk_launch_conv(ha, stream));
-        if (rows <= 0 || rows > c.ws.L[bn].n_bwd_rows) return IMK_EWORKSPACE;
-        b.dy_rows[bn] = rows;
+        if (rows <= 0 || rows > c.ws.L[obn].n_bwd_rows) return IMK_EWORKSPACE;
+        b.dy_rows[obn] = rows;
         if (head_fused) {
             if (rows > imk_conv_fused_wgrad_rows_max()) return IMK_EWORKSPACE;
-            OK(imk_wgf_add_job(b.jobs, ha.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b));
+            OK(imk_wgf_add_job(b.jobs, ha.wg_partial, rows, ol.ksize, ol.cin, ol.cout, grads + ol.off_w, grads + ol.off_b));
         }
     }
     // decoders 9..6
