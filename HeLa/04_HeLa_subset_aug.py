@@ -1,0 +1,12 @@
+"""HeLa augmented labelled-subset baseline (ALDT) on MI355X -- the generation-0 ensemble of the AIM+ driver: counterpart of the
+reference driver HeLa/04_HeLa_subset_aug.py (same loops and file / model / CSV names); the loop body lives in
+inconsistencymasks_amd/subset_driver.py."""
+import os
+import sys
+
+sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from inconsistencymasks_amd.subset_driver import run  # noqa: E402
+
+if __name__ == "__main__":
+    run("HeLa", aug=True)

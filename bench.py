@@ -378,6 +378,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        w = torch.zeros(1, device=dev)
+        dist.all_reduce(w)                     # communicator set up now (RCCL prints its version banner through C stdio here) ...
+        torch.cuda.synchronize()
+        import ctypes as _ct
+        _ct.CDLL(None).fflush(None)            # ... and flushed now, so that the JSON line below stays the LAST line of stdout
     n_gpus = dist.get_world_size() if use_dist else 1
     strong = args.scaling == "strong"
 
@@ -508,12 +513,19 @@ def main():
             ty = (ty * pos_w if K == 3 else ty).contiguous()
         else:
             ty = pool_y[src][:, 0].contiguous()
+        # host cost of enqueueing a step (fwd_bwd + all-reduce + adamw): timed over the epoch's first steps, while the GPU is
+        # still busy with the inference stage / the gathers above and the launch queue is far from full (later in the epoch
+        # the host runs ahead until the queue back-pressures it, which would time the GPU, not the host)
+        n_host = min(steps, 8)
         t_host = time.perf_counter()
         for s in range(steps):
+            if s == n_host:
+                host_enqueue.append((time.perf_counter() - t_host) / n_host)
             student.fwd_bwd(tx[s * BATCH:(s + 1) * BATCH], ty[s * BATCH:(s + 1) * BATCH], LOSS)
             scale = F._grad_allreduce(student)
             student.adamw_step(LR, WD, grad_scale=scale)
-        host_enqueue.append((time.perf_counter() - t_host) / max(steps, 1))
+        if steps and steps == n_host:
+            host_enqueue.append((time.perf_counter() - t_host) / n_host)
         e2.record()
         if record is not None:
             record.append((e0, e1, e2))
@@ -624,7 +636,7 @@ def main():
                  "conv_flops_per_image_forward": fwd_flops, "min_bytes_per_image_forward": fwd_min_bytes,
                  "note": "SURVEY 8d minimum HBM bytes (every tensor that crosses a block boundary written and read once; 3x per "
                          "training image) and conv FLOPs (3x forward per training image) over the measured stage time, per rank; "
-                         "host_enqueue = wall time the host needs to enqueue one step (fwd_bwd + all-reduce + adamw), it runs ahead of the GPU"}
+                         "host_enqueue = wall time the host needs to enqueue one step (fwd_bwd + all-reduce + adamw; first 8 steps of an epoch, before the launch queue can back-pressure): below the GPU step time the host is not the limiter"}
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": FAMILIES[v], "achieved": round(achieved, 1), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -701,7 +713,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, U_total, L_total, fwd_flops)
             out["cpu_baseline"]["parity_sample"] = parity_sample(cfg, models, x_unl)
             out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,8 +61,7 @@ def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_p
     mask, IoU of the blocked mask against the ground truth (rounded to 4 decimals) as the label; half of the samples are
     written augmented (geometry on image and mask, photometry on the image).  `{stem}_aug_{loop}.png`, labels.csv."""
     F = _F()
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False is not used by any reference script")
+    flip = (not rgb) and c == 3      # rgb=False (functions.py:3611 ff.): the nets see the file's channels in OpenCV's order (BGR)
     rng = random.Random(F.SEED if seed is None else seed)
     np_rng = np.random.default_rng(rng.getrandbits(32))
     iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
@@ -83,7 +82,7 @@ def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_p
                     idx = idx_all[s:s + F.INFER_BATCH]
                     x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
                     gt = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1), idx)), 0)).cuda()
-                    r = ensembles[subset].run(x, F.THRESHOLD, False, False, False)
+                    r = ensembles[subset].run(x.flip(-1).contiguous() if flip else x, F.THRESHOLD, False, False, False)
                     im = _random_morph(r["im"], plan, idx)
                     masks, img = r["masks"], x.clone()
                     _im.block_apply(im, img, masks)
@@ -163,8 +162,7 @@ def create_training_data_evalnet_miou_im_multiclass(models, h, w, c, num_classes
     image + label map; labels = class-wise IoU of the blocked prediction against the ground truth and class-wise
     detection of the IM-blocked ground truth (threshold 0.3); half of the samples are written augmented."""
     F = _F()
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False is not used by any reference script")
+    flip = (not rgb) and c == 3      # rgb=False (functions.py:3611 ff.): the nets see the file's channels in OpenCV's order (BGR)
     rng = random.Random(F.SEED if seed is None else seed)
     np_rng = np.random.default_rng(rng.getrandbits(32))
     iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
@@ -185,7 +183,7 @@ def create_training_data_evalnet_miou_im_multiclass(models, h, w, c, num_classes
                     idx = idx_all[s:s + F.INFER_BATCH]
                     x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
                     gts = list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1)[..., 0], idx))
-                    r = ensembles[subset].run(x, F.THRESHOLD, False, False, False)
+                    r = ensembles[subset].run(x.flip(-1).contiguous() if flip else x, F.THRESHOLD, False, False, False)
                     im = _random_morph(r["im"], plan, idx)
                     masks, img = r["masks"], x.clone()
                     _im.block_apply(im, img, masks)
@@ -540,8 +538,7 @@ def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w,
     """functions.py:5684-5757: 1..5 augmented copies `{stem}___{j}.png` of every pseudo-labelled pair, the number growing
     with the IoU the EvalNet ensemble predicts for (image, mask)."""
     F = _F()
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False is not used by any reference script")
+    flip = (not rgb) and c == 3      # rgb=False (functions.py:3611 ff.): the nets see the file's channels in OpenCV's order (BGR)
     iin, min_ = os.path.join(main_input_path, "images"), os.path.join(main_input_path, "masks")
     iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
     os.makedirs(iout, exist_ok=True)
@@ -554,8 +551,52 @@ def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w,
             chunk = mine[s:s + F.INFER_BATCH]
             x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
             m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
-            mean_iou = torch.stack([e.predict_device(x, m) for e in evalnets], 0).double().mean(0)[:, 0].cpu().numpy()
+            xin = x.flip(-1).contiguous() if flip else x
+            mean_iou = torch.stack([e.predict_device(xin, m) for e in evalnets], 0).double().mean(0)[:, 0].cpu().numpy()
             n_augs = torch.tensor([num_augs_from_miou(v, min_threshold, max_threshold) for v in mean_iou], device="cuda")
+            jobs = []
+            for j in range(5):
+                sel = torch.nonzero(n_augs > j).flatten()
+                if not sel.numel():
+                    break
+                o, om = augment_batch(x[sel].contiguous(), m[sel].contiguous(), draw_params(int(sel.numel()), **draw_kw))
+                o, om = o.cpu().numpy(), om.cpu().numpy()
+                for row, i in enumerate(sel.tolist()):
+                    name = f"{chunk[i][:-4]}___{j}.png"
+                    jobs.append((os.path.join(iout, name), o[row]))
+                    jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
+            list(pool.map(lambda a: F.write_png(*a), jobs))
+    if F._dist():
+        F._dist().barrier()
+
+
+def create_augment_images_and_masks_with_gt(main_gt_input_path, min_threshold, max_threshold, main_input_path, main_output_path,
+                                            brightness_range_alpha=(0.6, 1.4), brightness_range_beta=(-20, 20), max_blur=3,
+                                            max_noise=20, free_rotation=False, rgb=True):
+    """functions.py:6057-6121 (SUIM/16_SUIM_GT_IM++.py: a "perfect EvalNet"): the number of augmented copies `{stem}___{j}.png`
+    of a pseudo-labelled pair follows the IoU (get_IoU_multi_unique) of its pseudo-label against the ground-truth mask with the
+    IM pixels blanked.  `rgb` only chooses the channel order the reference hands to nobody here (the augmented image is made
+    from the file's own order): accepted, no effect."""
+    F = _F()
+    iin, min_, imin = (os.path.join(main_input_path, k) for k in ("images", "masks", "im"))
+    iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
+    os.makedirs(iout, exist_ok=True)
+    os.makedirs(mout, exist_ok=True)
+    mine = F.shard_list(os.listdir(iin))
+    draw_kw = dict(brightness_range_alpha=brightness_range_alpha, brightness_range_beta=brightness_range_beta,
+                   max_blur=max_blur, max_noise=max_noise, free_rotation=free_rotation)
+    with F._pool() as pool:
+        for s in range(0, len(mine), F.INFER_BATCH):
+            chunk = mine[s:s + F.INFER_BATCH]
+            rd = lambda d, ch: np.stack(list(pool.map(lambda n: F.read_png(os.path.join(d, n), ch), chunk)), 0)
+            x_np, m_np, im_np, gt_np = rd(iin, 3), rd(min_, 1), rd(imin, 1), rd(main_gt_input_path, 1)
+            n_augs = []
+            for i in range(len(chunk)):
+                gt = gt_np[i, :, :, 0].copy()
+                gt[im_np[i, :, :, 0] > 0] = 0                                  # :6102
+                n_augs.append(num_augs_from_miou(F.get_IoU_multi_unique(m_np[i, :, :, 0], gt), min_threshold, max_threshold))
+            x, m = torch.from_numpy(x_np).cuda(), torch.from_numpy(m_np).cuda()
+            n_augs = torch.tensor(n_augs, device="cuda")
             jobs = []
             for j in range(5):
                 sel = torch.nonzero(n_augs > j).flatten()
@@ -580,8 +621,7 @@ def create_augment_images_and_masks_with_evalnet_ensemble_multiclass(evalnets, h
     """functions.py:5946-6035: the number of augmented copies follows the mean predicted IoU over the classes > 0 whose
     mean detection score is at least 0.5."""
     F = _F()
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False is not used by any reference script")
+    flip = (not rgb) and c == 3      # rgb=False (functions.py:3611 ff.): the nets see the file's channels in OpenCV's order (BGR)
     iin, min_ = os.path.join(main_input_path, "images"), os.path.join(main_input_path, "masks")
     iout, mout = os.path.join(main_output_path, "images"), os.path.join(main_output_path, "masks")
     os.makedirs(iout, exist_ok=True)
@@ -594,7 +634,8 @@ def create_augment_images_and_masks_with_evalnet_ensemble_multiclass(evalnets, h
             chunk = mine[s:s + F.INFER_BATCH]
             x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
             m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
-            outs = torch.stack([e.predict_device(x, m) for e in evalnets], 0).double().mean(0).cpu().numpy()
+            xin = x.flip(-1).contiguous() if flip else x
+            outs = torch.stack([e.predict_device(xin, m) for e in evalnets], 0).double().mean(0).cpu().numpy()
             n_augs = []
             for row in outs:
                 valid = [row[ci] for ci in range(1, num_classes) if row[num_classes + ci] >= 0.5]

@@ -325,8 +325,11 @@ def _all_reduce_sum(vals):
 
 
 def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dilate_kernel, block_input, block_output,
-                flag):
-    """Shared body of the ISIC and multiclass writers.  kind in {'isic', 'multi'}."""
+                flag, flip_channels=False):
+    """Shared body of the ISIC and multiclass writers.  kind in {'isic', 'multi'}.
+    flip_channels: rgb=False of the reference (functions.py:2847-2850) -- the nets see the channel order of the file as
+    OpenCV decodes it (BGR) instead of RGB; the written image keeps the file's order either way, so the flip is applied to
+    the nets' input and undone on the blocked image."""
     names = os.listdir(images_path)
     mine = shard_list(names)
     ens = _ensemble(models, kind == "isic")
@@ -337,6 +340,8 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
             chunk = mine[i:i + INFER_BATCH]
             imgs = list(pool.map(lambda n: read_png(os.path.join(images_path, n), c), chunk))
             x = torch.from_numpy(np.stack(imgs, 0)).cuda()
+            if flip_channels:
+                x = x.flip(-1).contiguous()
             r = ens.run(x, THRESHOLD, False, block_input and fused_block, block_output and fused_block,
                         want_presence=(kind == "multi" and flag))
             if fused_block:
@@ -344,6 +349,8 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
             else:
                 img_out, masks, im = _morph_then_block(r, erode_kernel, dilate_kernel, block_input, block_output, x,
                                                        dilate_masks=(kind == "multi"))
+            if flip_channels:
+                img_out = img_out.flip(-1)
             img_np, m_np, im_np = img_out.cpu().numpy(), masks.cpu().numpy(), im.cpu().numpy()
             ims = r["im_size"].sum(1).cpu().numpy()
             pss = r["pred_size"].sum(1).cpu().numpy()
@@ -374,10 +381,8 @@ def create_pseudo_labels_im_ISIC_2018(models, h, w, c, images_path, main_output_
     out = {k: os.path.join(main_output_path, k) for k in ("images", "masks", "im")}
     for d in out.values():
         os.makedirs(d, exist_ok=True)
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False (feeding BGR to the net) is not used by any reference script")
     return _run_writer(models, h, w, c, images_path, out, "isic", erode_kernel, dilate_kernel, block_input,
-                       block_output, filter_bad_predictions)
+                       block_output, filter_bad_predictions, flip_channels=(not rgb and c == 3))
 
 
 def create_pseudo_labels_im_multiclass(models, h, w, c, images_path, main_output_path, rgb=True, erode_kernel=5,
@@ -388,10 +393,8 @@ def create_pseudo_labels_im_multiclass(models, h, w, c, images_path, main_output
     out = {k: os.path.join(main_output_path, k) for k in ("images", "masks", "im")}
     for d in out.values():
         os.makedirs(d, exist_ok=True)
-    if not rgb and c == 3:
-        raise NotImplementedError("rgb=False is not used by any reference script")
     return _run_writer(models, h, w, c, images_path, out, "multi", erode_kernel, dilate_kernel, block_input,
-                       block_output, filter_unequal_class_pred)
+                       block_output, filter_unequal_class_pred, flip_channels=(not rgb and c == 3))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -749,6 +752,7 @@ def train_ISIC_2018(train_images_dir, val_images_dir, val_masks_dir, test_images
     mIoU_unl, dice_unl = benchmark_ISIC2018(best_model, unlabeled_images_dir, unlabeled_masks_dir, unlabeled_pred_dir,
                                             h, w, c, print_results=print_results)
     print(f"{modelname} mIoU_val: {mIoU_val}")
+    flush_writes()      # the benchmarks' prediction PNGs are on disk (a failed write raises here, not at interpreter exit)
     return mIoU_val, mIoU_test, mIoU_unl, dice_val, dice_test, dice_unl
 
 
@@ -878,6 +882,7 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
     mPA_unl, mIoU_unl = benchmark_multiclass(best_model, unlabeled_images_dir, unlabeled_masks_dir, unlabeled_pred_dir,
                                              h, w, c, class_to_color_mapping, print_results=print_results)
     print(f"{modelname} mIoU_val: {mIoU_val}")
+    flush_writes()
     return mPA_val, mPA_test, mPA_unl, mIoU_val, mIoU_test, mIoU_unl
 
 
@@ -1165,6 +1170,7 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
     for gt, pd in ((val_gt_dir, val_pred_dir), (test_gt_dir, test_pred_dir), (unlabeled_gt_dir, unlabeled_pred_dir)):
         res += list(benchmark_hela(best_model, gt, pd, h, w, c))
     print(f"{modelname} mIoU_val: {res[0]}   mean_cell_count_error_val: {res[2]}")
+    flush_writes()
     return tuple(res)
 
 
@@ -1176,6 +1182,7 @@ from .evalnet_functions import (compute_classwise_detection, compute_classwise_d
                                 compute_classwise_IoU, create_augment_images_and_masks_with_evalnet_ensemble_binary,
                                 create_augment_images_and_masks_with_evalnet_ensemble_hela,
                                 create_augment_images_and_masks_with_evalnet_ensemble_multiclass,
+                                create_augment_images_and_masks_with_gt,
                                 create_training_data_evalnet_im_binary, create_training_data_evalnet_miou_im_hela,
                                 create_training_data_evalnet_miou_im_multiclass, load_evalnet, num_augs_from_miou,
                                 save_evalnet, train_evalnet_ISIC_2018, train_evalnet_miou_model_hela,

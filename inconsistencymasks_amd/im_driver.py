@@ -6,7 +6,12 @@ Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES (
 approach="IM_plus" is the IM+ variant (ISIC_2018/11_ISIC_2018_IM+.py:40-135, SUIM/12_SUIM_IM+.py, HeLa/11_HeLa_IM+.py,
 Cityscapes/11_Cityscapes_IM+.py): the IM output goes to a `temp` directory, NUM_IMAGES_IM_PLUS augmented copies of each
 pseudo-labelled pair (no originals) form the training set, augmentation strength and the U-Net width alpha grow per
-generation (Noisy Student)."""
+generation (Noisy Student).
+
+approach="aug_IM_plus" is AIM+ (ISIC_2018/13_ISIC_2018_aug_IM+.py:44-116, HeLa/13_HeLa_aug_IM+.py, Cityscapes/13_Cityscapes_aug_IM+.py,
+SUIM/14_SUIM_aug_IM+.py): IM+ that starts from the augmented-subset baseline (`*_subset_aug_{runid}_topK_j.h5`,
+subset_driver.run(..., aug=True)), keeps the un-augmented IM pairs beside their augmented copies and adds the AUGMENTED
+labelled set (TRAIN_LABELED_AUG) instead of the plain one; the multi-class scripts honour FILTER_INCONSISTENT_CLASS_PRED."""
 import csv
 import os
 import shutil
@@ -116,10 +121,11 @@ def run(dataset, approach="IM"):
     else:
         BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
     filt = S.get("FILTER_INCONSISTENT_CLASS_PRED", "false").lower() == "true"
-    plus = IM_PLUS[dataset] if approach == "IM_plus" else None
+    aim = approach == "aug_IM_plus"
+    plus = IM_PLUS[dataset] if approach in ("IM_plus", "aug_IM_plus") else None
     if plus:    # the IM+ scripts parse the blocking flags properly for every dataset (ISIC_2018/11_...IM+.py:38-39)
         BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
-        filt = False
+        filt = filt if (aim and ds["kind"] == "multi") else False      # Cityscapes/13_Cityscapes_aug_IM+.py:42, 68-71
         free_rot = S.get("FREE_ROTATION", "false").lower() == "true"
         n_plus = int(S.get("NUM_IMAGES_IM_PLUS", 1))
     P = lambda name: getattr(paths, f"{dataset.upper() if dataset != 'Cityscapes' else 'CITYSCAPES'}_{name}")
@@ -137,7 +143,7 @@ def run(dataset, approach="IM"):
                 out = {k: os.path.join(base, f"{k}_predictions", approach, *(["temp"] if plus else []), modelname)
                        for k in ("val", "test", "train_unlabeled")}
                 if gen == 0:
-                    files = [os.path.join(model_dir, f"{tag}_subset_{runid}_topK_{j}.h5") for j in range(1, n + 1)]
+                    files = [os.path.join(model_dir, f"{tag}_subset{'_aug' if aim else ''}_{runid}_topK_{j}.h5") for j in range(1, n + 1)]
                 else:
                     files = [os.path.join(model_dir, f"{name_of(gen - 1)}_topK_{j}.h5") for j in range(1, n + 1)]
                 best_models = [F.load_model(f) for f in files]
@@ -170,15 +176,15 @@ def run(dataset, approach="IM"):
                         F.create_augment_images_and_masks_hela(src, unl, n_plus, False, free_rot, **kw)
                     alpha = plus["alphas"][gen]
                 if rank == 0:    # labelled pairs join the pseudo-labelled directory
-                    if ds["kind"] == "hela":
-                        for sub in ("brightfield", "alive", "dead", "mod_position"):
-                            src = os.path.join(P("TRAIN_LABELED_DIR"), sub)
-                            for name in os.listdir(src):
-                                shutil.copy(os.path.join(src, name), os.path.join(unl, sub, name))
-                    else:
-                        for name in os.listdir(P("TRAIN_LABELED_IMAGES_DIR")):
-                            shutil.copy(os.path.join(P("TRAIN_LABELED_IMAGES_DIR"), name), os.path.join(unl, "images", name))
-                            shutil.copy(os.path.join(P("TRAIN_LABELED_MASKS_DIR"), name), os.path.join(unl, "masks", name))
+                    subs = ("brightfield", "alive", "dead", "mod_position") if ds["kind"] == "hela" else ("images", "masks")
+                    if aim:      # AIM+: the un-augmented IM pairs too (ISIC_2018/13_ISIC_2018_aug_IM+.py:110-112)
+                        for name in os.listdir(os.path.join(out["train_unlabeled"], subs[0])):
+                            for sub in subs:
+                                shutil.copy(os.path.join(out["train_unlabeled"], sub, name), os.path.join(unl, sub, name))
+                    lab = P("TRAIN_LABELED_AUG_DIR" if aim else "TRAIN_LABELED_DIR")      # :114-116 / 11_...IM+.py:110-112
+                    for name in os.listdir(os.path.join(lab, subs[0])):
+                        for sub in subs:
+                            shutil.copy(os.path.join(lab, sub, name), os.path.join(unl, sub, name))
                 if torch.distributed.is_initialized():
                     torch.distributed.barrier()
                 train_dir = os.path.join(unl, "brightfield" if ds["kind"] == "hela" else "images")

@@ -4,7 +4,11 @@ SUIM/15_SUIM_aug_IBAs++.py, Cityscapes/12_Cityscapes_IM++.py, Cityscapes/14_City
 on IM predictions of the labelled set (5 candidates, top-K by mean absolute error), then per generation the IM
 pseudo-labels of the unlabeled set get 1..5 augmented copies each, weighted by the IoU the EvalNets predict, and 5 U-Net
 candidates of growing width are trained on them.  Same loops, schedules, model / directory / CSV names.
-Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES, IM_EVALNET_CANDIDATES (comma-separated)."""
+Environment overrides for short runs: IM_RUNIDS, IM_NS, IM_GENS, IM_CANDIDATES, IM_EVALNET_CANDIDATES (comma-separated).
+
+run(dataset, gt=True) is SUIM/16_SUIM_GT_IM++.py ("GT_IM_plus_plus": an upper bound for IM++): no EvalNet -- the number of
+augmented copies follows the pseudo-label's IoU against the ground truth of the unlabeled set
+(create_augment_images_and_masks_with_gt), and an epoch has at least as many steps as one over TRAIN_FULL (:126-132)."""
 import csv
 import os
 import shutil
@@ -30,7 +34,7 @@ SCHEDULE = {"HeLa": _HELA, "ISIC_2018": _ISIC,
                                brb=[(-3, 3), (-6, 6), (-9, 9), (-12, 12), (-15, 15)])}
 
 
-def run(dataset, aug=False, train_new_evalnet=True):
+def run(dataset, aug=False, train_new_evalnet=True, gt=False):
     kind = DATASETS[dataset]["kind"]            # isic | hela | multi
     hela, multi = kind == "hela", kind == "multi"
     tag = {"HeLa": "HELA", "ISIC_2018": "ISIC_2018", "SUIM": "SUIM", "Cityscapes": "CITYSCAPES"}[dataset]
@@ -45,7 +49,11 @@ def run(dataset, aug=False, train_new_evalnet=True):
     BI, BO = S["BLOCK_INPUT"].lower() == "true", S["BLOCK_OUTPUT"].lower() == "true"
     t_min, t_max = float(S["MIN_THRESHOLD"]), float(S["MAX_THRESHOLD"])
     free_rot = S["FREE_ROTATION"].lower() == "true"
-    approach = "aug_IM_plus_plus" if aug else "IM_plus_plus"
+    approach = "GT_IM_plus_plus" if gt else ("aug_IM_plus_plus" if aug else "IM_plus_plus")
+    if gt:
+        if not multi or aug:
+            raise ValueError("the ground-truth variant exists for the multi-class datasets only (SUIM/16_SUIM_GT_IM++.py)")
+        train_new_evalnet = False
     subset_tag = f"{tag}_subset_aug" if aug else f"{tag}_subset"
     evalnet_tag = f"{tag}_evalnet_{'miou_' if (hela or multi) else ''}{'aug_' if aug else ''}im"
     P = lambda name: getattr(paths, f"{tag}_{name}")
@@ -129,10 +137,13 @@ def run(dataset, aug=False, train_new_evalnet=True):
                     else:
                         means.append(F.create_pseudo_labels_im_ISIC_2018(best_models, H, W, C, P(f"{split}_IMAGES_DIR"), tmp[key],
                                                                          True, EK, DK, BI, BO))
-                best_evalnets = [F.load_evalnet(os.path.join(model_dir, f"{evalnet_tag}_{runid}_topK_{j}.h5")) for j in range(1, n + 1)]
+                best_evalnets = [] if gt else [F.load_evalnet(os.path.join(model_dir, f"{evalnet_tag}_{runid}_topK_{j}.h5"))
+                                               for j in range(1, n + 1)]
                 aug_args = (t_min, t_max, tmp["train_unlabeled"], unl, sch["bra"][gen], sch["brb"][gen], sch["max_blurs"][gen],
                             sch["max_noises"][gen], free_rot)
-                if hela:
+                if gt:      # SUIM/16_SUIM_GT_IM++.py:110-120
+                    F.create_augment_images_and_masks_with_gt(P("TRAIN_UNLABELED_MASKS_DIR"), *aug_args, True)
+                elif hela:
                     F.create_augment_images_and_masks_with_evalnet_ensemble_hela(best_evalnets, H, W, C, *aug_args)
                 elif multi:
                     F.create_augment_images_and_masks_with_evalnet_ensemble_multiclass(best_evalnets, H, W, C, K, *aug_args, True)
@@ -148,6 +159,8 @@ def run(dataset, aug=False, train_new_evalnet=True):
                 barrier()
                 train_dir = os.path.join(unl, subs[0])
                 steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+                if gt:      # :126-132: never fewer steps than an epoch over the full training set
+                    steps = max(steps, len(os.listdir(P("TRAIN_FULL_IMAGES_DIR"))) // batch // world)
                 rows = []
                 for i in _ints("IM_CANDIDATES", [0, 1, 2, 3, 4]):
                     name_i = f"{modelname}_{i}"

@@ -3,7 +3,12 @@ ISIC_2018/03_ISIC_2018_subset.py:41-104, HeLa/03_HeLa_subset.py:41-104, SUIM/04_
 Cityscapes/03_Cityscapes_subset.py (copies of one template).  Ten candidates per run id are trained on the labelled
 subset only, ranked (ISIC: mIoU_val; SUIM / Cityscapes: mIoU_val; HeLa: tuple index 6 ascending, as in the reference),
 and the best TOP_Ks are renamed `{TAG}_subset_{runid}_topK_{j}.h5` -- the files `im_driver.run` loads for gen 0.
-Environment overrides for short runs: IM_RUNIDS, IM_CANDIDATES (comma-separated)."""
+Environment overrides for short runs: IM_RUNIDS, IM_CANDIDATES (comma-separated).
+
+run(dataset, aug=True) is the augmented-subset baseline (ALDT: ISIC_2018/04_ISIC_2018_subset_aug.py:34-43, HeLa/04_HeLa_subset_aug.py,
+Cityscapes/04_Cityscapes_subset_aug.py, SUIM/05_SUIM_subset_aug.py): the labelled set is first augmented into
+TRAIN_LABELED_AUG with the functions' default arguments, the candidates train on that, names carry `subset_aug` -- the
+generation-0 ensemble of the AIM+ drivers (im_driver.run(..., approach="aug_IM_plus"))."""
 import csv
 import os
 
@@ -35,7 +40,7 @@ def train_candidate(ds, dataset, train_dir, name_i, h5, model, steps, H, W, C, K
                         P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
 
 
-def run(dataset):
+def run(dataset, aug=False):
     ds = DATASETS[dataset]
     S = F.config[ds["section"]]
     H, W, C = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"])
@@ -46,8 +51,18 @@ def run(dataset):
     F.init_distributed()
     rank, world = F._rank_world()
     tag = {"HeLa": "HELA", "Cityscapes": "CITYSCAPES"}.get(dataset, dataset)
-    approach = "subset"
-    train_dir = os.path.join(P("TRAIN_LABELED_DIR"), "brightfield") if ds["kind"] == "hela" else P("TRAIN_LABELED_IMAGES_DIR")
+    approach = "subset_aug" if aug else "subset"
+    if aug:     # default arguments, as the reference's scripts call them
+        if ds["kind"] == "isic":
+            F.create_augment_images_and_masks_ISIC_2018(P("TRAIN_LABELED_IMAGES_DIR"), P("TRAIN_LABELED_MASKS_DIR"), P("TRAIN_LABELED_AUG_MAIN_DIR"))
+        elif ds["kind"] == "multi":
+            F.create_augment_images_and_masks_multiclass(P("TRAIN_LABELED_IMAGES_DIR"), P("TRAIN_LABELED_MASKS_DIR"), P("TRAIN_LABELED_AUG_MAIN_DIR"))
+        else:
+            F.create_augment_images_and_masks_hela(P("TRAIN_LABELED_DIR"), P("TRAIN_LABELED_AUG_DIR"))
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+    lab = "TRAIN_LABELED_AUG" if aug else "TRAIN_LABELED"
+    train_dir = os.path.join(P(f"{lab}_DIR"), "brightfield") if ds["kind"] == "hela" else P(f"{lab}_IMAGES_DIR")
     steps = max(len(os.listdir(train_dir)) // batch // world, 1)
     os.makedirs(model_dir, exist_ok=True)
     idx, desc = _RANK[ds["kind"]]

@@ -95,6 +95,13 @@ class UNet:
             # torch.Generator() would start from the same constant seed every time and every "candidate" would be the
             # same model.  Draw the seed from torch's global stream, so torch.manual_seed() still makes a run repeatable.
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # Data parallel (one process per GPU): every rank must start from the SAME weights -- only gradients are
+            # all-reduced afterwards -- but each rank's global stream is its own.  Rank 0's draw wins.
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                box = [seed]
+                dist.broadcast_object_list(box, src=0)
+                seed = int(box[0])
         gen.manual_seed(int(seed))
         self.seed = int(seed)
         flat = torch.zeros(self.plan.n_total, dtype=torch.float32)

@@ -387,6 +387,11 @@ def test_keras_checkpoint_converter_mapping(built_lib, tmp_path):
     assert K.main(["--from-keras-npz", npz, dst, "--height", "64", "--width", "64", "--act-out", "sigmoid"]) == 0
     m2 = F.load_model(dst, device="cpu")
     assert torch.equal(m2.params, m.params) and (m2.plan.alpha, m2.plan.act_out) == (0.5, "sigmoid")
+    # the file a TensorFlow user writes with np.savez(path, *model.get_weights()): arrays named arr_0 ... arr_103 (numeric order)
+    npz2, dst2 = str(tmp_path / "arr.npz"), str(tmp_path / "c.h5")
+    np.savez(npz2, *[d[k] for k in sorted(d.files)])
+    assert K.main(["--from-keras-npz", npz2, dst2, "--height", "64", "--width", "64", "--act-out", "sigmoid"]) == 0
+    assert torch.equal(F.load_model(dst2, device="cpu").params, m.params)
 
 
 def test_background_png_writes_flush(built_lib, tmp_path):

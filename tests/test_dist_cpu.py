@@ -34,8 +34,13 @@ WORKER = textwrap.dedent("""
     F._sync_moving_stats(m)
     # fewer training files than ranks: every rank keeps the whole list
     few = F._train_shard(["only.png"])
+    # an UNSEEDED get_unet() (what the reference's scripts call): each rank's global RNG differs, the replicas must not
+    from inconsistencymasks_amd.unet import UNet
+    torch.manual_seed(100 + dist.get_rank())
+    u = UNet(32, 32, 3, 1, 0.5, "sigmoid", seed=None, device="cpu")
     print(json.dumps({"rank": dist.get_rank(), "n": len(mine), "mean": mean, "g": (m.grads * scale).tolist(),
-                      "stats": m.stats.tolist(), "whole": whole, "params": m.params.tolist(), "few": few}))
+                      "stats": m.stats.tolist(), "whole": whole, "params": m.params.tolist(), "few": few,
+                      "unet_seed": u.seed, "unet_sum": float(u.params.double().abs().sum())}))
     dist.destroy_process_group()
 """)
 
@@ -63,3 +68,4 @@ def test_gloo_world2(tmp_path):
         assert o["whole"] == [float(int(n[4:8])) for n in sorted(names)]
         assert o["params"] == [9.0, 9.0, 9.0, 0.5, 3.0]  # trainable part untouched, moving statistics averaged
         assert o["few"] == ["only.png"]
+    assert outs[0]["unet_seed"] == outs[1]["unet_seed"] and outs[0]["unet_sum"] == outs[1]["unet_sum"]   # rank 0's draw on every rank

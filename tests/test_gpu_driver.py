@@ -692,3 +692,98 @@ def test_isic_im_plus_plus_two_ranks_on_one_gpu(tmp_path):
     assert "ISIC_2018_evalnet_im_1_topK_1.h5" in models and stem + "_topK_1.h5" in models
     res = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(res) == 3 and len(res[1].split(";")) == 7
+
+
+def test_isic_aug_subset_and_aim_plus_toy_run(tmp_path):
+    """ISIC_2018/04_ISIC_2018_subset_aug.py (ALDT: the labelled set augmented into train_labeled_aug, candidates trained on it,
+    `ISIC_2018_subset_aug_{runid}_topK_j.h5`) followed by ISIC_2018/13_ISIC_2018_aug_IM+.py:44-116 (AIM+: gen 0 loads those
+    models; training set = augmented copies + the un-augmented IM pairs + the AUGMENTED labelled set)."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CONFIG.format(base=base) + "FREE_ROTATION = True\nNUM_IMAGES_IM_PLUS = 1\n")
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1"}
+    subprocess.run([sys.executable, "-c", SETUP.format(root=ROOT)], env=env, check=True, cwd=tmp_path)
+    for script in ("04_ISIC_2018_subset_aug.py", "13_ISIC_2018_aug_IM+.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", script)], env=env, cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, script + r.stdout[-2000:] + r.stderr[-3000:]
+    aug = sorted(os.listdir(base / "train_labeled_aug" / "images"))
+    assert len(aug) == 16 * 10 and aug == sorted(os.listdir(base / "train_labeled_aug" / "masks"))     # 9 copies + the original
+    models = sorted(os.listdir(base / "models"))
+    assert "ISIC_2018_subset_aug_1_topK_1.h5" in models and "ISIC_2018_subset_aug_1_topK_2.h5" in models
+    stem = "ISIC_2018_aug_IM_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
+    temp = base / "train_unlabeled_predictions" / "aug_IM_plus" / "temp" / stem
+    plus = base / "train_unlabeled_predictions" / "aug_IM_plus" / stem
+    kept = sorted(os.listdir(temp / "images"))
+    want = sorted([f"{k[:-4]}_aug_0.png" for k in kept] + kept + aug)
+    assert sorted(os.listdir(plus / "images")) == want and sorted(os.listdir(plus / "masks")) == want
+    assert (base / "csv" / f"results_{stem}.csv").exists() and (base / "csv" / "results_ISIC_2018_subset_aug_1.csv").exists()
+
+
+def test_suim_gt_im_plus_plus_toy_run(tmp_path):
+    """SUIM/16_SUIM_GT_IM++.py: IM++ without an EvalNet -- 1..5 augmented copies per pseudo-labelled pair by its IoU against
+    the ground truth (IM pixels blanked), at least an epoch over TRAIN_FULL worth of steps."""
+    base = tmp_path / "data"
+    cfg = tmp_path / "config.ini"
+    extra = "NUM_EPOCHS_EVALNET = 1\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 1\nNUM_LOOPS_VAL = 1\n"
+    cfg.write_text(MULTI_CONFIG.format(base=base).replace("TOP_Ks = 2\n", "TOP_Ks = 2\n" + extra)
+                   + "ALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n")
+    env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_GENS": "0", "IM_CANDIDATES": "0,1"}
+    setup = MULTI_SETUP.format(root=ROOT) + "\nsample(4, paths.SUIM_TRAIN_FULL_IMAGES_DIR, paths.SUIM_TRAIN_FULL_MASKS_DIR)\n"
+    subprocess.run([sys.executable, "-c", setup], env=env, check=True, cwd=tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "SUIM", "16_SUIM_GT_IM++.py")], env=env, cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = "SUIM_GT_IM_plus_plus_1_n2_gen0_e0_d0_bi_True_bo_True"
+    models = sorted(os.listdir(base / "models"))
+    assert stem + "_topK_1.h5" in models and not any("evalnet" in m for m in models)
+    unl = base / "train_unlabeled_predictions" / "GT_IM_plus_plus" / stem
+    names = os.listdir(unl / "images")
+    per_image = {}
+    for n in names:
+        if "___" in n:
+            per_image.setdefault(n.split("___")[0], []).append(int(n.split("___")[1][:-4]))
+    assert len(per_image) == 24 and all(sorted(v) == list(range(len(v))) and 1 <= len(v) <= 5 for v in per_image.values())
+    assert len(names) == sum(len(v) for v in per_image.values()) + 16
+    assert max(len(v) for v in per_image.values()) >= 3          # the toy ensemble's pseudo-labels are good: many copies
+
+
+def test_writer_rgb_false_feeds_the_file_order_to_the_nets(tmp_path):
+    """rgb=False (functions.py:2847-2850: the nets get the channels as OpenCV decodes the file, BGR): equals the rgb=True run
+    on the channel-flipped files, the written images keeping each file's own channel order."""
+    sys.path.insert(0, ROOT)
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd.unet import get_unet
+    rng = np.random.default_rng(1)
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    os.makedirs(d1); os.makedirs(d2)
+    for i in range(5):
+        img = rng.integers(0, 256, (32, 48, 3)).astype(np.uint8)
+        F.write_png(str(d1 / f"i{i}.png"), img)
+        F.write_png(str(d2 / f"i{i}.png"), img[..., ::-1].copy())
+    models = [get_unet(32, 48, 3, 1, 0.5, "relu", "sigmoid", seed=s) for s in (1, 2)]
+    for m in models:
+        m.repack()
+    F.create_pseudo_labels_im_ISIC_2018(models, 32, 48, 3, str(d1), str(tmp_path / "o1"), False, 0, 0, True, True, False)
+    F.create_pseudo_labels_im_ISIC_2018(models, 32, 48, 3, str(d2), str(tmp_path / "o2"), True, 0, 0, True, True, False)
+    for i in range(5):
+        for sub in ("masks", "im"):
+            assert np.array_equal(F.read_png(str(tmp_path / "o1" / sub / f"i{i}.png"), 1), F.read_png(str(tmp_path / "o2" / sub / f"i{i}.png"), 1))
+        a, b = F.read_png(str(tmp_path / "o1" / "images" / f"i{i}.png"), 3), F.read_png(str(tmp_path / "o2" / "images" / f"i{i}.png"), 3)
+        assert np.array_equal(a, b[..., ::-1])
+
+
+def test_bench_one_rank_process_group_rccl():
+    """bench.py --gpus 1 with IMK_FORCE_DIST=1: a real one-rank `nccl` (= RCCL) process group, so that init_process_group with
+    device_id, the flat gradient all-reduce of every step, the MAX / SUM reductions of the timing and dist.barrier execute on
+    the GPU box (the multi-rank path otherwise only runs over gloo in this repository's tests).  The JSON line must be the
+    last line of stdout (RCCL prints a version banner through C stdio)."""
+    import json
+    env = {**os.environ, "IMK_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "96", "--labeled", "32", "--steps", "1",
+                        "--pretrain-steps", "10", "--bn-settle-steps", "10", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["config"]["process_group"].startswith("nccl") and out["value"] > 0
+    assert out["roofline"]["step"]["train_step"]["host_enqueue_ms_per_step"] > 0

@@ -13,7 +13,7 @@ image, so this converter is meant to run OFFLINE on a machine that has `h5py` (T
   (`conv2d_17`, `batch_normalization_9`, ...) in the order unet.py:46-67 creates them, which is the order of
   `oracle/unet_oracle.layer_table` and of the flat parameter vector.  Kernels stay HWIO, exactly as Keras stores them.
 * safetensors -> `model.get_weights()` order (.npz, arrays named w000, w001, ...): a TensorFlow user restores it with
-  `model.set_weights([d[k] for k in sorted(d.files)])` on a model built by the reference's `get_unet`.
+  `model.set_weights([d[k] for k in sorted(d.files)])` (zero-padded names) on a model built by the reference's `get_unet`.
   The same .npz is accepted as INPUT (`--from-keras-npz`), for checkpoints dumped with `np.savez(..., *model.get_weights())`.
 
 The mapping logic is pure Python / numpy and is unit-tested without h5py (tests/test_cpu_api.py)."""
@@ -165,7 +165,9 @@ def main(argv=None):
         return 0
     if a.from_keras_npz:
         d = np.load(a.src)
-        arrays = [d[k] for k in sorted(d.files)]
+        # np.savez(path, *model.get_weights()) names the arrays arr_0 ... arr_113: order by the NUMERIC suffix (a plain sort
+        # puts arr_10 in front of arr_2); this tool's own zero-padded w000 ... names sort the same either way
+        arrays = [d[k] for k in sorted(d.files, key=lambda k: int(re.search(r"(\d+)$", k).group(1)))]
         c_in, n_out, alpha = infer_config(arrays[0].shape, arrays[-2].shape)
         table = layer_table(c_in, n_out, alpha)
         sd, act = state_dict_from_weight_list(arrays, table), a.act_out
