@@ -389,17 +389,14 @@ def main():
     import ctypes
     from inconsistencymasks_amd import functions as F
     from inconsistencymasks_amd import im as imk_im
-    from inconsistencymasks_amd._lib import lib as imk_lib
     from inconsistencymasks_amd.unet import UNet
 
     NV = len(FAMILIES)
-    def prof_collect():
-        pc = (ctypes.c_int64 * NV)(); pms = (ctypes.c_double * NV)(); pby = (ctypes.c_double * NV)(); pfl = (ctypes.c_double * NV)()
-        imk_lib.imk_prof_collect_ex(pc, pms, pby, pfl)
-        return [int(v) for v in pc], [float(v) for v in pms], [float(v) for v in pby], [float(v) for v in pfl]
     # HIP events (on the launch stream) around every k-th hooked launch, from process start: the setup phase is
     # collected separately so that the whole-process average can be compared with `rocprofv3 --stats` of this command
-    imk_lib.imk_prof_enable(0 if args.no_prof else args.prof_period)
+    from inconsistencymasks_amd.prof import Profiler
+    prof = Profiler(0 if args.no_prof else args.prof_period)
+    prof_collect = prof.collect
 
     # ---- synthetic, HBM-resident inputs ---------------------------------------------------------------------------
     # strong: every rank generates THE set (seed 42) and keeps its contiguous block (functions.shard_list's rule);
@@ -552,7 +549,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     pc, pms, pby, pfl = prof_collect()
-    imk_lib.imk_prof_enable(0)
+    prof.set_period(0)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -649,17 +646,19 @@ def main():
                 "all_families": fam_all, "step": step_view,
                 "note": "timed region: the weight-gradient kernels (side stream) and the ensemble's other models run beside "
                         "the main-stream kernels, event-bracketed durations include that sharing; 'exclusive' = the same "
-                        "workload with every kernel alone on one stream (imk_debug_single_stream).  bound = mfma for the "
+                        "workload with every kernel alone on one stream (the plans' single_stream switch).  bound = mfma for the "
                         "GEMM-class conv families (>= 33 channels: far above the fp16 ridge), hbm otherwise"}
     # the same generation once more with every kernel alone on the stream: the kernels' own rates
-    imk_lib.imk_debug_single_stream(1)
-    imk_lib.imk_prof_enable(7 if not args.no_prof else 0)     # outside the timed region: dense sampling
+    for m in models + [student]:
+        m.debug(single_stream=True)
+    prof.set_period(7 if not args.no_prof else 0)     # outside the timed region: dense sampling
     prof_collect()
     generation()
     barrier()
     xc, xms, xby, xfl = prof_collect()
-    imk_lib.imk_prof_enable(0)
-    imk_lib.imk_debug_single_stream(0)
+    prof.set_period(0)
+    for m in models + [student]:
+        m.debug(single_stream=False)
     if xms[v]:
         x_ach = (xfl[v] / xms[v] / 1e9) if mfma_bound else (xby[v] / xms[v] / 1e6)
         roofline["exclusive"] = {"achieved": round(x_ach, 1), "frac": round(x_ach / peak, 4),

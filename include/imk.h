@@ -164,7 +164,7 @@ IMK_API int imk_unet_tensor_info(const imk_unet_plan *plan, int batch, int mode,
  * workspace: imk_unet_forward_im_workspace_bytes(plan, n_models, B, k), 1 <= k <= min(n_models, 3): with k > 1 the models
  * run on k streams side by side (forked from and joined to `stream` with events; the call stays asynchronous), with
  * k = 1 back to back.  Shapes the fused kernel does not cover (sigmoid heads with more than 4 maps, H*W not a multiple
- * of 16, more than 8 models) and imk_debug_materialize(1) take the unfused route through the fp32 probability stack
+ * of 16, more than 8 models) and plans with the materialize debug switch take the unfused route through the fp32 probability stack
  * (n_models * align256(B*H*W*n_out*4) + k * imk_unet_workspace_bytes(plan, B, 0) bytes are enough for that one).      */
 IMK_API int64_t imk_unet_forward_im_workspace_bytes(const imk_unet_plan *plan, int n_models, int batch, int n_streams);
 IMK_API int imk_unet_forward_im(const imk_unet_plan *plan, int n_models,
@@ -275,34 +275,37 @@ IMK_API int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
 IMK_API int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
                             int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
-/* Debug/parity: with on = 1, inference also stores the intermediates that fused kernels normally keep on chip
- * (the Conv3x3 output inside a fused Conv3x3 -> Conv1x1 kernel), so that imk_unet_tensor_info can be used on
- * every layer.  Global flag; training always stores them (the backward pass needs them). */
-IMK_API int imk_debug_materialize(int on);
-
-/* Measurement: with on = 1 every kernel runs on the caller's stream (no side stream for the weight gradients, the
- * ensemble's models back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
-IMK_API int imk_debug_single_stream(int on);
+/* Debug / measurement switches of ONE plan (U-Net or EvalNet); -1 leaves a switch as it is.  The library keeps no global state:
+ * the caller owns the plan and these two flags in it.
+ *   materialize = 1: inference also stores the intermediates that fused kernels normally keep on chip (the Conv3x3 output
+ *     inside a fused Conv3x3 -> Conv1x1 kernel, the input block's output), so that imk_unet_tensor_info works on every layer.
+ *     Training always stores them (the backward pass needs them).
+ *   single_stream = 1: every kernel runs on the caller's stream (no side stream for the weight gradients, the ensemble's models
+ *     back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
+IMK_API int imk_unet_plan_debug(imk_unet_plan *plan, int materialize, int single_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of every kernel family of the path, on the stream the
- * kernel is launched on.  imk_prof_enable(k) makes every k-th hooked launch record an event pair (0 = off);
- * imk_prof_collect synchronises those events and returns, per family v (0..IMK_PROF_VARIANTS-1), the number of sampled
- * launches, their summed duration in ms and their summed ALGORITHMIC bytes (every input tensor read once + every
- * output tensor written once), then resets.  Families:
+ * kernel is launched on.  A context is created and owned by the caller and bound to the calling thread: while bound, every
+ * period-th hooked launch made by THAT thread records an event pair into it (period 0 = off).  imk_prof_collect synchronises
+ * those events and returns, per family v (0..IMK_PROF_VARIANTS-1), the number of sampled launches, their summed duration in
+ * ms, their summed ALGORITHMIC bytes (every input tensor read once + every output tensor written once) and -- flops may be
+ * NULL -- the summed FLOPs (2 x multiply-adds, logical channel counts; 0 for families that are not convolutions), then
+ * resets the records.  Families:
  *   0..5  conv_mfma_kernel<TH,MT>: v = 3*(TH==8) + log2(MT)      6  conv_pipe_kernel
  *   7  wgrad_mfma_kernel      8  bn_bwd_prep(_pool)_kernel       9  bn_bwd_coef_kernel     10  bn_finalize_kernel
- *   11 wgf_stage1 + wgf_stage2 (one bracket)                     12 head_kernel            13  head_loss_kernel
+ *   11 wgf_stage1 + wgf_stage2 (one bracket)                     12 head_kernel            13  head_loss_kernel / head_cce_fused_kernel
  *   14 loss_finalize / adamw / pack_conv_batched / bn_fold_batched                         15  im_binary_* / im_multi_kernel
  *   16 conv_gemm_kernel (wide layers, forward / dgrad)           17 wgrad_gemm_kernel (wide layers, weight gradient)
- * Process-global and not thread-safe; for benchmarking only (two hipEventRecord per sampled launch while enabled).
+ * A context must not be shared between threads that launch concurrently (two hipEventRecord per sampled launch while bound).
  * ---------------------------------------------------------------------------------------------- */
 #define IMK_PROF_VARIANTS 18
-IMK_API int imk_prof_enable(int on);
-IMK_API int imk_prof_collect(int64_t *count, double *ms, double *bytes);
-/* the same, plus the summed FLOPs (2 x multiply-adds, logical channel counts) of the sampled conv / weight-gradient launches
- * (0 for the families that are not convolutions); flops may be NULL */
-IMK_API int imk_prof_collect_ex(int64_t *count, double *ms, double *bytes, double *flops);
+typedef struct imk_prof imk_prof;   /* opaque, host memory */
+IMK_API int imk_prof_create(int period, imk_prof **out);
+IMK_API void imk_prof_destroy(imk_prof *ctx);
+IMK_API int imk_prof_bind(imk_prof *ctx);              /* ctx or NULL (unbind) for the calling thread */
+IMK_API int imk_prof_set_period(imk_prof *ctx, int period);
+IMK_API int imk_prof_collect(imk_prof *ctx, int64_t *count, double *ms, double *bytes, double *flops);
 
 #ifdef __cplusplus
 }

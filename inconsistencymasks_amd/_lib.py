@@ -76,12 +76,13 @@ SIGNATURES = {
     "imk_eval_multiclass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_eval_soft_out_doubles": (c_int64, [c_int]),
     "imk_eval_soft_sums": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "imk_debug_materialize": (c_int, [c_int]),
-    "imk_debug_single_stream": (c_int, [c_int]),
-    "imk_prof_enable": (c_int, [c_int]),
-    "imk_prof_collect": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
-    "imk_prof_collect_ex": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
-                                    ctypes.POINTER(ctypes.c_double)]),
+    "imk_unet_plan_debug": (c_int, [c_void_p, c_int, c_int]),
+    "imk_prof_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "imk_prof_destroy": (None, [c_void_p]),
+    "imk_prof_bind": (c_int, [c_void_p]),
+    "imk_prof_set_period": (c_int, [c_void_p, c_int]),
+    "imk_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(ctypes.c_double)]),
     "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_float, c_float, c_float, c_void_p]),
 }

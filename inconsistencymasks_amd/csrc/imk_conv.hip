@@ -1525,52 +1525,73 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 }
 
 // ---- optional per-launch event timing (bench.py roofline) ---------------------------------------------
+#include <new>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int variant; double bytes, flops; };
-int g_prof_period = 0;   // 0 = off, k = time every k-th hooked launch
-long g_prof_counter = 0;
-std::vector<ProfRec> g_prof;       // recorded launches since the last collect
-std::vector<hipEvent_t> g_ev_pool; // recycled events
-
-hipEvent_t prof_event() {
-    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
-}
-
 }  // namespace
+// Measurement context (include/imk.h: imk_prof_*): owned by the caller, bound to the thread that launches -- the library itself
+// keeps no mutable global, only this per-thread binding
+struct imk_prof {
+    int period = 0;                    // time every k-th hooked launch
+    long counter = 0;
+    std::vector<ProfRec> recs;         // recorded launches since the last collect
+    std::vector<hipEvent_t> pool;      // recycled events
+    hipEvent_t event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+static thread_local imk_prof *t_prof = nullptr;
 
-extern "C" int imk_prof_enable(int on) { g_prof_period = on < 0 ? 0 : on; return IMK_OK; }
+extern "C" int imk_prof_create(int period, imk_prof **out) {
+    IMK_CHECK_ARG(out && period >= 0);
+    imk_prof *p = new (std::nothrow) imk_prof();
+    if (!p) return IMK_EINVAL;
+    p->period = period;
+    *out = p;
+    return IMK_OK;
+}
+extern "C" void imk_prof_destroy(imk_prof *p) {
+    if (!p) return;
+    if (t_prof == p) t_prof = nullptr;
+    for (auto &r : p->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : p->pool) (void)hipEventDestroy(e);
+    delete p;
+}
+extern "C" int imk_prof_bind(imk_prof *p) { t_prof = p; return IMK_OK; }
+extern "C" int imk_prof_set_period(imk_prof *p, int period) { IMK_CHECK_ARG(p && period >= 0); p->period = period; return IMK_OK; }
 
 int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops) {
-    if (g_prof_period <= 0 || (g_prof_counter++ % g_prof_period) != 0) return -1;
-    ProfRec pr{prof_event(), prof_event(), family, bytes, flops};
-    if (hipEventRecord(pr.e0, stream) != hipSuccess) { g_ev_pool.push_back(pr.e0); g_ev_pool.push_back(pr.e1); return -1; }
-    g_prof.push_back(pr);
-    return (int)g_prof.size() - 1;
+    imk_prof *p = t_prof;
+    if (!p || p->period <= 0 || (p->counter++ % p->period) != 0) return -1;
+    ProfRec pr{p->event(), p->event(), family, bytes, flops};
+    if (hipEventRecord(pr.e0, stream) != hipSuccess) { p->pool.push_back(pr.e0); p->pool.push_back(pr.e1); return -1; }
+    p->recs.push_back(pr);
+    return (int)p->recs.size() - 1;
 }
 void imk_prof_end(int slot, hipStream_t stream) {
-    if (slot >= 0 && slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
+    imk_prof *p = t_prof;
+    if (p && slot >= 0 && slot < (int)p->recs.size()) (void)hipEventRecord(p->recs[slot].e1, stream);
 }
 
-extern "C" int imk_prof_collect_ex(int64_t *count, double *ms, double *bytes, double *flops) {
-    IMK_CHECK_ARG(count && ms && bytes);
+extern "C" int imk_prof_collect(imk_prof *p, int64_t *count, double *ms, double *bytes, double *flops) {
+    IMK_CHECK_ARG(p && count && ms && bytes);
     static_assert(IMK_PROF_VARIANTS == PF_COUNT, "include/imk.h and imk_common.h disagree");
     for (int v = 0; v < IMK_PROF_VARIANTS; ++v) { count[v] = 0; ms[v] = 0; bytes[v] = 0; if (flops) flops[v] = 0; }
-    for (auto &r : g_prof) {
+    for (auto &r : p->recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
             count[r.variant] += 1; ms[r.variant] += t; bytes[r.variant] += r.bytes;
             if (flops) flops[r.variant] += r.flops;
         }
-        g_ev_pool.push_back(r.e0); g_ev_pool.push_back(r.e1);
+        p->pool.push_back(r.e0); p->pool.push_back(r.e1);
     }
-    g_prof.clear();
+    p->recs.clear();
     return IMK_OK;
 }
-extern "C" int imk_prof_collect(int64_t *count, double *ms, double *bytes) { return imk_prof_collect_ex(count, ms, bytes, nullptr); }
 
 // Launch geometry of the per-tile kernel for one conv.
 // n / d = (n * div_magic(d)) >> 32 for d > 1 and n * d < 2^32 (a tile's index inside its image: pipe_fits); d = 1 is handled

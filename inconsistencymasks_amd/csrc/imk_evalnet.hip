@@ -232,7 +232,7 @@ extern "C" int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, voi
     ensure_side_streams(plan);
     static const int n_side_env = []() { const char *s = getenv("IMK_SIDE_STREAMS"); int v = s ? atoi(s) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && !g_imk_single_stream) ? n_side_env : 0, 1LL << 62};
+    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && !plan->dbg_single_stream) ? n_side_env : 0, 1LL << 62};
     {   // Dense gradients and the loss values: batch reduction of the head kernel's per-sample terms
         const ImkLayer &d0 = plan->layers[t.dense[0]];
         const ImkLayer *d1 = nh > 1 ? &plan->layers[t.dense[1]] : nullptr;

@@ -13,8 +13,6 @@
 #include "imk_kernels.h"
 #include "imk_plan.h"
 
-extern bool g_imk_materialize;     // imk_debug_materialize(1): inference also stores the intermediates of fused kernels
-extern bool g_imk_single_stream;   // imk_debug_single_stream(1): no side streams (kernels run alone: exclusive timings)
 
 namespace {
 
@@ -203,12 +201,12 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
     if (conv2 >= 0) {
         const ImkLayer &l2 = c.p->layers[conv2];
         const bool pipe_chain = l2.pk_chain >= 0 && imk_conv_can_chain(a, l2.cout);
-        if (pipe_chain || (!x_override && l2.ksize == 1 && imk_conv_can_chain_tile(a, l2.cout, c.train || g_imk_materialize))) {
+        if (pipe_chain || (!x_override && l2.ksize == 1 && imk_conv_can_chain_tile(a, l2.cout, c.train || c.p->dbg_materialize))) {
             a.wpk2 = pipe_chain ? reinterpret_cast<const f16 *>(c.packed + l2.pk_chain) : c.wfwd(conv2);
             a.bias2 = c.params + l2.off_b;
             a.out2 = c.act(conv2);
             a.cout2 = l2.cout; a.cs_out2 = imk_pad8(l2.cout);
-            if (!c.train && !g_imk_materialize) a.out = nullptr;   // the intermediate never leaves the chip
+            if (!c.train && !c.p->dbg_materialize) a.out = nullptr;   // the intermediate never leaves the chip
             stat_conv = conv2;
             if (fused) *fused = true;
         }
@@ -239,7 +237,7 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
 // block's Conv1x1 on upsample + skip (unet.py:32-35; the input block in front of the first encoder block has its own form,
 // LM_STEM).  Neither pre's output nor the 3x3's leaves the chip.  Returns IMK_EUNSUPPORTED (nothing launched) where that does not apply.
 inline int run_conv_pre_pair(Ctx &c, int pre, int c3, int c1) {
-    if (c.train || g_imk_materialize) return IMK_EUNSUPPORTED;
+    if (c.train || c.p->dbg_materialize) return IMK_EUNSUPPORTED;
     const ImkLayer &lp = c.p->layers[pre], &l = c.p->layers[c3], &l2 = c.p->layers[c1];
     if (lp.ksize != 1 || lp.bn_after < 0 || l.src != pre || l.src_bn != lp.bn_after || l.lmode != LM_AFFINE || l2.pk_chain < 0)
         return IMK_EUNSUPPORTED;

@@ -51,6 +51,10 @@ struct imk_unet_plan {
     mutable hipEvent_t ev_fork[40] = {};
     mutable hipEvent_t ev_join[MAX_SIDE] = {};
     mutable bool side_ok = false;
+    // Debug / measurement switches of THIS plan (imk_unet_plan_debug; the caller owns the plan, the library keeps no global):
+    // materialize: inference also stores the intermediates of fused kernels (layer-by-layer parity);
+    // single_stream: no side streams -- every kernel alone on the caller's stream (exclusive kernel timings).
+    bool dbg_materialize = false, dbg_single_stream = false;
     int find(const char *name) const {
         for (size_t i = 0; i < layers.size(); ++i) if (layers[i].name == name) return (int)i;
         return -1;

@@ -5,9 +5,6 @@
 #include "imk_net.h"
 #include "imk_head.h"
 
-bool g_imk_materialize = false;
-bool g_imk_single_stream = false;
-
 namespace {
 
 // ---- topology ------------------------------------------------------------------------------------
@@ -126,7 +123,7 @@ int run_forward(Ctx &c, const Topo &t, float *probs, float *params_rw) {
     bool stem_fused = false;
     {
         const ImkLayer &st = c.p->layers[t.in_c], &c3 = c.p->layers[t.e_c3[0]];
-        if (!c.train && !g_imk_materialize && imk_conv_stem_fusable(st.cin, st.cout, c3.cout)) {
+        if (!c.train && !c.p->dbg_materialize && imk_conv_stem_fusable(st.cin, st.cout, c3.cout)) {
             ImkInput x{};
             x.in = c.x_in[0]; x.lmode = LM_STEM; x.cin = c3.cin; x.cs_in = imk_pad8(c3.cin); x.u8_c = st.cin;
             x.sc = c.bn_scale(t.in_bn); x.sh = c.bn_shift(t.in_bn);
@@ -211,9 +208,12 @@ extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer
     return IMK_OK;
 }
 
-extern "C" int imk_debug_materialize(int on) { g_imk_materialize = on != 0; return IMK_OK; }
-
-extern "C" int imk_debug_single_stream(int on) { g_imk_single_stream = on != 0; return IMK_OK; }
+extern "C" int imk_unet_plan_debug(imk_unet_plan *plan, int materialize, int single_stream) {
+    IMK_CHECK_ARG(plan);
+    if (materialize >= 0) plan->dbg_materialize = materialize != 0;
+    if (single_stream >= 0) plan->dbg_single_stream = single_stream != 0;
+    return IMK_OK;
+}
 
 extern "C" int64_t imk_unet_packed_bytes(const imk_unet_plan *plan) { return plan ? plan->packed_bytes : IMK_EINVAL; }
 
@@ -289,7 +289,7 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
     ha.block_in = block_in; ha.block_out = block_out; ha.img_out = img_out; ha.masks_out = masks_out; ha.im_out = im_out;
     ha.im_size = im_size; ha.pred_size = pred_size; ha.presence = presence;
     static const bool fuse_off = []() { const char *e = getenv("IMK_HEAD_IM_FUSE"); return e && e[0] == '0'; }();
-    bool fused = !fuse_off && !g_imk_materialize && imk_head_im_supported(ha) &&
+    bool fused = !fuse_off && !plan->dbg_materialize && imk_head_im_supported(ha) &&
                  (int64_t)(head_slab_bytes(plan, batch, true) * n_models + ws.total) <= workspace_bytes;
     const size_t slab = head_slab_bytes(plan, batch, fused);
     if ((int64_t)(slab * n_models + ws.total) > workspace_bytes) return IMK_EWORKSPACE;
@@ -304,7 +304,7 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
     if (n_slabs > n_models) n_slabs = n_models;
     if (n_slabs > max_streams) n_slabs = max_streams;
     static const bool conc_off = []() { const char *e = getenv("IMK_ENSEMBLE_STREAMS"); return e && e[0] == '0'; }();
-    if (n_slabs > 1 && (conc_off || g_imk_single_stream || !ensure_side_streams(plan))) n_slabs = 1;
+    if (n_slabs > 1 && (conc_off || plan->dbg_single_stream || !ensure_side_streams(plan))) n_slabs = 1;
     hipStream_t main_stream = (hipStream_t)stream_;
     if (n_slabs > 1) {
         IMK_HIP(hipEventRecord(plan->ev_fork[0], main_stream));
@@ -394,7 +394,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : (1LL << 62); }();
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !g_imk_single_stream) ? n_side_env : 0, side_px};
+    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !plan->dbg_single_stream) ? n_side_env : 0, side_px};
     bool loss_done = false;
     auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than the head's kernel)
         if (loss_done || b.n_side <= 0 || b.n_fork <= 0) return IMK_OK;

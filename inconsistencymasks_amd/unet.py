@@ -124,6 +124,12 @@ class UNet:
         self._fold_ok = False        # folded inference BN statistics match params (moving statistics)
         self.train_state = None
 
+    def debug(self, materialize=None, single_stream=None):
+        """Debug / measurement switches of this model's plan (imk_unet_plan_debug): materialize -- inference also stores the
+        intermediates fused kernels keep on chip; single_stream -- no side streams (exclusive kernel timings)."""
+        check(lib.imk_unet_plan_debug(self.plan.ptr, -1 if materialize is None else int(bool(materialize)),
+                                      -1 if single_stream is None else int(bool(single_stream))), "imk_unet_plan_debug")
+
     # ---- parameters -------------------------------------------------------------------------------
     def ready_for_inference(self):
         """training steps re-pack the conv weights but leave the folded BN statistics stale: refresh if needed"""

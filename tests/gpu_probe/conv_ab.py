@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 
 def child():
     import torch, hashlib
-    from inconsistencymasks_amd._lib import lib
+    from inconsistencymasks_amd.prof import Profiler
+    pr = Profiler(0)
     from inconsistencymasks_amd.unet import UNet
     torch.manual_seed(0)
     dev = "cuda"
@@ -15,14 +16,13 @@ def child():
     def prof(fn, n):
         for _ in range(2): fn()
         torch.cuda.synchronize()
-        lib.imk_prof_enable(1)
+        pr.set_period(1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
-        lib.imk_prof_enable(0)
-        c = (ctypes.c_int64 * 7)(); ms = (ctypes.c_double * 7)(); by = (ctypes.c_double * 7)()
-        lib.imk_prof_collect(c, ms, by)
+        pr.set_period(0)
+        c, ms, by, _ = pr.collect()
         tot = e0.elapsed_time(e1) / n
         return tot, {i: (int(c[i]) // n, round(ms[i] / n, 3), round(by[i] / ms[i] / 1e6) if ms[i] else 0) for i in range(7) if c[i]}
     p = m.predict_device(x)

@@ -15,7 +15,7 @@ for _ in range(3):
     m.train_step(x, y, loss, 3e-3, 1e-4)
 out = {"params": m.params.cpu().numpy()}
 if os.environ.get("MAT") == "1":
-    lib.imk_debug_materialize(1)
+    m.debug(materialize=True)
 p = m.predict_device(x)
 out["probs"] = p.cpu().numpy()
 names = [l["name"] for l in m.plan.layers if l["kind"] == 0 and l["name"] != "out"]

@@ -65,11 +65,11 @@ def test_inference_parity(name):
     from inconsistencymasks_amd._lib import lib
     cfg = CFGS[name]
     m, sd, xa, xb, _ = make(cfg, 21)
-    lib.imk_debug_materialize(1)
+    m.debug(materialize=True)
     try:
         out = m.predict([xa, xb])
     finally:
-        lib.imk_debug_materialize(0)
+        m.debug(materialize=False)
     taps = {}
     ref, _ = E.forward(sd, xa, ob(cfg, xb), cfg["two"], cfg["na"], cfg["nb"], emulate_fp16=True, taps=taps)
     for n, t in taps.items():

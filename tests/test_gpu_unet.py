@@ -88,9 +88,9 @@ def test_inference_parity(UNet, name):
     xd = torch.from_numpy(x).cuda()
     taps = {}
     ref = U.forward(sd, x, cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], emulate_fp16=True, taps=taps).numpy()
-    # (1) the stored path: imk_debug_materialize(1) keeps the on-chip intermediates of fused kernels (and the input block's
+    # (1) the stored path: the plan's materialize switch keeps the on-chip intermediates of fused kernels (and the input block's
     #     output), so every layer can be compared
-    lib.imk_debug_materialize(1)
+    m.debug(materialize=True)
     try:
         probs_stored = m.predict_device(xd).cpu().numpy()
         for l in m.plan.layers:
@@ -98,7 +98,7 @@ def test_inference_parity(UNet, name):
                 got = m.intermediate(l["name"], cfg["b"], 0).numpy()
                 assert rel_l2(got, taps[l["name"]].numpy()) <= 1e-2, l["name"]
     finally:
-        lib.imk_debug_materialize(0)
+        m.debug(materialize=False)
     # (2) the default path -- what bench.py and the writers run: the input block is computed on load by the first encoder
     #     conv (LM_STEM) where the widths allow it, Conv3x3 -> Conv1x1 pairs are chained.  Every tensor this path still
     #     stores (the block outputs *.c1 and the decoder's *.ca) is compared layer by layer, too.
@@ -373,7 +373,7 @@ def test_cityscapes_im_plus_schedule_batch32(UNet, alpha):
 @pytest.mark.parametrize("name", ["isic", "hela"])
 def test_fused_input_block_matches_stored_one(UNet, name):
     """Inference computes the input block (x/255 -> Conv1x1+ReLU -> BN) inside the first encoder conv's load (LM_STEM) instead of
-    storing its output; imk_debug_materialize(1) runs the stored path.  Same fp16 roundings, fp32 sums of <= 4 products in a
+    storing its output; the plan's materialize switch runs the stored path.  Same fp16 roundings, fp32 sums of <= 4 products in a
     different order: probabilities agree to 2e-3."""
     from inconsistencymasks_amd._lib import lib
     cfg = CFGS[name]
@@ -381,11 +381,11 @@ def test_fused_input_block_matches_stored_one(UNet, name):
     m.load_state_dict(randomize_bn(m.state_dict(), 6))
     x, _, _ = make_input(cfg, 7)
     fused = m.predict(x)
-    lib.imk_debug_materialize(1)
+    m.debug(materialize=True)
     try:
         stored = m.predict(x)
     finally:
-        lib.imk_debug_materialize(0)
+        m.debug(materialize=False)
     assert np.abs(fused - stored).max() <= 2e-3
     assert (np.abs(fused - stored) > 0).mean() < 0.5 or np.abs(fused - stored).max() <= 1e-3
 
