@@ -275,6 +275,12 @@ IMK_API int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
 IMK_API int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mode, int layer_idx, int which,
                             int64_t *byte_offset, int *h, int *w, int *c, int *c_stride);
 
+/* Momentum of the BatchNorm moving statistics in the training steps of ONE plan (U-Net or EvalNet).  Default 0.99 = Keras'
+ * BatchNormalization default, which the reference never overrides (unet.py:7).  Data-parallel runs with per-GPU batch 32 make
+ * N times fewer optimizer steps per epoch: 0.99^N keeps the moving average's memory the same in SAMPLES (functions.py of this
+ * repository: IMK_DP_BN_MOMENTUM=scaled; off by default, it is a deviation from the reference's recipe). */
+IMK_API int imk_unet_plan_set_bn_momentum(imk_unet_plan *plan, float momentum);
+
 /* Debug / measurement switches of ONE plan (U-Net or EvalNet); -1 leaves a switch as it is.  The library keeps no global state:
  * the caller owns the plan and these two flags in it.
  *   materialize = 1: inference also stores the intermediates that fused kernels normally keep on chip (the Conv3x3 output

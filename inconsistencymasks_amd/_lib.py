@@ -77,6 +77,7 @@ SIGNATURES = {
     "imk_eval_soft_out_doubles": (c_int64, [c_int]),
     "imk_eval_soft_sums": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "imk_unet_plan_debug": (c_int, [c_void_p, c_int, c_int]),
+    "imk_unet_plan_set_bn_momentum": (c_int, [c_void_p, c_float]),
     "imk_prof_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "imk_prof_destroy": (None, [c_void_p]),
     "imk_prof_bind": (c_int, [c_void_p]),

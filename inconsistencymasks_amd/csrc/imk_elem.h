@@ -14,7 +14,7 @@ struct ImkCtl {
 
 int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *beta, float *mov_mean, float *mov_var, float *scale, float *shift,
-                           float *save_mean, float *save_invstd, hipStream_t stream);
+                           float *save_mean, float *save_invstd, hipStream_t stream, float momentum = 0.99f);   // Keras default momentum
 int imk_bn_prep_blocks(int B, int H, int W, int cs);
 int imk_launch_bn_bwd_prep(int mode, const f16 *g_direct, const f16 *g_other, const f16 *z, const float *sc,
                            const float *sh, f16 *dy_out, float *partial, int B, int H, int W, int cs, hipStream_t stream,

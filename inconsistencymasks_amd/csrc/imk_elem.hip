@@ -13,7 +13,6 @@ IMK_STAMP_TABLE(elem)
 namespace {
 
 constexpr float BN_EPS = 1e-3f;       // Keras BatchNormalization default epsilon
-constexpr float BN_MOMENTUM = 0.99f;  // Keras default momentum
 
 // Column sums of the two halves of partial[n_part][2 * cs] for channel ch in double precision, by one 256-thread block:
 // every thread's rows are requested before any is used (one memory latency), lanes combine with shuffles, the 4 waves through
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ beta, float *__restrict__ mov_mean,
                                                           float *__restrict__ mov_var, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ save_mean,
-                                                          float *__restrict__ save_invstd) {
+                                                          float *__restrict__ save_invstd, float momentum) {
     const int ch = blockIdx.x;
     const int t = threadIdx.x;
     if (ch >= c) {  // padded channels: identity-zero
@@ -76,11 +75,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         shift[ch] = bet - (float)mean * sc;
         save_mean[ch] = (float)mean;
         save_invstd[ch] = invstd;
-        mov_mean[ch] = mm * BN_MOMENTUM + (float)mean * (1.f - BN_MOMENTUM);
+        mov_mean[ch] = mm * momentum + (float)mean * (1.f - momentum);
         // Keras' fused BatchNormalization feeds the moving average the Bessel-corrected batch variance (n / (n - 1); the
         // normalisation itself uses the biased one)
         const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        mov_var[ch] = mv * BN_MOMENTUM + (float)unbiased * (1.f - BN_MOMENTUM);
+        mov_var[ch] = mv * momentum + (float)unbiased * (1.f - momentum);
     }
     IMK_STAMP_END(2);
 }
@@ -691,10 +690,10 @@ __global__ __launch_bounds__(256) void evalnet_head_reduce_kernel(const float *_
 // -----------------------------------------------------------------------------------------------------
 int imk_launch_bn_finalize(const float *partial, int n_part, int c, int cs, double count, const float *gamma,
                            const float *beta, float *mov_mean, float *mov_var, float *scale, float *shift,
-                           float *save_mean, float *save_invstd, hipStream_t stream) {
+                           float *save_mean, float *save_invstd, hipStream_t stream, float momentum) {
     ImkProfScope prof(PF_BN_FINALIZE, (double)n_part * 2 * cs * 4 + 8.0 * cs * 4, stream);
     bn_finalize_kernel<<<cs, 256, 0, stream>>>(partial, n_part, c, cs, count, gamma, beta, mov_mean, mov_var, scale, shift,
-                                               save_mean, save_invstd);
+                                               save_mean, save_invstd, momentum);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

@@ -228,7 +228,7 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
         if (rows <= 0 || rows > c.ws.L[bn].n_stats_tiles) return IMK_EWORKSPACE;
         rc = imk_launch_bn_finalize(a.stats_partial, rows, b.cout, cs, (double)c.B * d.h * d.w,
                                     c.params + b.off_w, c.params + b.off_b, params_rw + b.off_mean, params_rw + b.off_var,
-                                    sc, sc + cs, sv, sv + cs, c.stream);
+                                    sc, sc + cs, sv, sv + cs, c.stream, c.p->bn_momentum);
     }
     return rc;
 }

@@ -55,6 +55,8 @@ struct imk_unet_plan {
     // materialize: inference also stores the intermediates of fused kernels (layer-by-layer parity);
     // single_stream: no side streams -- every kernel alone on the caller's stream (exclusive kernel timings).
     bool dbg_materialize = false, dbg_single_stream = false;
+    // momentum of the BatchNorm moving statistics in training steps (imk_unet_plan_set_bn_momentum; Keras default 0.99)
+    float bn_momentum = 0.99f;
     int find(const char *name) const {
         for (size_t i = 0; i < layers.size(); ++i) if (layers[i].name == name) return (int)i;
         return -1;

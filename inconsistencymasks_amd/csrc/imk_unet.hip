@@ -208,6 +208,12 @@ extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer
     return IMK_OK;
 }
 
+extern "C" int imk_unet_plan_set_bn_momentum(imk_unet_plan *plan, float momentum) {
+    IMK_CHECK_ARG(plan && momentum >= 0.f && momentum < 1.f);
+    plan->bn_momentum = momentum;
+    return IMK_OK;
+}
+
 extern "C" int imk_unet_plan_debug(imk_unet_plan *plan, int materialize, int single_stream) {
     IMK_CHECK_ARG(plan);
     if (materialize >= 0) plan->dbg_materialize = materialize != 0;

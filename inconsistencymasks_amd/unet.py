@@ -130,6 +130,10 @@ class UNet:
         check(lib.imk_unet_plan_debug(self.plan.ptr, -1 if materialize is None else int(bool(materialize)),
                                       -1 if single_stream is None else int(bool(single_stream))), "imk_unet_plan_debug")
 
+    def set_bn_momentum(self, momentum):
+        """momentum of the BatchNorm moving statistics in training steps (Keras default 0.99)"""
+        check(lib.imk_unet_plan_set_bn_momentum(self.plan.ptr, float(momentum)), "imk_unet_plan_set_bn_momentum")
+
     # ---- parameters -------------------------------------------------------------------------------
     def ready_for_inference(self):
         """training steps re-pack the conv weights but leave the folded BN statistics stale: refresh if needed"""
