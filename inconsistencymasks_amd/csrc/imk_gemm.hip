@@ -337,6 +337,8 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     // output channels per workgroup: 128 or 64, whichever pads less (ties: the larger tile, one read of the input fewer)
     const int g128 = imk_cdiv_d(mt_total, 8), g64 = imk_cdiv_d(mt_total, 4);
     pn = (g128 * 8 <= g64 * 4) ? 4 : 2;
+    static const int force_pn = []() { const char *e = getenv("IMK_GEMM_PN"); return e ? atoi(e) : 0; }();
+    if (force_pn == 2 || (force_pn == 4 && mt_total > 4)) pn = force_pn;
     const int bn = 16 * pn * G_WN;
     const int halo = ks3 ? 1 : 0;
     gm.tiles_x = imk_cdiv(a.W, TW); gm.tiles_y = imk_cdiv(a.H, G_TH);
@@ -352,6 +354,12 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     if (lds < out_bytes) lds = out_bytes;
     if (lds < red_bytes) lds = red_bytes;
     if (lds > 64 * 1024) return IMK_EUNSUPPORTED;
+    // workgroups per compute unit: capped by padding the LDS request (160 KB / w), IMK_GEMM_W = 2 / 3 / 4 (0: what fits)
+    static const int force_w = []() { const char *e = getenv("IMK_GEMM_W"); return e ? atoi(e) : 0; }();
+    if (force_w >= 1 && force_w <= 3) {
+        const size_t want = (size_t)160 * 1024 / (force_w + 1) + 1024;
+        if (lds < want && want <= 64 * 1024) lds = want;
+    }
     grid = imk_cdiv_d(gm.n_sp, 8) * 8 * gm.gy;
     static const int dbg = []() { const char *e = getenv("IMK_GEMM_DBG"); return e ? atoi(e) : 0; }();
     gm.dbg = dbg;

@@ -448,6 +448,21 @@ struct Bwd {
                 return imk_wgf_add_job(jobs, a.wg_partial, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
             }
         }
+        // A Conv1x1 with 24-64 channels on both sides that feeds a BatchNorm -- the blocks' second conv (its input is the ReLU mask
+        // of its dgrad) and the decoder blocks' first one (upsample + add input, no mask): dgrad and weight gradient from one
+        // read of dy, z and x (imk_bwd1.hip) instead of two launches that read them twice.
+        if (stat_bn < 0 && l.ksize == 1 && l.bn_after >= 0 && l.src >= 0 &&
+            ((l.lmode == LM_RAW && mask && mask == c.act(l.src)) || (l.lmode == LM_UPADD && !mask)) &&
+            imk_bwd1x1_ok(l.lmode, imk_pad8(l.cin), imk_pad8(l.cout), mask != nullptr)) {
+            const Dim d = res_dim(c.p->cfg, l.res);
+            const int rows = imk_bwd1x1_rows((long long)c.B * d.h * d.w);
+            float *wgp = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
+            const int bn = l.bn_after;
+            int rc = imk_launch_bwd1x1(conv_input(c, conv), c.dy(bn), c.act(conv), reinterpret_cast<const float *>(c.base + c.ws.L[bn].coef),
+                                       c.wbwd(conv), dst, wgp, c.B, d.h, d.w, l.cout, c.stream);
+            if (rc) return rc;
+            return imk_wgf_add_job(jobs, wgp, rows, l.ksize, l.cin, l.cout, grads + l.off_w, grads + l.off_b);
+        }
         // A 3x3 conv that reads a BatchNorm output, its dgrad feeding that BatchNorm's gradient (Conv1x1 -> BN -> Conv3x3 of
         // the decoder blocks, input block -> first encoder conv): x = BN(z) with z the tensor the gradient statistics read.
         if (!mask && stat_bn >= 0 && l.ksize == 3 && l.lmode == LM_AFFINE && l.src_bn == stat_bn &&

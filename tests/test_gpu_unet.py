@@ -559,7 +559,7 @@ def test_decoder_first_stage_matches_its_own_launch(tmp_path):
     Inference agrees to fp16 rounding, not bit for bit: round 2 asserted bit-identity on ONE seed; on others (12-16, round-2
     and round-3 kernels alike) a handful of the last decoder block's outputs -- always next to the image border -- differ by
     one fp16 ulp (tests/gpu_probe/prestage_ab.py; cause not found yet), so the bound here is: at most 0.1 % of the block's
-    outputs differ, by at most 4e-3 (values are O(1)), probabilities within 1e-3."""
+    outputs differ, by a few fp16 ulps (4e-3 absolute + 4e-3 relative), probabilities within 3e-3 (a tenth of the parity tolerance)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "pre_child.py"
@@ -577,5 +577,5 @@ def test_decoder_first_stage_matches_its_own_launch(tmp_path):
             a, b = got[0]["last%d" % i], got[1]["last%d" % i]
             diff = a != b
             assert diff.mean() <= 1e-3, (seed, i, int(diff.sum()))
-            assert np.abs(a - b).max() <= 4e-3, (seed, i)       # one fp16 ulp of an O(1) input of the chained 1x1, through its 8-term sum
-            assert np.abs(got[0]["probs%d" % i] - got[1]["probs%d" % i]).max() <= 1e-3, (seed, i)
+            assert np.all(np.abs(a - b) <= 4e-3 + 4e-3 * np.abs(b)), (seed, i)   # a few fp16 ulps (one ulp of an input of the chained 1x1, through its 8-term sum)
+            assert np.abs(got[0]["probs%d" % i] - got[1]["probs%d" % i]).max() <= 3e-3, (seed, i)
