@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--labeled", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch event timing (roofline fields empty)")
+    ap.add_argument("--step-events", action="store_true", help="diagnostic: one event per training step, percentiles on stderr")
     ap.add_argument("--prof-period", type=int, default=61, help="time every k-th hooked kernel launch with HIP events")
     ap.add_argument("--pretrain-steps", type=int, default=300)
     ap.add_argument("--bn-settle-steps", type=int, default=600)
@@ -485,6 +486,8 @@ def main():
         return ps, ims, keep
 
     host_enqueue = []
+    step_events = []
+    last_batch = []
 
     def generation(record=None):
         e0, e1, e2 = ev(), ev(), ev()
@@ -510,20 +513,20 @@ def main():
             ty = (ty * pos_w if K == 3 else ty).contiguous()
         else:
             ty = pool_y[src][:, 0].contiguous()
-        # host cost of enqueueing a step (fwd_bwd + all-reduce + adamw): timed over the epoch's first steps, while the GPU is
-        # still busy with the inference stage / the gathers above and the launch queue is far from full (later in the epoch
-        # the host runs ahead until the queue back-pressures it, which would time the GPU, not the host)
-        n_host = min(steps, 8)
-        t_host = time.perf_counter()
         for s in range(steps):
-            if s == n_host:
-                host_enqueue.append((time.perf_counter() - t_host) / n_host)
             student.fwd_bwd(tx[s * BATCH:(s + 1) * BATCH], ty[s * BATCH:(s + 1) * BATCH], LOSS)
             scale = F._grad_allreduce(student)
             student.adamw_step(LR, WD, grad_scale=scale)
-        if steps and steps == n_host:
-            host_enqueue.append((time.perf_counter() - t_host) / n_host)
+            if args.step_events:
+                step_events.append(ev()); step_events[-1].record()
+        last_batch[:] = [tx[:BATCH], ty[:BATCH]]
         e2.record()
+        if args.step_events and step_events:
+            torch.cuda.synchronize()
+            dt = sorted(a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:]))
+            print(f"[step events] n={len(dt)} min {dt[0]:.3f} p10 {dt[len(dt)//10]:.3f} median {dt[len(dt)//2]:.3f} p90 {dt[9*len(dt)//10]:.3f} "
+                  f"max {dt[-1]:.3f} ms; e1 -> first step end {e1.elapsed_time(step_events[0]):.3f} ms", file=sys.stderr)
+            step_events.clear()
         if record is not None:
             record.append((e0, e1, e2))
         info.update(epoch_steps=int(steps), n_train=n_train)
@@ -539,7 +542,6 @@ def main():
     barrier()
     setup_prof = prof_collect()
     rec = []
-    host_enqueue.clear()
     t0 = time.perf_counter()
     # Sampling: an event record is a barrier packet on the stream (~5 us before the next kernel starts), so bracketing
     # every launch costs ~10 % of a training step; every 61st hooked launch (prime, coprime to the ~135 launches of a
@@ -550,6 +552,18 @@ def main():
     elapsed = time.perf_counter() - t0
     pc, pms, pby, pfl = prof_collect()
     prof.set_period(0)
+    # host cost of enqueueing a step (fwd_bwd + all-reduce + adamw), outside the timed region: from an idle device, 8 steps at
+    # a time (~1000 launches: inside an epoch the host runs ahead until the launch queue back-pressures it, which would
+    # time the GPU, not the host)
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t_host = time.perf_counter()
+        for s in range(8):
+            student.fwd_bwd(last_batch[0], last_batch[1], LOSS)
+            scale = F._grad_allreduce(student)
+            student.adamw_step(0.0, 0.0, grad_scale=scale)
+        host_enqueue.append((time.perf_counter() - t_host) / 8)
+    torch.cuda.synchronize()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -633,7 +647,7 @@ def main():
                  "conv_flops_per_image_forward": fwd_flops, "min_bytes_per_image_forward": fwd_min_bytes,
                  "note": "SURVEY 8d minimum HBM bytes (every tensor that crosses a block boundary written and read once; 3x per "
                          "training image) and conv FLOPs (3x forward per training image) over the measured stage time, per rank; "
-                         "host_enqueue = wall time the host needs to enqueue one step (fwd_bwd + all-reduce + adamw; first 8 steps of an epoch, before the launch queue can back-pressure): below the GPU step time the host is not the limiter"}
+                         "host_enqueue = wall time the host needs to enqueue one step (fwd_bwd + all-reduce + adamw; 8 steps from an idle device, outside the timed region, median of 5): below the GPU step time the host is not the limiter"}
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": FAMILIES[v], "achieved": round(achieved, 1), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src,

@@ -756,9 +756,84 @@ int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, doub
 }
 
 
+// Softmax heads: the shared matrix-core arithmetic of imk_head.h (HeadMfma).  Persistent over groups of 64 pixels per wave
+// (4 units of 16, all activation loads of a group issued first); a wave's 64 x K probabilities are contiguous in the
+// [pixel][K] output, so they go through a wave-private LDS slab and leave as 16-byte stores.
+template <int NCT, int KT>
+__global__ __launch_bounds__(256) void head_softmax_kernel(const f16 *__restrict__ z, const float *__restrict__ sc,
+                                                           const float *__restrict__ sh, const float *__restrict__ w,
+                                                           const float *__restrict__ bias, int cin, int cs, int K,
+                                                           long long n_pix, float *__restrict__ probs, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float s_slab[];     // [4 waves][64][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
+    float *so = s_slab + (size_t)wave * 64 * K;
+    HeadMfma<NCT, KT> h;
+    h.load(w, bias, sc, sh, cin, cs, K);
+    const long long n_grp = (n_pix + 63) / 64;
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_grp; grp += (long long)gridDim.x * 4) {
+        f16x4 zr[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long px = grp * 64 + u * 16 + p16;
+            h.load_z(z, px < n_pix ? px : n_pix - 1, cs, zr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 pr[KT];
+            h.probs(zr[u], K, pr);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kt + 4 * g + r;
+                    if (k < K) so[(u * 16 + p16) * K + k] = pr[kt][r];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const long long left = n_pix - grp * 64;
+        const int n_here = (int)(left < 64 ? left : 64) * K;           // floats this wave owns, contiguous
+        float *dst = probs + grp * 64 * K;
+        if (vec && (n_here & 3) == 0) {
+            for (int i = lane; i < n_here / 4; i += 64) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(so)[i];
+        } else {
+            for (int i = lane; i < n_here; i += 64) dst[i] = so[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+static int launch_head_softmax(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                               int K, long long n_pix, float *probs, hipStream_t stream) {
+    static const int cap = []() { const char *e = getenv("IMK_HEAD_BLOCKS"); return e ? atoi(e) : 2048; }();
+    const long long want = (n_pix + 255) / 256;
+    const int nb = (int)(want < cap ? want : cap);
+    const size_t lds = (size_t)4 * 64 * K * sizeof(float);
+    const int vec = (reinterpret_cast<uintptr_t>(probs) & 15) == 0;
+    const int nct = cs > 16 ? 2 : 1, kt = (K + 15) / 16;
+#define IMK_HS(NCT, KT) head_softmax_kernel<NCT, KT><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, cs, K, n_pix, probs, vec)
+#define IMK_HS_K(NCT)                                                                                                    \
+    switch (kt) {                                                                                                        \
+        case 1: IMK_HS(NCT, 1); break;                                                                                   \
+        case 2: IMK_HS(NCT, 2); break;                                                                                   \
+        case 3: IMK_HS(NCT, 3); break;                                                                                   \
+        default: IMK_HS(NCT, 4); break;                                                                                  \
+    }
+    if (nct == 1) { IMK_HS_K(1) } else { IMK_HS_K(2) }
+#undef IMK_HS_K
+#undef IMK_HS
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
+
 int imk_launch_head(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                     int K, int softmax, long long n_pix, float *probs, hipStream_t stream) {
     if (K > 64) return IMK_EUNSUPPORTED;
+    if (softmax && (cs == 8 || cs == 16 || cs == 24 || cs == 32)) {
+        ImkProfScope prof(PF_HEAD, (double)n_pix * (cs * 2 + K * 4), stream);
+        return launch_head_softmax(z, sc, sh, w, bias, cin, cs, K, n_pix, probs, stream);
+    }
     const int nb = (int)((n_pix + 255) / 256);
     const size_t lds = ((size_t)K * cs + K + 2 * cs + 256 * (size_t)(K | 1)) * sizeof(float);
     ImkProfScope prof(PF_HEAD, (double)n_pix * (cs * 2 + K * 4), stream);

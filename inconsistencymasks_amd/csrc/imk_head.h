@@ -59,6 +59,115 @@ __device__ __forceinline__ void head_softmax_row(const float (&xin)[CS], const f
     for (int k = 0; k < K; ++k) row[k] *= inv;
 }
 
+// ---- softmax heads on the matrix cores (head_softmax_kernel: probabilities -> HBM; head_im_softmax_kernel: -> votes) ------
+// logits^T [class][pixel] = W^T . x^T + b on v_mfma_f32_16x16x4_f32 (fp32 products and sums, like the reference's float32
+// output layer): a wave takes 16 pixels per unit, lane (p16 = lane & 15, g = lane >> 4) supplies the channels 16 ct + 4 g + r
+// of pixel p16 (the 8 bytes it loads itself) and receives the classes 16 kt + 4 g + r of the same pixel, so the softmax is
+// registers + two shuffles over the 4 lanes of a pixel.  The per-thread form above spent a broadcast LDS read per product:
+// 2.0 ms per 128 Cityscapes images and 2 models at alpha 2 (profiles/r03_configs_kernel_stats_cityscapes_a2.csv).
+// Both kernels call probs() below and nothing else, so the stored and the voted probabilities are the same bits.
+template <int NCT /* 16-channel tiles of the input */, int KT /* 16-class tiles */>
+struct HeadMfma {
+    float wa[KT][NCT][4], bias_r[KT][4], sc_r[NCT][4], sh_r[NCT][4];
+
+    __device__ __forceinline__ void load(const float *__restrict__ w /*[cin][K]*/, const float *__restrict__ bias,
+                                         const float *__restrict__ sc, const float *__restrict__ sh, int cin, int cs, int K) {
+        const int lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * g + r, k = 16 * kt + p16;
+                    wa[kt][ct][r] = (c < cin && k < K) ? w[(size_t)c * K + k] : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; bias_r[kt][r] = k < K ? bias[k] : 0.f; }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * g + r;
+                sc_r[ct][r] = c < cs ? sc[c] : 0.f;
+                sh_r[ct][r] = c < cs ? sh[c] : 0.f;
+            }
+    }
+
+    // this lane's 4 channels of every tile of pixel p (cs is a multiple of 8: a lane's 4 channels are all inside or all outside)
+    __device__ __forceinline__ void load_z(const f16 *__restrict__ z, long long p, int cs, f16x4 (&zr)[NCT]) const {
+        const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            zr[ct] = f16x4{0, 0, 0, 0};
+            if (16 * ct + 4 * g < cs) zr[ct] = *reinterpret_cast<const f16x4 *>(z + p * cs + 16 * ct + 4 * g);
+        }
+    }
+
+    // softmax probabilities of the lane's pixel: pr[kt][r] = class 16 kt + 4 g + r (0 for classes >= K)
+    __device__ __forceinline__ void probs(const f16x4 (&zr)[NCT], int K, f32x4 (&pr)[KT]) const {
+        const int g = (threadIdx.x & 63) >> 4;
+        float xf[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xf[ct][r] = (float)(f16)((float)zr[ct][r] * sc_r[ct][r] + sh_r[ct][r]);   // as head_input
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            pr[kt] = f32x4{bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kt][ct][r], xf[ct][r], pr[kt], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * kt + 4 * g + r >= K) pr[kt][r] = -INFINITY;     // padding classes: exp -> 0
+                mx = fmaxf(mx, pr[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[kt][r] = expf(pr[kt][r] - mx); sum += pr[kt][r]; }
+        sum += __shfl_xor(sum, 16, 64);      // (s_g + s_g^1) + (s_g^2 + s_g^3): the same bits on the 4 lanes of a pixel
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[kt][r] *= inv;
+    }
+
+    // arg-max over the K classes of the lane's pixel, the lowest index winning ties (numpy's argmax, functions.py:3225);
+    // the same value on the 4 lanes of the pixel
+    __device__ __forceinline__ int argmax(const f32x4 (&pr)[KT], int K) const {
+        const int g = (threadIdx.x & 63) >> 4;
+        float bv = -1.f;
+        int bk = 0x7fffffff;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kt + 4 * g + r;
+                if (k < K && pr[kt][r] > bv) { bv = pr[kt][r]; bk = k; }     // ascending k within a lane: strict > keeps the first
+            }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int ok = __shfl_xor(bk, o, 64);
+            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        return bk == 0x7fffffff ? 0 : bk;
+    }
+};
+
 // ---- fused head + inconsistency mask (imk_im.hip) -------------------------------------------------------------------------
 #define IMK_HEAD_IM_MAX_MODELS 8
 struct ImkHeadImArgs {

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void im_multi_kernel(
 // straight into the vote.  Per pixel it reads N x cs fp16 + the image and writes image + label map(s) + IM:
 // ISIC 2 x 16 + 3 B in, 5 B out (SURVEY 8d's fused figure) instead of 8 + 3 in / 5 out behind 2 x (16 in, 4 out).
 // A workgroup never straddles two images.  Sigmoid heads: 4 consecutive pixels per thread (1024 per workgroup), all
-// N x 4 activation loads of a thread issued before the first use; softmax heads: one pixel per thread (the K
-// probabilities of a pixel live in an LDS row).
+// N x 4 activation loads of a thread issued before the first use; softmax heads: the matrix-core arithmetic of imk_head.h
+// (HeadMfma), four lanes per pixel.
 template <int NF>
 __device__ __forceinline__ void head_im_finish(const ImkHeadImArgs &a, const uint8_t (*s_final)[BIN_CHUNK], const uint8_t *s_im,
                                                int *s_cnt, const int *cnt_a, const int *cnt_m, bool count_fg, int b, int p_base,
@@ -391,54 +391,60 @@ __global__ __launch_bounds__(256) void head_im_sigmoid_kernel(ImkHeadImArgs a, i
     head_im_finish<KB>(a, s_final, s_im, s_cnt, cnt_a, cnt_m, true, b, p_base, n_px, vec_out, vec_img);
 }
 
-template <int CS>
+// Softmax heads: HeadMfma (imk_head.h) gives every group of 4 lanes the K probabilities of one pixel; a wave takes 64 of
+// the workgroup's 256 pixels (4 units of 16), model after model, and keeps label / agreement per unit in registers.
+template <int NCT, int KT>
 __global__ __launch_bounds__(256) void head_im_softmax_kernel(ImkHeadImArgs a, int vec_out, int vec_img) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // N x head image (imk_head.h), then rows [256][K | 1]
     __shared__ __attribute__((aligned(16))) uint8_t s_final[1][BIN_CHUNK];   // MC_CHUNK bytes used
     __shared__ __attribute__((aligned(16))) uint8_t s_im[BIN_CHUNK];
-    __shared__ uint32_t s_pres[64];
+    __shared__ uint32_t s_pres[IMK_HEAD_IM_MAX_MODELS][64];
     __shared__ int s_cnt[2];
-    const int K = a.K, hw = a.hw;
-    const int per_model = head_lds_floats<CS>(K);
-    float *s_rows = s_dyn + a.n_models * per_model;
-    const int b = blockIdx.y, t = threadIdx.x;
+    const int K = a.K, hw = a.hw, cs = a.cs;
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, p16 = lane & 15, g = lane >> 4;
     const int p_base = blockIdx.x * MC_CHUNK;
     const int n_px = min(MC_CHUNK, hw - p_base);
-    for (int n = 0; n < a.n_models; ++n) head_stage<CS>(a.w[n], a.bias[n], a.sc[n], a.sh[n], a.cin, K, s_dyn + n * per_model);
+    for (int i = t; i < IMK_HEAD_IM_MAX_MODELS * 64; i += 256) (&s_pres[0][0])[i] = 0;
     if (t < 2) s_cnt[t] = 0;
-    const long long p = (long long)b * hw + p_base + t;
-    const bool live = t < n_px;
+    __syncthreads();
     int cnt_a[1] = {0}, cnt_m[1] = {0};
-    int label0 = 0;
-    bool agree = true;
-    float *row = s_rows + t * (K | 1);
+    int label0[4] = {0, 0, 0, 0};
+    bool agree[4] = {true, true, true, true};
     for (int n = 0; n < a.n_models; ++n) {
-        if (t < 64) s_pres[t] = 0;
-        __syncthreads();                 // (first pass: the head images are staged, too)
-        if (live) {
-            float xin[CS];
-            const float *hw_n = s_dyn + n * per_model;
-            head_input<CS>(a.z[n], p, hw_n, K, xin);
-            head_softmax_row<CS>(xin, hw_n, K, row);
-            int best = 0;
-            float bv = row[0];
-            for (int k = 1; k < K; ++k) {        // strict >: the lowest index wins ties, like numpy's argmax
-                const float v = row[k];
-                if (v > bv) { bv = v; best = k; }
-            }
-            s_pres[best] = 1;
-            if (n == 0) label0 = best; else agree = agree && (best == label0);
+        HeadMfma<NCT, KT> h;
+        h.load(a.w[n], a.bias[n], a.sc[n], a.sh[n], a.cin, cs, K);
+        f16x4 zr[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 64 * wave + 16 * u + p16;
+            h.load_z(a.z[n], (long long)b * hw + p_base + (q < n_px ? q : 0), cs, zr[u]);
         }
-        __syncthreads();
-        if (a.presence && t < K && s_pres[t]) a.presence[((size_t)n * a.batch + b) * K + t] = 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 pr[KT];
+            h.probs(zr[u], K, pr);
+            const int best = h.argmax(pr, K);
+            if (g == 0 && 64 * wave + 16 * u + p16 < n_px) s_pres[n][best] = 1;
+            if (n == 0) label0[u] = best; else agree[u] = agree[u] && (best == label0[u]);
+        }
     }
-    if (live) {
-        const uint8_t im = agree ? 0 : 255;
-        s_im[t] = im;
-        s_final[0][t] = (agree && !(a.block_out && im)) ? (uint8_t)label0 : 0;
-        cnt_m[0] = agree ? 0 : 1;
+    if (g == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 64 * wave + 16 * u + p16;
+            if (q < n_px) {
+                const uint8_t im = agree[u] ? 0 : 255;
+                s_im[q] = im;
+                s_final[0][q] = (agree[u] && !(a.block_out && im)) ? (uint8_t)label0[u] : 0;
+                cnt_m[0] += agree[u] ? 0 : 1;
+            }
+        }
     }
     __syncthreads();
+    if (a.presence)
+        for (int i = t; i < a.n_models * 64; i += 256) {
+            const int n = i >> 6, k = i & 63;
+            if (k < K && s_pres[n][k]) a.presence[((size_t)n * a.batch + b) * K + k] = 1;
+        }
     head_im_finish<1>(a, s_final, s_im, s_cnt, cnt_a, cnt_m, false, b, p_base, n_px, vec_out, vec_img);
 }
 
@@ -482,7 +488,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 static size_t head_im_lds(const ImkHeadImArgs &a) {
-    return ((size_t)a.n_models * (a.K * a.cs + a.K + 2 * a.cs) + (a.softmax ? (size_t)MC_CHUNK * (a.K | 1) : 0)) * sizeof(float);
+    if (a.softmax) return 0;      // weights live in registers (HeadMfma)
+    return (size_t)a.n_models * (a.K * a.cs + a.K + 2 * a.cs) * sizeof(float);
 }
 
 bool imk_head_im_supported(const ImkHeadImArgs &a) {
@@ -515,12 +522,16 @@ int imk_launch_head_im(const ImkHeadImArgs &a, hipStream_t stream) {
         KERN<<<grid, 256, lds, stream>>>(a, 1, vec_img2);                                                                   \
     } while (0)
     if (a.softmax) {
-        switch (a.cs) {
-            case 8: IMK_HIM_LAUNCH(head_im_softmax_kernel<8>); break;
-            case 16: IMK_HIM_LAUNCH(head_im_softmax_kernel<16>); break;
-            case 24: IMK_HIM_LAUNCH(head_im_softmax_kernel<24>); break;
-            default: IMK_HIM_LAUNCH(head_im_softmax_kernel<32>); break;
+        const int kt = (a.K + 15) / 16;
+#define IMK_HIM_K(NCT)                                                                                                      \
+        switch (kt) {                                                                                                       \
+            case 1: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 1>)); break;                                                \
+            case 2: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 2>)); break;                                                \
+            case 3: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 3>)); break;                                                \
+            default: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 4>)); break;                                               \
         }
+        if (a.cs <= 16) { IMK_HIM_K(1) } else { IMK_HIM_K(2) }
+#undef IMK_HIM_K
     } else {
         // the reference's ensembles have 2-4 members: 2 and 3 get all their loads hoisted (compile-time N)
 #define IMK_HIM_SIG(CSV, KBV)                                                                                               \

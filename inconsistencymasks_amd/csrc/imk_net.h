@@ -536,13 +536,36 @@ struct Bwd {
 };
 
 // Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
-// Side streams + fork/join events of a plan, created on first use (training: weight gradients; ensemble inference: one
-// model per stream).
+// Side streams (training: weight gradients; ensemble inference: one model per stream) are shared by every plan of the
+// process on a device; the fork / join events are the plan's own.  One pair per PLAN cost 15 % of a SUIM training step
+// in bench.py: three teachers + the student = 8 streams on the runtime's 4 hardware queues, the student's side stream
+// landed on the queue of its main stream and the "concurrent" weight gradients ran in line behind barrier packets
+// (1.99 ms per step; 1.73 with GPU_MAX_HW_QUEUES=8 or with this pool).  Streams created here live as long as the process.
+struct ImkSidePool {
+    std::once_flag once;
+    hipStream_t s[imk_unet_plan::MAX_SIDE] = {};
+    bool ok = false;
+};
+inline ImkSidePool &imk_side_pool() {
+    static ImkSidePool pools[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return pools[dev & 63];
+}
+
 inline bool ensure_side_streams(const imk_unet_plan *plan) {
     std::call_once(plan->side_once, [plan]() {
-        bool ok = true;
+        ImkSidePool &pool = imk_side_pool();
+        std::call_once(pool.once, [&pool]() {
+            bool ok = true;
+            for (auto &st : pool.s) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            pool.ok = ok;
+        });
+        bool ok = pool.ok;
+        static const bool own = []() { const char *e = getenv("IMK_SIDE_POOL"); return e && e[0] == '0'; }();   // A/B: streams per plan (leaked)
         for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
-            ok = ok && hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking) == hipSuccess;
+            plan->side[i] = pool.s[i];
+            if (own) ok = ok && hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
         }
         for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;

@@ -181,8 +181,7 @@ extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) {
     if (!plan) return;
     for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
         if (!plan->side[i]) continue;
-        (void)hipStreamSynchronize(plan->side[i]);
-        (void)hipStreamDestroy(plan->side[i]);
+        (void)hipStreamSynchronize(plan->side[i]);      // the streams belong to the process-wide pool (imk_net.h)
         if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
     }
     for (auto &e : plan->ev_fork) if (e) (void)hipEventDestroy(e);
