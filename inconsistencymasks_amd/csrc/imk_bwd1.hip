@@ -37,9 +37,13 @@ struct Bwd1Args {
     long long n_pix;
 };
 
-template <int LM>
-__global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
+// SMALL: at most 32 channels on both sides (2 x 2 tiles, one k-step) -- the full-resolution layers, where the kernel's time
+// is: 4 instead of 2 weight-gradient partial sums per input-channel tile (every wave works: wave = (tile, half of the
+// tile's 4 k-steps), combined in a fixed order at the end), a quarter of the fragment / accumulator registers.
+template <int LM, bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) {
     constexpr int NPX = 128, H16 = WG_STRIDE_H;
+    constexpr int NF = SMALL ? 2 : 4, NSK = SMALL ? 1 : 2;   // input-channel tiles (= output tiles) and dgrad k-steps at most
     constexpr bool MASK = LM == LM_RAW;
     constexpr int NS = 4;                                   // staging slots per thread and tensor: 128 pixels x 8 chunks / 256
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -54,18 +58,21 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
     stage_affine_table(a.x, s_aff);
 
     // dgrad weight fragments (<= 4 input-channel tiles x <= 2 k-steps), in registers for the whole kernel
-    f16x8 wf[4][2];
+    f16x8 wf[NF][NSK];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NSK; ++s) {
             const bool live = f < a.cit_n && s < a.n_pass;
             wf[f][s] = live ? *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)(f * a.n_pass + s) * 64 + lane) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     // weight-gradient accumulators of this wave: input-channel tile `wave` x 4 output tiles, + the bias row (wave 0)
-    f32x4 accw[4], accb = f32x4{0, 0, 0, 0};
+    // (SMALL: input-channel tile wave & 1, k-steps 2 (wave >> 1) .. + 1 of every pixel tile)
+    f32x4 accw[NF], accb = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int o = 0; o < 4; ++o) accw[o] = f32x4{0, 0, 0, 0};
+    for (int o = 0; o < NF; ++o) accw[o] = f32x4{0, 0, 0, 0};
+    const int wci = SMALL ? (wave & 1) : wave, kk0 = SMALL ? 2 * (wave >> 1) : 0;
+    constexpr int NKK = SMALL ? 2 : 4;
 
     // staging: item i = t + 256 k <-> (pixel i >> 3, chunk i & 7) of the tile, the same for dy / z (chunks of cs_o) and x (of cs_i)
     f16x8 r_dy[NS], r_z[NS];
@@ -126,22 +133,22 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
             const int pix = (wave * 2 + pg) * 16 + n;
-            f32x4 dacc[4];
+            f32x4 dacc[NF];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) dacc[f] = f32x4{0, 0, 0, 0};
+            for (int f = 0; f < NF; ++f) dacc[f] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NSK; ++s) {
                 if (s < a.n_pass) {
                     int c8 = s * a.nc8p + g;
                     if (g >= a.nc8p || c8 >= nco8) c8 = 0;                    // zero weights there: any finite chunk
                     const f16x8 bf = *reinterpret_cast<const f16x8 *>(s_d + ((c8 >> 1) * NPX + pix) * H16 + (c8 & 1) * 8);
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
+                    for (int f = 0; f < NF; ++f)
                         if (f < a.cit_n) dacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][s], bf, dacc[f], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 if (f < a.cit_n) {
                     f16x4 v;
                     const f16x4 xm = *reinterpret_cast<const f16x4 *>(s_x + (f * NPX + pix) * H16 + 4 * g);
@@ -152,18 +159,19 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
             }
         }
         // ---- dW [ci][co] += x^T . dA over the tile's 4 k-steps of 32 pixels: this wave's input-channel tile -----------------
-        if (wave < a.cit_n) {
+        if (wci < a.cit_n) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kq = 0; kq < NKK; ++kq) {
+                const int kk = kk0 + kq;
                 const int row = 2 * kk + (g >> 1), xx = 4 * (g & 1) + qq;      // k-slot <-> pixel map of wgrad_mfma_kernel
-                const f16 *pa = s_x + (wave * NPX + row * 16 + xx) * H16 + 4 * pp;
+                const f16 *pa = s_x + (wci * NPX + row * 16 + xx) * H16 + 4 * pp;
                 const h4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa));
                 const h4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pa + 8 * H16));
                 f16x8 af;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { af[e] = (f16)a0[e]; af[4 + e] = (f16)a1[e]; }
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
+                for (int o = 0; o < NF; ++o) {
                     if (o < a.cot_n) {
                         const f16 *pb = s_d + (o * NPX + row * 16 + xx) * H16 + 4 * pp;
                         const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { bf[e] = (f16)b0[e]; bf[4 + e] = (f16)b1[e]; }
                         accw[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, accw[o], 0, 0, 0);
-                        if (wave == 0) {                     // column sums of dA -> bias gradient: A = ones in row o
+                        if (wci == 0) {                      // column sums of dA -> bias gradient: A = ones in row o
                             f16x8 e1;
 #pragma unroll
                             for (int j = 0; j < 8; ++j) e1[j] = (f16)(n == o ? 1.0f : 0.0f);
@@ -197,10 +205,30 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(Bwd1Args a) {
         tile = next;
     }
     // ---- this workgroup's weight-gradient partial rows: [pair = cit * cot_n + cot][tap 0 | bias][256] -----------------------
-    if (wave < a.cit_n) {
+    if constexpr (SMALL) {      // two partial sums per input-channel tile (waves w and w + 2): combined in that order through LDS
+        float *s_acc = reinterpret_cast<float *>(smem);      // [2 tiles][NF + 1][256]; the slices are dead (last barrier of the loop)
+        if (wave >= 2) {
+#pragma unroll
+            for (int o = 0; o < NF; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[((wci * (NF + 1)) + o) * 256 + r * 64 + lane] = accw[o][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_acc[((wci * (NF + 1)) + NF) * 256 + r * 64 + lane] = accb[r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int o = 0; o < NF; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accw[o][r] += s_acc[((wci * (NF + 1)) + o) * 256 + r * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accb[r] += s_acc[((wci * (NF + 1)) + NF) * 256 + r * 64 + lane];
+        }
+    }
+    if (wave < a.cit_n && (!SMALL || wave < 2)) {
         float *wp = a.wg_partial + (size_t)blockIdx.x * a.cit_n * a.cot_n * 2 * 256;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < NF; ++o) {
             if (o < a.cot_n) {
                 float *dst = wp + ((size_t)(wave * a.cot_n + o) * 2) * 256 + lane;
 #pragma unroll
@@ -221,9 +249,11 @@ bool bwd1_env_on() {
 
 }  // namespace
 
-int imk_bwd1x1_rows(long long n_pix) {
+int imk_bwd1x1_rows(long long n_pix, int cs_in, int cs_out) {
     const long long n_tiles = (n_pix + 127) / 128;
-    return (int)(n_tiles < 512 ? n_tiles : 512);     // 2 workgroups per compute unit (215-235 registers)
+    static const int cap_small = []() { const char *e = getenv("IMK_BWD1X1_ROWS"); return e ? atoi(e) : 768; }();
+    const int cap = (cs_in <= 32 && cs_out <= 32) ? cap_small : 512;   // 3 workgroups per compute unit in the <= 32-channel form, 2 above
+    return (int)(n_tiles < cap ? n_tiles : cap);
 }
 
 // Conv1x1 with 17-64 (padded) channels on both sides, reading a plain fp16 tensor (the ReLU mask of its dgrad) or upsample + add
@@ -243,13 +273,14 @@ int imk_launch_bwd1x1(const ImkInput &x, const f16 *dy, const f16 *z, const floa
     a.cit_n = (a.cs_i + 15) / 16; a.cot_n = (a.cs_o + 15) / 16;
     a.n_pix = (long long)B * H * W;
     if (a.n_pass > 2 || a.cit_n > 4 || a.cot_n > 4) return IMK_EUNSUPPORTED;
-    const int grid = imk_bwd1x1_rows(a.n_pix);
+    const int grid = imk_bwd1x1_rows(a.n_pix, a.cs_i, a.cs_o);
     const size_t lds = (size_t)(8 * 128 * WG_STRIDE_H + 128 * 72) * sizeof(f16) + (3 * (size_t)a.cs_o + 4 * (size_t)a.cs_i) * sizeof(float);
     const double px = (double)a.n_pix;
     const double bytes = px * a.cs_o * 4 + px * a.cs_i * 2 * (x.lmode == LM_UPADD ? 1.25 : 1.0) + px * a.cs_i * 2;
     ImkProfScope prof(PF_WGRAD_GEMM, bytes, stream, 4.0 * px * x.cin * cout);
-    if (x.lmode == LM_RAW) bwd1x1_kernel<LM_RAW><<<grid, 256, lds, stream>>>(a);
-    else if (x.lmode == LM_UPADD) bwd1x1_kernel<LM_UPADD><<<grid, 256, lds, stream>>>(a);
+    const bool small = a.cit_n <= 2 && a.cot_n <= 2 && a.n_pass == 1;
+    if (x.lmode == LM_RAW) { if (small) bwd1x1_kernel<LM_RAW, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_RAW, false><<<grid, 256, lds, stream>>>(a); }
+    else if (x.lmode == LM_UPADD) { if (small) bwd1x1_kernel<LM_UPADD, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_UPADD, false><<<grid, 256, lds, stream>>>(a); }
     else return IMK_EUNSUPPORTED;
     IMK_LAUNCH_CHECK();
     return IMK_OK;

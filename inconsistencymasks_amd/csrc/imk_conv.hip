@@ -2007,8 +2007,8 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
     }
     // a Conv1x1 with 24-64 channels on both sides may get it from the fused backward kernel (imk_bwd1.hip): one row per workgroup
     if (ksize == 1 && imk_pad8(cin) >= 24 && imk_pad8(cin) <= 64 && imk_pad8(cout) >= 24 && imk_pad8(cout) <= 64 &&
-        ns < (size_t)imk_bwd1x1_rows((long long)B * H * W))
-        ns = (size_t)imk_bwd1x1_rows((long long)B * H * W);
+        ns < (size_t)imk_bwd1x1_rows((long long)B * H * W, imk_pad8(cin), imk_pad8(cout)))
+        ns = (size_t)imk_bwd1x1_rows((long long)B * H * W, imk_pad8(cin), imk_pad8(cout));
     // a softmax output layer may get its weight gradient from the fused head kernel (imk_headf.hip): one row per workgroup
     if (ksize == 1 && n_pairs <= 8 && ns < (size_t)imk_loss_blocks((long long)B * H * W)) ns = (size_t)imk_loss_blocks((long long)B * H * W);
     return (ns + (ns + WG_RED_CHUNK - 1) / WG_RED_CHUNK) * n_pairs * (T + 1) * 256;  // partials + stage-1 scratch

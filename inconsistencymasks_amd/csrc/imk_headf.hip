@@ -27,7 +27,7 @@ struct HeadCceArgs {
     const f16 *z;                 // [n_pix][CS] last decoder activation (pre-BatchNorm)
     const float *sc, *sh;         // its BatchNorm scale / shift (batch statistics) [CS]
     const float *w, *bias;        // output layer: kernel [cin][K] fp32, bias [K]
-    int cin, K;
+    int cin, cs, K;               // cs: channel stride of z / dy (8, 16, 24 or 32; the kernel's CS = 16 or 32 is its tile capacity)
     long long n_pix;
     const uint8_t *y;             // class ids [n_pix]
     const ImkCtl *ctl;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int c = 16 * ct + 4 * g + r; sc_r[ct][r] = a.sc[c]; sh_r[ct][r] = a.sh[c]; }
+        for (int r = 0; r < 4; ++r) { const int c = 16 * ct + 4 * g + r; sc_r[ct][r] = c < a.cs ? a.sc[c] : 0.f; sh_r[ct][r] = c < a.cs ? a.sh[c] : 0.f; }
 
     f32x4 accw[NCT][KT], accb = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
             ok[u] = px < a.n_pix;
             const long long pc = ok[u] ? px : a.n_pix - 1;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) zr[u][ct] = *reinterpret_cast<const f16x4 *>(a.z + pc * CS + 16 * ct + 4 * g);
+            for (int ct = 0; ct < NCT; ++ct) {
+                zr[u][ct] = f16x4{0, 0, 0, 0};
+                if (16 * ct + 4 * g < a.cs) zr[u][ct] = *reinterpret_cast<const f16x4 *>(a.z + pc * a.cs + 16 * ct + 4 * g);
+            }
             yv[u] = a.y[pc];
         }
 #pragma unroll
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
                     s1[ct][r] += f;
                     s2[ct][r] += f * (float)zr[u][ct][r];
                 }
-                if (ok[u]) *reinterpret_cast<f16x4 *>(a.dy + (grp * 64 + u * 16 + p16) * CS + 16 * ct + 4 * g) = dh;
+                if (ok[u] && 16 * ct + 4 * g < a.cs) *reinterpret_cast<f16x4 *>(a.dy + (grp * 64 + u * 16 + p16) * a.cs + 16 * ct + 4 * g) = dh;
             }
             // LDS image for the weight gradient: pixel u * 16 + p16, this lane's 4 channels / 4 classes of every tile
 #pragma unroll
@@ -263,8 +266,11 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
         }
     if (lane == 0) s_st[wave * (2 * CS + 1) + 2 * CS] = loss;
     __syncthreads();
-    if (t < 2 * CS) a.dystat_partial[(size_t)blockIdx.x * 2 * CS + t] =
-        (s_st[t] + s_st[(2 * CS + 1) + t]) + (s_st[2 * (2 * CS + 1) + t] + s_st[3 * (2 * CS + 1) + t]);
+    if (t < 2 * a.cs) {           // rows of the statistics are [2][cs]
+        const int which = t >= a.cs, q = which * CS + (t - which * a.cs);
+        a.dystat_partial[(size_t)blockIdx.x * 2 * a.cs + t] =
+            (s_st[q] + s_st[(2 * CS + 1) + q]) + (s_st[2 * (2 * CS + 1) + q] + s_st[3 * (2 * CS + 1) + q]);
+    }
     if (t == 0) a.loss_partial[blockIdx.x] = (s_st[2 * CS] + s_st[(2 * CS + 1) + 2 * CS]) + (s_st[2 * (2 * CS + 1) + 2 * CS] + s_st[3 * (2 * CS + 1) + 2 * CS]);
     // weight-gradient partial rows of this workgroup: [pair = ct * cot_n + kt][tap 0 | bias row][256]
     float *wp = a.wg_partial + (size_t)blockIdx.x * NCT * a.cot_n * 2 * 256;
@@ -287,10 +293,10 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
 
 }  // namespace
 
-// Softmax heads with 16 or 32 (padded) input channels and up to 64 classes.  `rows_cap`: capacity (rows) of dystat_partial.
+// Softmax heads with 8 ... 32 (padded) input channels and up to 64 classes.  `rows_cap`: capacity (rows) of dystat_partial.
 bool imk_head_cce_fused_ok(int cs, int K, long long n_pix, int rows_cap) {
     static const bool off = []() { const char *e = getenv("IMK_HEAD_FUSE"); return e && e[0] == '0'; }();
-    if (off || (cs != 16 && cs != 32) || K < 2 || K > 64) return false;
+    if (off || (cs != 8 && cs != 16 && cs != 24 && cs != 32) || K < 2 || K > 64) return false;
     return imk_loss_blocks(n_pix) <= rows_cap;
 }
 
@@ -299,17 +305,17 @@ int imk_head_cce_fused_rows(long long n_pix) { return imk_loss_blocks(n_pix); }
 int imk_launch_head_cce_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                               int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
                               float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream) {
-    HeadCceArgs a{z, sc, sh, w, bias, cin, K, n_pix, y, ctl, stats, dy, loss_partial, dystat_partial, wg_partial,
+    HeadCceArgs a{z, sc, sh, w, bias, cin, cs, K, n_pix, y, ctl, stats, dy, loss_partial, dystat_partial, wg_partial,
                   (imk_pad8(K) + 15) / 16};
-    const int kt = (K + 15) / 16, nct = cs / 16;
+    const int kt = (K + 15) / 16, csv = cs <= 16 ? 16 : 32, nct = csv / 16;
     const int grid = imk_loss_blocks(n_pix);
     const size_t img = (size_t)4 * (nct + kt) * 64 * WG_STRIDE_H * sizeof(f16);
-    const size_t red = ((size_t)4 * (nct * kt + 1) * 256 + 4 * (2 * cs + 1)) * sizeof(float);
+    const size_t red = ((size_t)4 * (nct * kt + 1) * 256 + 4 * (2 * csv + 1)) * sizeof(float);
     const size_t lds = img > red ? img : red;
     ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + 1 + cs * 2), stream, 6.0 * n_pix * cin * K);
 #define IMK_HF(CSV, KTV) head_cce_fused_kernel<CSV, KTV><<<grid, 256, lds, stream>>>(a)
 #define IMK_HF_KT(CSV) do { if (kt == 1) IMK_HF(CSV, 1); else if (kt == 2) IMK_HF(CSV, 2); else if (kt == 3) IMK_HF(CSV, 3); else IMK_HF(CSV, 4); } while (0)
-    if (cs == 16) IMK_HF_KT(16); else if (cs == 32) IMK_HF_KT(32); else return IMK_EUNSUPPORTED;
+    if (csv == 16) IMK_HF_KT(16); else IMK_HF_KT(32);
 #undef IMK_HF_KT
 #undef IMK_HF
     IMK_LAUNCH_CHECK();

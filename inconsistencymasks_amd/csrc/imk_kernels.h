@@ -123,7 +123,7 @@ inline double imk_wgrad_flops(const ImkWgradArgs &a) {   // 2 * pixels * taps * 
 }
 // Conv1x1 (+ ReLU, + BatchNorm behind it) with 24-64 channels on both sides: dgrad and weight gradient in one kernel (imk_bwd1.hip)
 bool imk_bwd1x1_ok(int lmode, int cs_in, int cs_out, bool masked);
-int imk_bwd1x1_rows(long long n_pix);       // workgroups = weight-gradient partial rows
+int imk_bwd1x1_rows(long long n_pix, int cs_in, int cs_out);       // workgroups = weight-gradient partial rows
 int imk_launch_bwd1x1(const ImkInput &x, const f16 *dy, const f16 *z, const float *coef, const f16 *wpk_bwd, f16 *dx,
                       float *wg_partial, int B, int H, int W, int cout, hipStream_t stream);
 int imk_wgrad_splits(int B, int H, int W, int cin, int cout);

@@ -455,7 +455,7 @@ struct Bwd {
             ((l.lmode == LM_RAW && mask && mask == c.act(l.src)) || (l.lmode == LM_UPADD && !mask)) &&
             imk_bwd1x1_ok(l.lmode, imk_pad8(l.cin), imk_pad8(l.cout), mask != nullptr)) {
             const Dim d = res_dim(c.p->cfg, l.res);
-            const int rows = imk_bwd1x1_rows((long long)c.B * d.h * d.w);
+            const int rows = imk_bwd1x1_rows((long long)c.B * d.h * d.w, imk_pad8(l.cin), imk_pad8(l.cout));
             float *wgp = reinterpret_cast<float *>(c.base + c.ws.L[conv].wg_partial);
             const int bn = l.bn_after;
             int rc = imk_launch_bwd1x1(conv_input(c, conv), c.dy(bn), c.act(conv), reinterpret_cast<const float *>(c.base + c.ws.L[bn].coef),
