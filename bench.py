@@ -495,12 +495,18 @@ def main():
         ps, ims, keep = im_stage(x_unl)
         e1.record()
         # training set = kept pseudo-labelled pairs + labelled pairs (the directory the reference builds)
+        if use_dist and world > 1:   # every rank must run the same number of gradient all-reduces: the smallest shard decides.
+            # Issued BEFORE the keep rule's host sync below, so that the agreed count is there when the host wakes up: one
+            # host round trip per generation, not two
+            if cfg["keep_rule"]:
+                steps_cap.copy_(((keep.sum() + n_lab) // BATCH).reshape(1))
+            else:
+                steps_cap.fill_((U + n_lab) // BATCH)
+            dist.all_reduce(steps_cap, op=dist.ReduceOp.MIN)
         src = torch.cat([torch.nonzero(keep).squeeze(1), lab_idx]) if cfg["keep_rule"] else None
         n_train = src.shape[0] if src is not None else U + n_lab         # (the nonzero above is the keep rule's one host sync)
         steps = n_train // BATCH
-        if use_dist and world > 1:   # every rank must run the same number of gradient all-reduces: the smallest shard decides
-            steps_cap.fill_(steps)
-            dist.all_reduce(steps_cap, op=dist.ReduceOp.MIN)
+        if use_dist and world > 1:
             steps = int(steps_cap.item())
         student.params.copy_(init_params)
         student._packed_ok = False

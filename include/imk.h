@@ -12,9 +12,12 @@
  *     (a hipStream_t passed as void*; NULL = the null stream) and the caller owns every buffer until
  *     it has synchronised that stream;
  *   - all pointers are DEVICE pointers unless a parameter says "host";
- *   - compute entry points keep no global state; a PLAN owns one set of side streams / events, so one plan must not be
- *     driven from two host threads at the same time (use one plan per thread; plans are cheap).  The debug and measurement
- *     hooks at the end of this file (imk_debug_*, imk_prof_*) are process-global switches and are not thread-safe.
+ *   - compute entry points keep no mutable global state; a PLAN owns its fork / join events, so one plan must not be
+ *     driven from two host threads at the same time (use one plan per thread; plans are cheap).  The side streams the
+ *     training step and the ensemble forward fork onto are created once per device and shared by every plan of the
+ *     process (more streams than the runtime has hardware queues serialise behind each other); they are never destroyed.
+ *     The debug switches at the end of this file act on ONE plan (imk_unet_plan_debug); the measurement context
+ *     (imk_prof_*) is created and owned by the caller and bound to the launching thread.
  *   - images and masks are uint8, NHWC; probabilities float32 NHWC; sizes int64.
  */
 #ifndef IMK_H
