@@ -922,7 +922,12 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // gradient here.  Before round 2 these layers ran on the per-tile kernel (one tile per workgroup, weights re-copied per
 // tile, no overlap of staging and MFMAs): 2.3x the step time from alpha 1 to 1.25 for 1.56x the flops.
 // =====================================================================================================
-template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL>
+// CHAIN2 (inference; round 3): the block's Conv1x1+ReLU (at most 32 output channels) as a second stage on the 3x3's output tile,
+// which never leaves the chip.  Each wave parks its 64 pixels x 32 channels in a private LDS slab ([pixel][32 + 8] halfs: the
+// 16-byte reads of 16 pixels hit 64 different banks) and reads them back as the B operand of one more MFMA per output tile --
+// the k order of the 1x1's regular forward pack, so the result is bit-identical to the two launches.  Replaces the per-tile
+// chain (conv_mfma_kernel<..., CHAIN>) for these widths: persistent workgroups, next tile's loads in flight, weights staged once.
+template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL, bool CHAIN2 = false>
 __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, int grid_q, int grid_r) {
     constexpr int P = 4;
@@ -939,7 +944,9 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);        // up to 4 x 32 floats (LM_UPADD)
     float *s_red = s_aff + 4 * 32;                                             // [4 waves][2][16 * MT]
     f16 *s_w = reinterpret_cast<f16 *>(s_red + 4 * 2 * 16 * MT);               // [MT][ns][512]
+    constexpr int MIDP = 40;                                                   // halfs per pixel of the chain's slab
     const int t = threadIdx.x;
+    f16 *s_mid = s_w + (size_t)MT * ns * 512 + (t >> 6) * 64 * MIDP;           // CHAIN2: this wave's [64 pixels][MIDP]
     IMK_STAMP_BEGIN(conv, 50000 + LM * 1000 + MT * 10 + (DYSTAT ? 1 : 0));
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int H = a.H, W = a.W;
@@ -988,10 +995,24 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
             const int co = 16 * m + 4 * g + r;
             bias[m][r] = (EPI == EP_RELU && a.bias && co < a.cout) ? a.bias[co] : 0.f;
         }
-    const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);
+    const bool want_stats = !CHAIN2 && (DYSTAT || ((EPI == EP_RELU) && a.stats_partial));
     bool lane_out[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) lane_out[m] = 16 * m + 4 * g < a.cs_out;      // this lane's 4 channels exist in the output tensor
+    // CHAIN2: the 1x1's A fragments (its regular forward pack: [channel tile][k-step 0][lane][8]), bias, output geometry
+    f16x8 a2[2] = {f16x8{0, 0, 0, 0, 0, 0, 0, 0}, f16x8{0, 0, 0, 0, 0, 0, 0, 0}};
+    float bias2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    bool lane_out2[2] = {false, false};
+    const unsigned cso2_b = CHAIN2 ? (unsigned)a.cs_out2 * 2u : 0u;
+    if constexpr (CHAIN2) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (16 * m < a.cout2) a2[m] = *reinterpret_cast<const f16x8 *>(a.wpk2 + ((size_t)m * 64 + lane) * 8);
+            lane_out2[m] = 16 * m + 4 * g < a.cs_out2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int co = 16 * m + 4 * g + r; bias2[m][r] = co < a.cout2 ? a.bias2[co] : 0.f; }
+        }
+    }
 
     float s1[MT][4], s2[MT][4];
 #pragma unroll
@@ -1033,19 +1054,19 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
             }
         }
         __syncthreads();
-        const char *b_o1 = pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, cso_b);
+        const char *b_o1 = CHAIN2 ? pix_base(a.out2, tc.b, H, W, tc.ty0, tc.tx0, cso2_b) : pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, cso_b);
         const char *b_mk = EPI == EP_MASK ? pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
         const char *b_zq = DYSTAT ? pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
-        unsigned o1[P];
+        unsigned o1[P];        // byte offset of the lane's pixels in the tensor this launch writes (CHAIN2: the 1x1's output)
         bool inb[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if constexpr (FULL) {
-                o1[p] = o1c[p]; inb[p] = true;
+                o1[p] = CHAIN2 ? (unsigned)((wave * 4 + p) * W + n) * cso2_b : o1c[p]; inb[p] = true;
             } else {        // partial tiles clamp the coordinates used for LOADS (stores are guarded)
                 const int my = H - 1 - tc.ty0, mx = W - 1 - tc.tx0, r = wave * 4 + p;
                 inb[p] = r <= my && n <= mx;
-                o1[p] = __umul24(__umul24(min(r, my), W) + min(n, mx), cso_b);
+                o1[p] = __umul24(__umul24(min(r, my), W) + min(n, mx), CHAIN2 ? cso2_b : cso_b);
             }
         }
         f16x4 mk[MT][P], zq[MT][P];
@@ -1083,6 +1104,38 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                 }
             }
         }
+        if constexpr (CHAIN2) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f16x4 v = {0, 0, 0, 0};
+                    if (m < MT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[m < MT ? m : 0][p][r] + bias[m < MT ? m : 0][r], 0.f);
+                    }
+                    *reinterpret_cast<f16x4 *>(s_mid + (p * 16 + n) * MIDP + 16 * m + 4 * g) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const f16x8 bf2 = *reinterpret_cast<const f16x8 *>(s_mid + (p * 16 + n) * MIDP + 8 * g);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (16 * m < a.cs_out2) {
+                        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[m], bf2, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                        f16x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(d[r] + bias2[m][r], 0.f);
+                        if ((FULL || inb[p]) && lane_out2[m]) *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p] + 32 * m + 8 * g) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1109,6 +1162,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                     }
                 }
             }
+        }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
         tc = tn;
@@ -1794,12 +1848,13 @@ static int launch_conv_pipe_any(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_PIPE_SEL
 }
 
-template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL>
+template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL, bool CHAIN2 = false>
 static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;
     const int ns = ((a.ksize == 3 ? 9 : 1) * NC8 + 3) / 4;
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 32 + 4 * 2 * 16 * MT) * sizeof(float) + (size_t)MT * ns * 1024;
-    auto kern = conv_wide_kernel<LM, NC8, MT, EPI, DYSTAT, FULL>;
+    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 32 + 4 * 2 * 16 * MT) * sizeof(float) + (size_t)MT * ns * 1024 +
+                       (CHAIN2 ? (size_t)4 * 64 * 40 * sizeof(f16) : 0);
+    auto kern = conv_wide_kernel<LM, NC8, MT, EPI, DYSTAT, FULL, CHAIN2>;
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
@@ -1848,6 +1903,31 @@ static bool conv_wide_ok(const ImkConvArgs &a) {
     if (a.x.lmode == LM_POOL || a.x.lmode == LM_STEM) return false;
     if (a.x.lmode == LM_U8 && a.x.cin > 4) return false;
     return true;
+}
+
+// Conv3x3+ReLU -> Conv1x1+ReLU in one launch of the wide kernel (inference: the intermediate is not stored, no statistics)
+static bool conv_wide_chain_ok(const ImkConvArgs &a) {
+    static const bool off = []() { const char *e = getenv("IMK_WIDE_CHAIN"); return e && e[0] == '0'; }();
+    if (off || !a.wpk2 || a.out || a.stats_partial || a.epi != EP_RELU || a.ksize != 3) return false;
+    if (a.x.cs_in < 16 || a.x.cs_in > 32 || a.cout > 32 || a.cout2 > 32 || (a.x.cs_in <= 16 && a.cout <= 16)) return false;
+    if (a.x.lmode != LM_AFFINE) return false;     // (the pooled-input form, alpha 1's second encoder block, gains nothing: 1.170 vs 1.166 ms)
+    ImkConvArgs plain = a;
+    plain.wpk2 = nullptr;
+    return conv_wide_ok(plain);
+}
+static int launch_conv_wide_chain(const ImkConvArgs &a, hipStream_t stream) {
+    const bool full = (a.H % 16 == 0) && (a.W % TW == 0);
+    const int nc8 = a.x.cs_in / 8;
+    const bool mt2 = a.cout > 16;
+#define IMK_WC(NC8V, MTV) (full ? launch_conv_wide_k<LM_AFFINE, NC8V, MTV, EP_RELU, false, true, true>(a, stream)  \
+                                : launch_conv_wide_k<LM_AFFINE, NC8V, MTV, EP_RELU, false, false, true>(a, stream))
+    switch (nc8) {
+        case 2: return mt2 ? IMK_WC(2, 2) : IMK_EUNSUPPORTED;
+        case 3: return mt2 ? IMK_WC(3, 2) : IMK_WC(3, 1);
+        case 4: return mt2 ? IMK_WC(4, 2) : IMK_WC(4, 1);
+        default: return IMK_EUNSUPPORTED;
+    }
+#undef IMK_WC
 }
 
 static int launch_conv_wide_any(const ImkConvArgs &a, hipStream_t stream) {
@@ -1972,6 +2052,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
         if (a.epi != EP_RELU || !a.out2 || !a.bias2 || a.cs_out2 % 8) return IMK_EUNSUPPORTED;
         if (pipe_ok) return a.cout2 > 16 ? IMK_EUNSUPPORTED : launch_conv_pipe_any(a, stream);
         if (!imk_conv_can_chain_tile(a, a.cout2, a.out != nullptr)) return IMK_EUNSUPPORTED;
+        if (conv_wide_chain_ok(a)) return launch_conv_wide_chain(a, stream);
         return launch_conv_mfma(a, stream);
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);
