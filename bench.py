@@ -513,12 +513,11 @@ def main():
         student.init_train_state()
         perm = torch.randperm(n_train, device=dev, generator=gen_perm)
         src = src[perm] if src is not None else perm
-        tx = pool_x[src]                     # the epoch's shuffle and the keep filter as one gather; batches are contiguous views
-        if binary:
-            ty = pool_y[src].permute(0, 2, 3, 1) // 255                      # parse_image_*: 255 -> 1
-            ty = (ty * pos_w if K == 3 else ty).contiguous()
-        else:
-            ty = pool_y[src][:, 0].contiguous()
+        # the epoch's shuffle, the keep filter and the parsers' mask normalisation (255 -> 1, HeLa position x 3) as ONE gather per
+        # tensor inside libimk (imk_gather_pairs); batches are contiguous views of the result
+        tx, ty = F.gather_pairs(src, img=pool_x, mask_planar=pool_y, div255=binary, mul=pos_w if (binary and K == 3) else None)
+        if not binary:
+            ty = ty[..., 0]                  # [n, H, W, 1] class ids: a view
         for s in range(steps):
             student.fwd_bwd(tx[s * BATCH:(s + 1) * BATCH], ty[s * BATCH:(s + 1) * BATCH], LOSS)
             scale = F._grad_allreduce(student)

@@ -214,6 +214,19 @@ typedef struct imk_aug_params {   /* one per image, device array */
     uint32_t seed;                /* per-image seed of the counter-based noise generator */
 } imk_aug_params;
 
+/* Epoch assembly of a training set that lives in HBM: row r of the outputs = row idx[r] of the inputs -- the shuffle + batch of
+ * the reference's tf.data pipeline (functions.py:207-209) with the mask normalisation of its parsers folded in
+ * (parse_image_ISIC_2018: mask / 255, functions.py:975; parse_image_hela: / 255 and position x Position_weight,
+ * functions.py:1001-1011).
+ *   img   [n_src, row_img] uint8 (any layout; a row is copied as it is)            -> img_out  [n, row_img]     (img may be NULL)
+ *   mask  [n_src, planes, hw] uint8, planar (as imk_im_binary / imk_unet_forward_im write label maps)
+ *                                                                                   -> mask_out [n, hw, planes], interleaved,
+ *         every value v -> (div255 ? v / 255 : v) * (mul ? mul[plane] : 1)  (mul: device, [planes])   (mask may be NULL)
+ *   idx   device, int64 [n]; n <= 65535.  Outputs must not alias inputs. */
+IMK_API int imk_gather_pairs(const uint8_t *img, int64_t row_img, const uint8_t *mask, int planes, int64_t hw, int div255,
+                             const uint8_t *mul, const int64_t *idx, int64_t n, uint8_t *img_out, uint8_t *mask_out,
+                             void *stream);
+
 /* Replaces augment_image_and_mask (functions.py:2779-2826) + add_noise_and_blur (:1481-1506) for a batch.
  *   img  [B,H,W,C] u8 -> img_out;  mask [B,H,W,Cm] u8 (or NULL) -> mask_out (geometric part only).
  * 90-degree turns need h == w (set any_quarter_turn if any params[i].rot is 1 or 3).  Not in place. */

@@ -71,6 +71,7 @@ SIGNATURES = {
                                         ctypes.POINTER(c_int)]),
     "imk_evalnet_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "imk_gather_pairs": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "imk_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "imk_eval_binary": (c_int, [c_void_p, c_float, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imk_eval_multiclass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -96,7 +96,72 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t *__restrict_
         for (int c = 0; c < Cm; ++c) mask_out[((size_t)b * Ho * Wo + p) * Cm + c] = mask[src_index(yo, xo) * Cm + c];
 }
 
+// ---- epoch assembly of a device-resident training set ------------------------------------------------------------------
+// dst row r = src row idx[r]: the shuffle + batch of the reference's tf.data pipeline (functions.py:207-209) over a set that
+// already lives in HBM, with the mask normalisation of its parsers folded in (parse_image_ISIC_2018: mask / 255,
+// functions.py:975; parse_image_hela: / 255, position x Position_weight, functions.py:1001-1011).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t *__restrict__ src, const int64_t *__restrict__ idx,
+                                                          uint8_t *__restrict__ dst, int64_t row_bytes, int vec) {
+    const int64_t r = blockIdx.y;
+    const uint8_t *s = src + idx[r] * row_bytes;
+    uint8_t *d = dst + r * row_bytes;
+    if (vec) {
+        const int64_t n16 = row_bytes / 16;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(s)[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    }
+}
+// planar [n_src][planes][hw] -> interleaved [n][hw][planes], v -> (div255 ? v / 255 : v) * mul[plane]
+__global__ __launch_bounds__(256) void gather_planes_kernel(const uint8_t *__restrict__ src, const int64_t *__restrict__ idx,
+                                                            uint8_t *__restrict__ dst, int planes, int64_t hw, int div255,
+                                                            const uint8_t *__restrict__ mul) {
+    const int64_t r = blockIdx.y;
+    const uint8_t *s = src + idx[r] * planes * hw;
+    uint8_t *d = dst + r * planes * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+        for (int k = 0; k < planes; ++k) {
+            unsigned v = s[(int64_t)k * hw + i];
+            if (div255) v /= 255u;
+            if (mul) v *= mul[k];
+            d[i * planes + k] = (uint8_t)v;
+        }
+}
+
 }  // namespace
+
+extern "C" int imk_gather_pairs(const uint8_t *img, int64_t row_img, const uint8_t *mask, int planes, int64_t hw, int div255,
+                                const uint8_t *mul, const int64_t *idx, int64_t n, uint8_t *img_out, uint8_t *mask_out,
+                                void *stream_) {
+    IMK_CHECK_ARG(idx && n > 0 && (img || mask));
+    IMK_CHECK_ARG(!img || (img_out && row_img > 0 && img != img_out));
+    IMK_CHECK_ARG(!mask || (mask_out && planes > 0 && hw > 0 && mask != mask_out));
+    if (n > 65535) return IMK_EUNSUPPORTED;      // rows ride on gridDim.y
+    hipStream_t stream = (hipStream_t)stream_;
+    auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (img) {
+        const int vec = row_img % 16 == 0 && a16(img) && a16(img_out);
+        const int64_t work = vec ? row_img / 16 : row_img;
+        const int bx = (int)(work / 256 < 1 ? 1 : (work / 256 > 64 ? 64 : work / 256));
+        gather_rows_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(img, idx, img_out, row_img, vec);
+        IMK_LAUNCH_CHECK();
+    }
+    if (mask) {
+        if (planes == 1 && !div255 && !mul) {
+            const int64_t row = hw;
+            const int vec = row % 16 == 0 && a16(mask) && a16(mask_out);
+            const int64_t work = vec ? row / 16 : row;
+            const int bx = (int)(work / 256 < 1 ? 1 : (work / 256 > 64 ? 64 : work / 256));
+            gather_rows_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(mask, idx, mask_out, row, vec);
+        } else {
+            const int bx = (int)(hw / 256 < 1 ? 1 : (hw / 256 > 64 ? 64 : hw / 256));
+            gather_planes_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(mask, idx, mask_out, planes, hw, div255, mul);
+        }
+        IMK_LAUNCH_CHECK();
+    }
+    return IMK_OK;
+}
 
 extern "C" int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, int h, int w, int c, int cm,
                            const imk_aug_params *params, uint8_t *img_out, uint8_t *mask_out, int any_quarter_turn,

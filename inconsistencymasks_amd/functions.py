@@ -525,6 +525,34 @@ def parse_image_multiclass(image_path, n_classes, image_channels=3):
     return image, mask
 
 
+def gather_pairs(idx, img=None, mask_planar=None, div255=False, mul=None):
+    """Rows idx of a device-resident set in one libimk launch per tensor (imk_gather_pairs): what list_files(shuffle).map(parse)
+    .batch() delivers per epoch (functions.py:207-209) when the files already sit in HBM.  img [N, ...] uint8 -> [n, ...];
+    mask_planar [N, P, H, W] uint8 (as the IM kernels write label maps) -> [n, H, W, P] with v -> (v / 255 if div255) * mul[p]
+    (parse_image_ISIC_2018 / parse_image_hela, functions.py:975, 1001-1011).  Returns (img_out, mask_out); absent ones are None."""
+    idx = idx.to(torch.int64).contiguous()
+    n = int(idx.shape[0])
+    out_i = out_m = None
+    for lo in range(0, n, 65535):          # the row index rides on gridDim.y
+        hi = min(n, lo + 65535)
+        if img is not None:
+            if out_i is None:
+                out_i = torch.empty((n,) + tuple(img.shape[1:]), dtype=torch.uint8, device=img.device)
+            row = int(img[0].numel())
+        if mask_planar is not None:
+            if out_m is None:
+                N, P, H, W = mask_planar.shape
+                out_m = torch.empty((n, H, W, P), dtype=torch.uint8, device=mask_planar.device)
+        check(lib.imk_gather_pairs(img.data_ptr() if img is not None else None, row if img is not None else 0,
+                                   mask_planar.data_ptr() if mask_planar is not None else None,
+                                   int(mask_planar.shape[1]) if mask_planar is not None else 0,
+                                   int(mask_planar.shape[2] * mask_planar.shape[3]) if mask_planar is not None else 0,
+                                   1 if div255 else 0, mul.data_ptr() if mul is not None else None, idx[lo:hi].data_ptr(), hi - lo,
+                                   out_i[lo:hi].data_ptr() if out_i is not None else None,
+                                   out_m[lo:hi].data_ptr() if out_m is not None else None, _stream()), "imk_gather_pairs")
+    return out_i, out_m
+
+
 class _EpochLoader:
     """list_files(seed).map(parse).batch(B).repeat(): seeded shuffle per pass, one short batch per pass
     (functions.py:207-209), PNG decode on a thread pool, whole set cached on the device after the first pass."""
@@ -548,7 +576,8 @@ class _EpochLoader:
             self._load()
         if not self._order:      # new pass: one shuffled copy of the set, batches are contiguous views of it
             perm = torch.as_tensor(self.rng.permutation(len(self.files)), device="cuda")
-            self._px, self._py = self.x[perm], self.y[perm]
+            self._px, _ = gather_pairs(perm, img=self.x)           # the epoch's shuffle: one libimk launch per tensor
+            self._py, _ = gather_pairs(perm, img=self.y)
             self._order = [(i, min(i + self.batch, len(perm))) for i in range(0, len(perm), self.batch)]
         lo, hi = self._order.pop(0)
         return self._px[lo:hi], self._py[lo:hi]

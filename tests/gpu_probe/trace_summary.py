@@ -12,7 +12,7 @@ rows.sort()
 # start of a forward: the uint8 stem (training) or the first encoder conv with the input block on load (inference, LM_STEM = 6)
 stems = [i for i, r in enumerate(rows) if re.match(r"conv_(pipe|wide)_kernel<\(ImkLoadMode\)[46]|conv_(pipe|wide)_kernel<[46]", r[2])]   # wide: alpha > 1
 folds = [i for i, r in enumerate(rows) if r[2].startswith("pack_conv_batched_kernel")]   # end of an optimizer step
-heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2]]                          # end of an inference call
+heads = [i for i, r in enumerate(rows) if "head_kernel" in r[2] or "head_softmax_kernel" in r[2]]                          # end of an inference call
 def show(seg, title):
     t0 = seg[0][0]
     span = (seg[-1][1] - t0) / 1e3

@@ -63,3 +63,27 @@ def test_augment_rejects_quarter_turn_of_non_square():
     prm[0].rot = 1
     with pytest.raises(_lib.ImkError):
         augment.augment_batch(torch.zeros((1, 8, 16, 3), dtype=torch.uint8, device="cuda"), None, prm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("planes,hw_shape,c", [(1, (16, 16), 3), (3, (24, 40), 1), (1, (5, 7), 3)])
+def test_gather_pairs_is_an_indexed_copy_with_the_parsers_mask_arithmetic(planes, hw_shape, c):
+    """imk_gather_pairs = x[idx] and (mask[idx] // 255 * mul) moved to NHWC: the shuffle + parse of the reference's tf.data
+    pipeline over a device-resident set (functions.py:207-209, 975, 1001-1011), bit for bit against torch indexing."""
+    import torch
+    from inconsistencymasks_amd import functions as F
+    g = torch.Generator(device="cuda").manual_seed(5)
+    H, W = hw_shape
+    x = torch.randint(0, 256, (37, H, W, c), dtype=torch.uint8, device="cuda", generator=g)
+    m = (torch.randint(0, 2, (37, planes, H, W), dtype=torch.uint8, device="cuda", generator=g) * 255)
+    idx = torch.randperm(37, device="cuda", generator=g)[:29]
+    mul = torch.tensor([1, 1, 3][:planes], dtype=torch.uint8, device="cuda") if planes == 3 else None
+    gx, gm = F.gather_pairs(idx, img=x, mask_planar=m, div255=True, mul=mul)
+    want_m = m[idx].permute(0, 2, 3, 1) // 255
+    if mul is not None:
+        want_m = want_m * mul
+    assert torch.equal(gx, x[idx]) and torch.equal(gm, want_m.contiguous())
+    # class-id maps: no arithmetic, one plane
+    ids = torch.randint(0, 35, (37, 1, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    _, gi = F.gather_pairs(idx, mask_planar=ids)
+    assert torch.equal(gi[..., 0], ids[idx][:, 0])
