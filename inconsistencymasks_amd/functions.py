@@ -985,8 +985,11 @@ def get_pos_contours(img, erode_kernel=3):
     """functions.py:6181-6218: centres (x, y) of the blobs of a position mask.  The reference erodes, thresholds at 10,
     takes cv2.findContours + cv2.moments of every contour and reports (int(m10 / m00) + 1, int(m01 / m00) + 1), skipping
     contours whose polygon area m00 is zero (single pixels, one-pixel-wide lines).  Restated here with connected components
-    (scipy), Moore-neighbour border tracing and Green's-theorem polygon moments; contours of HOLES (RETR_TREE reports them
-    as extra contours) are not traced.  Unpinned: OpenCV is not available to the reference in this environment."""
+    (scipy), Moore-neighbour border tracing and Green's-theorem polygon moments.  RETR_TREE also reports every HOLE of a blob
+    as a contour of its own -- the blob's pixels that have a pixel of the hole in their 4-neighbourhood (Suzuki-Abe border
+    following with 8-connected blobs and 4-connected holes) -- and the reference's loop adds a position for each: here a hole is a
+    4-connected background component that does not reach the blob's bounding box, and its contour is traced as the outer border of
+    (hole + that ring of blob pixels).  Unpinned: OpenCV is not available to the reference in this environment."""
     from scipy import ndimage
     a = np.asarray(img)
     assert a.ndim in (2, 3), "Invalid image dimensions."
@@ -995,6 +998,7 @@ def get_pos_contours(img, erode_kernel=3):
     if erode_kernel > 0:
         a = ndimage.grey_erosion(a.astype(np.uint8), size=(erode_kernel, erode_kernel), mode="constant", cval=255)
     lab, n = ndimage.label(a > 10, structure=np.ones((3, 3)))
+    cross = ndimage.generate_binary_structure(2, 1)
     pos = []
     for sl, idx in zip(ndimage.find_objects(lab), range(1, n + 1)):
         comp = np.pad(lab[sl] == idx, 1)
@@ -1004,6 +1008,15 @@ def get_pos_contours(img, erode_kernel=3):
             cx = m10 / m00 + sl[1].start - 1        # back to image coordinates (the component was cropped and padded)
             cy = m01 / m00 + sl[0].start - 1
             pos.append((int(cx) + 1, int(cy) + 1))
+        bg, nb = ndimage.label(~comp, structure=cross)
+        for h in range(1, nb + 1):
+            if h == bg[0, 0]:                        # the outside (the padding ring belongs to it)
+                continue
+            hole = bg == h
+            ring = ndimage.binary_dilation(hole, structure=cross) & comp
+            m00, m10, m01 = _polygon_moments(_trace_outer_border(hole | ring))
+            if m00 != 0:
+                pos.append((int(m10 / m00 + sl[1].start - 1) + 1, int(m01 / m00 + sl[0].start - 1) + 1))
     return pos
 
 

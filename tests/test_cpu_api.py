@@ -446,3 +446,18 @@ def test_position_contour_centres_known_answers():
     # the polygon of a 3x3 ring of pixels is the 2x2 square through their centres
     ring = np.pad(np.array([[1, 1, 1], [1, 0, 1], [1, 1, 1]], bool), 1)
     assert F._polygon_moments(F._trace_outer_border(ring)) == (4.0, 8.0, 8.0)
+    # RETR_TREE: a hole is a contour of its own (the blob pixels around it) and adds a position -- a square frame has two
+    # concentric contours, both centred on the frame; a one-pixel hole's contour is the diamond of its 4 neighbours (area 2)
+    frame = np.zeros((40, 40), np.uint8)
+    frame[10:21, 5:16] = 255
+    frame[13:18, 8:13] = 0
+    assert F.get_pos_contours(frame, erode_kernel=0) == [(11, 16), (11, 16)]
+    dot = np.zeros((40, 40), np.uint8)
+    dot[10:21, 5:16] = 255
+    dot[12, 7] = 0
+    assert F.get_pos_contours(dot, erode_kernel=0) == [(11, 16), (8, 13)]
+    two = np.zeros((40, 60), np.uint8)                      # holes belong to their own blob only
+    two[5:16, 5:16] = 255
+    two[8:13, 8:13] = 0
+    two[20:31, 30:41] = 255
+    assert sorted(F.get_pos_contours(two, erode_kernel=0)) == [(11, 11), (11, 11), (36, 26)]
