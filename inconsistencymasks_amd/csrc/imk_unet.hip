@@ -462,7 +462,11 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     OK(b.flush_wgrads());
     // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
     for (int i = 3; i >= 0; --i) {
-        if (i == 0) b.defer_finalize = true;   // last block: nothing left to hide its split reductions behind
+        if (i == 0) {
+            b.defer_finalize = true;   // last block: nothing left to hide its split reductions behind
+            static const bool swap_off = []() { const char *e = getenv("IMK_TAIL_SWAP"); return e && e[0] == '0'; }();
+            if (!swap_off) b.hold_conv = t.e_c3[0];
+        }
         OK(b.bn_bwd(t.e_bn[i], 1, reinterpret_cast<f16 *>(c.base + c.ws.dU[3 - i]),
                     reinterpret_cast<f16 *>(c.base + c.ws.dP[i])));
         OK(b.wgrad_dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
@@ -471,7 +475,12 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.flush_wgrads());
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
-    OK(b.wgrad(t.in_c, nullptr, true));
+    if (b.has_held) {
+        OK(b.wgrad(t.in_c));                        // full resolution: forked onto the side stream at once
+        b.pending[b.n_pending++] = b.held;          // launched on the main stream by finish_wgrads
+    } else {
+        OK(b.wgrad(t.in_c, nullptr, true));
+    }
     OK(b.finish_wgrads());
     if (!loss_done) OK(imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, stream));
 #undef OK
