@@ -759,7 +759,7 @@ int imk_launch_bn_bwd_coef(const float *partial, int n_part, int c, int cs, doub
 // Softmax heads: the shared matrix-core arithmetic of imk_head.h (HeadMfma).  Persistent over groups of 64 pixels per wave
 // (4 units of 16, all activation loads of a group issued first); a wave's 64 x K probabilities are contiguous in the
 // [pixel][K] output, so they go through a wave-private LDS slab and leave as 16-byte stores.
-template <int NCT, int KT>
+template <int KT>
 __global__ __launch_bounds__(256) void head_softmax_kernel(const f16 *__restrict__ z, const float *__restrict__ sc,
                                                            const float *__restrict__ sh, const float *__restrict__ w,
                                                            const float *__restrict__ bias, int cin, int cs, int K,
@@ -767,15 +767,15 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const f16 *__restrict
     extern __shared__ __attribute__((aligned(16))) float s_slab[];     // [4 waves][64][K]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
     float *so = s_slab + (size_t)wave * 64 * K;
-    HeadMfma<NCT, KT> h;
+    HeadMfma<KT> h;
     h.load(w, bias, sc, sh, cin, cs, K);
     const long long n_grp = (n_pix + 63) / 64;
     for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_grp; grp += (long long)gridDim.x * 4) {
-        f16x4 zr[4][NCT];
+        f16x8 zr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long px = grp * 64 + u * 16 + p16;
-            h.load_z(z, px < n_pix ? px : n_pix - 1, cs, zr[u]);
+            zr[u] = h.load_z(z, px < n_pix ? px : n_pix - 1, cs);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -811,17 +811,14 @@ static int launch_head_softmax(const f16 *z, const float *sc, const float *sh, c
     const int nb = (int)(want < cap ? want : cap);
     const size_t lds = (size_t)4 * 64 * K * sizeof(float);
     const int vec = (reinterpret_cast<uintptr_t>(probs) & 15) == 0;
-    const int nct = cs > 16 ? 2 : 1, kt = (K + 15) / 16;
-#define IMK_HS(NCT, KT) head_softmax_kernel<NCT, KT><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, cs, K, n_pix, probs, vec)
-#define IMK_HS_K(NCT)                                                                                                    \
-    switch (kt) {                                                                                                        \
-        case 1: IMK_HS(NCT, 1); break;                                                                                   \
-        case 2: IMK_HS(NCT, 2); break;                                                                                   \
-        case 3: IMK_HS(NCT, 3); break;                                                                                   \
-        default: IMK_HS(NCT, 4); break;                                                                                  \
+    const int kt = (K + 15) / 16;
+#define IMK_HS(KT) head_softmax_kernel<KT><<<nb, 256, lds, stream>>>(z, sc, sh, w, bias, cin, cs, K, n_pix, probs, vec)
+    switch (kt) {
+        case 1: IMK_HS(1); break;
+        case 2: IMK_HS(2); break;
+        case 3: IMK_HS(3); break;
+        default: IMK_HS(4); break;
     }
-    if (nct == 1) { IMK_HS_K(1) } else { IMK_HS_K(2) }
-#undef IMK_HS_K
 #undef IMK_HS
     IMK_LAUNCH_CHECK();
     return IMK_OK;

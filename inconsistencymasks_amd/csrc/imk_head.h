@@ -60,15 +60,18 @@ __device__ __forceinline__ void head_softmax_row(const float (&xin)[CS], const f
 }
 
 // ---- softmax heads on the matrix cores (head_softmax_kernel: probabilities -> HBM; head_im_softmax_kernel: -> votes) ------
-// logits^T [class][pixel] = W^T . x^T + b on v_mfma_f32_16x16x4_f32 (fp32 products and sums, like the reference's float32
-// output layer): a wave takes 16 pixels per unit, lane (p16 = lane & 15, g = lane >> 4) supplies the channels 16 ct + 4 g + r
-// of pixel p16 (the 8 bytes it loads itself) and receives the classes 16 kt + 4 g + r of the same pixel, so the softmax is
-// registers + two shuffles over the 4 lanes of a pixel.  The per-thread form above spent a broadcast LDS read per product:
-// 2.0 ms per 128 Cityscapes images and 2 models at alpha 2 (profiles/r03_configs_kernel_stats_cityscapes_a2.csv).
+// logits^T [class][pixel] = W^T . x^T + b on v_mfma_f32_16x16x32_f16, ONE k-step for all (<= 32) input channels, with the fp32
+// weights of the reference's float32 output layer split into two fp16 halves w = hi + lo (hi = fp16(w), lo = fp16(w - hi)): the
+// products with the fp16 activations are exact in fp32 and the two MFMAs carry ~22 bits of w (1e-7 relative).  A wave takes 16
+// pixels per unit, lane (p16 = lane & 15, g = lane >> 4) supplies the channels 8 g + j of pixel p16 (the 16 bytes it loads
+// itself) and receives the classes 16 kt + 4 g + r of the same pixel, so the softmax is registers + two shuffles over the 4
+// lanes of a pixel.  History: one thread per pixel with a broadcast LDS read per product took 2.0 ms per 128 Cityscapes images
+// and 2 models at alpha 2; fp32 MFMAs (16x16x4, 8 dependent steps per class tile) 1.0 ms, 40 % of it matrix-core time.
 // Both kernels call probs() below and nothing else, so the stored and the voted probabilities are the same bits.
-template <int NCT /* 16-channel tiles of the input */, int KT /* 16-class tiles */>
+template <int KT /* 16-class tiles */>
 struct HeadMfma {
-    float wa[KT][NCT][4], bias_r[KT][4], sc_r[NCT][4], sh_r[NCT][4];
+    f16x8 whi[KT], wlo[KT];
+    float bias_r[KT][4], sc8[8], sh8[8];
 
     __device__ __forceinline__ void load(const float *__restrict__ w /*[cin][K]*/, const float *__restrict__ bias,
                                          const float *__restrict__ sc, const float *__restrict__ sh, int cin, int cs, int K) {
@@ -76,50 +79,38 @@ struct HeadMfma {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * ct + 4 * g + r, k = 16 * kt + p16;
-                    wa[kt][ct][r] = (c < cin && k < K) ? w[(size_t)c * K + k] : 0.f;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * g + j, k = 16 * kt + p16;
+                const float v = (c < cin && k < K) ? w[(size_t)c * K + k] : 0.f;
+                whi[kt][j] = (f16)v;
+                wlo[kt][j] = (f16)(v - (float)whi[kt][j]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; bias_r[kt][r] = k < K ? bias[k] : 0.f; }
         }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * ct + 4 * g + r;
-                sc_r[ct][r] = c < cs ? sc[c] : 0.f;
-                sh_r[ct][r] = c < cs ? sh[c] : 0.f;
-            }
+        for (int j = 0; j < 8; ++j) { const int c = 8 * g + j; sc8[j] = c < cs ? sc[c] : 0.f; sh8[j] = c < cs ? sh[c] : 0.f; }
     }
 
-    // this lane's 4 channels of every tile of pixel p (cs is a multiple of 8: a lane's 4 channels are all inside or all outside)
-    __device__ __forceinline__ void load_z(const f16 *__restrict__ z, long long p, int cs, f16x4 (&zr)[NCT]) const {
+    // this lane's 8 channels of pixel p (cs is a multiple of 8: they are all inside or all outside the tensor)
+    __device__ __forceinline__ f16x8 load_z(const f16 *__restrict__ z, long long p, int cs) const {
         const int g = (threadIdx.x & 63) >> 4;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            zr[ct] = f16x4{0, 0, 0, 0};
-            if (16 * ct + 4 * g < cs) zr[ct] = *reinterpret_cast<const f16x4 *>(z + p * cs + 16 * ct + 4 * g);
-        }
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (8 * g < cs) v = *reinterpret_cast<const f16x8 *>(z + p * cs + 8 * g);
+        return v;
     }
 
     // softmax probabilities of the lane's pixel: pr[kt][r] = class 16 kt + 4 g + r (0 for classes >= K)
-    __device__ __forceinline__ void probs(const f16x4 (&zr)[NCT], int K, f32x4 (&pr)[KT]) const {
+    __device__ __forceinline__ void probs(const f16x8 &z8, int K, f32x4 (&pr)[KT]) const {
         const int g = (threadIdx.x & 63) >> 4;
-        float xf[NCT][4];
+        f16x8 x8;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xf[ct][r] = (float)(f16)((float)zr[ct][r] * sc_r[ct][r] + sh_r[ct][r]);   // as head_input
+        for (int j = 0; j < 8; ++j) x8[j] = (f16)((float)z8[j] * sc8[j] + sh8[j]);        // as head_input
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             pr[kt] = f32x4{bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pr[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kt][ct][r], xf[ct][r], pr[kt], 0, 0, 0);
+            pr[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[kt], x8, pr[kt], 0, 0, 0);
+            pr[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[kt], x8, pr[kt], 0, 0, 0);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -135,7 +126,7 @@ struct HeadMfma {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pr[kt][r] = expf(pr[kt][r] - mx); sum += pr[kt][r]; }
+            for (int r = 0; r < 4; ++r) { pr[kt][r] = __builtin_amdgcn_exp2f((pr[kt][r] - mx) * 1.44269504088896f); sum += pr[kt][r]; }   // v_exp_f32 (1 ulp of 2^x)
         sum += __shfl_xor(sum, 16, 64);      // (s_g + s_g^1) + (s_g^2 + s_g^3): the same bits on the 4 lanes of a pixel
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;

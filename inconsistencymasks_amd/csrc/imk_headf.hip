@@ -8,10 +8,11 @@
 // logit gradient written once and read twice: 80 bytes per pixel each way).
 //
 // All products run on the matrix cores, laid out so that no value changes lanes between the stages:
-//   logits^T [class][pixel] = W^T . x^T + b     v_mfma_f32_16x16x4_f32 (exact fp32 fma chains, as the reference's fp32 head):
+//   logits^T [class][pixel] = W^T . x^T + b     v_mfma_f32_16x16x32_f16 with the fp32 weights split into fp16 hi + lo halves
+//       (two MFMAs per 16-class tile, fp32 accumulation: the reference's float32 output layer to ~1e-7 relative):
 //       A = W^T (rows = classes of a 16-class tile), B = x^T: lane (pixel p = lane & 15, g = lane >> 4) supplies the channels
-//       16 ct + 4 g + r it loaded itself (two 8-byte loads per pixel at 32 channels) and receives the classes 16 kt + 4 g + r
-//       of ITS pixel: softmax max / sum = registers + two shuffles over the 4 lanes of a pixel;
+//       8 g + j it loaded itself (one 16-byte load) and receives the classes 16 kt + 4 g + r of ITS pixel: softmax max / sum =
+//       registers + two shuffles over the 4 lanes of a pixel;
 //   dy^T [channel][pixel] = W . dlogit^T        v_mfma_f32_16x16x32_f16: the contraction runs over the classes = the ROW index
 //       of the logits tile, so the fp16 logit gradients are the B operand as they stand (k-slot (g, j) <-> class
 //       16 (2 s + (j >> 2)) + 4 g + (j & 3); the A fragments of W are built in that order), and the result lands on the
@@ -57,17 +58,23 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
     const float gs = S / (float)a.n_pix;
 
     // ---- operands that live in registers for the whole kernel ----------------------------------------------------------
-    // logits: A[class row p16][k-slot g] of k-step (ct, r) = W[c = 16 ct + 4 g + r][16 kt + p16]
-    float wa[KT][NCT][4];
+    // logits: ONE k-step of v_mfma_f32_16x16x32_f16 covers all (<= 32) input channels: A[class row p16][k-slot (g, j)] =
+    // W[c = 8 g + j][16 kt + p16], the fp32 weight split into two halves w = hi + lo (hi = fp16(w), lo = fp16(w - hi)): the
+    // products x * hi, x * lo are exact in fp32 and their sum carries ~22 bits of w -- the reference's float32 output layer to
+    // 1e-7 relative, at 1/8 of the matrix-core time of the fp32 MFMA chain (8 dependent 16x16x4 steps per class tile before).
+    f16x8 whi[KT], wlo[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j, k = 16 * kt + p16;
+            const float w = (c < cin && k < K) ? a.w[(size_t)c * K + k] : 0.f;
+            whi[kt][j] = (f16)w;
+            wlo[kt][j] = (f16)(w - (float)whi[kt][j]);
+        }
+    float sc8[8], sh8[8];          // BatchNorm of the channels 8 g + j (the logits' B operand)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * ct + 4 * g + r, k = 16 * kt + p16;
-                wa[kt][ct][r] = (c < cin && k < K) ? a.w[(size_t)c * K + k] : 0.f;
-            }
+    for (int j = 0; j < 8; ++j) { const int c = 8 * g + j; sc8[j] = c < a.cs ? a.sc[c] : 0.f; sh8[j] = c < a.cs ? a.sh[c] : 0.f; }
     // dgrad: A[channel row p16][k-slot (g, j)] of k-step s = fp16(W[16 ct + p16][class 16 (2 s + (j >> 2)) + 4 g + (j & 3)])
     f16x8 wd[NCT][NS];
 #pragma unroll
@@ -79,15 +86,11 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
                 const int c = 16 * ct + p16, k = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);
                 wd[ct][s][j] = (f16)((c < cin && k < K) ? a.w[(size_t)c * K + k] : 0.f);
             }
-    float bias_r[KT][4], sc_r[NCT][4], sh_r[NCT][4];
+    float bias_r[KT][4];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; bias_r[kt][r] = k < K ? a.bias[k] : 0.f; }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int c = 16 * ct + 4 * g + r; sc_r[ct][r] = c < a.cs ? a.sc[c] : 0.f; sh_r[ct][r] = c < a.cs ? a.sh[c] : 0.f; }
 
     f32x4 accw[NCT][KT], accb = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
     const long long n_grp = (a.n_pix + 63) / 64;
     for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_grp; grp += (long long)gridDim.x * 4) {
         f16x4 zr[4][NCT];
+        f16x8 z8[4];
         int yv[4];
         bool ok[4];
 #pragma unroll
@@ -116,29 +120,23 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
                 zr[u][ct] = f16x4{0, 0, 0, 0};
                 if (16 * ct + 4 * g < a.cs) zr[u][ct] = *reinterpret_cast<const f16x4 *>(a.z + pc * a.cs + 16 * ct + 4 * g);
             }
+            z8[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (8 * g < a.cs) z8[u] = *reinterpret_cast<const f16x8 *>(a.z + pc * a.cs + 8 * g);
             yv[u] = a.y[pc];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // x = fp16(z * sc + sh): the head's input, as head_kernel / head_loss_kernel form it
-            f16x4 xh[NCT];
-            float xf[NCT][4];
+            f16x8 x8;                                  // channels 8 g + j of the lane's pixel
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xh[ct][r] = (f16)((float)zr[u][ct][r] * sc_r[ct][r] + sh_r[ct][r]);
-                    xf[ct][r] = (float)xh[ct][r];
-                }
+            for (int j = 0; j < 8; ++j) x8[j] = (f16)((float)z8[u][j] * sc8[j] + sh8[j]);
             // logits of the lane's pixel: classes 16 kt + 4 g + r
             f32x4 lg[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 lg[kt] = f32x4{bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) lg[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kt][ct][r], xf[ct][r], lg[kt], 0, 0, 0);
+                lg[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[kt], x8, lg[kt], 0, 0, 0);
+                lg[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[kt], x8, lg[kt], 0, 0, 0);
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -154,11 +152,12 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { lg[kt][r] = expf(lg[kt][r] - mx); sum += lg[kt][r]; }
+                for (int r = 0; r < 4; ++r) { lg[kt][r] = __builtin_amdgcn_exp2f((lg[kt][r] - mx) * 1.44269504088896f); sum += lg[kt][r]; }   // v_exp_f32: 2 instructions instead of expf's ~10 (the softmax was VALU-bound)
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
             f16x4 gh[KT2];
+            float p_hit = -1.f;
 #pragma unroll
             for (int kt = 0; kt < KT2; ++kt) gh[kt] = f16x4{0, 0, 0, 0};
 #pragma unroll
@@ -168,9 +167,11 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
                     const int k = 16 * kt + 4 * g + r;
                     const float pk = lg[kt][r] * inv;
                     const bool hit = k == yv[u];
-                    if (hit && ok[u]) loss += -logf(fmaxf(pk, 1.17549435e-38f));
+                    p_hit = hit ? pk : p_hit;
                     gh[kt][r] = (k < K && ok[u]) ? (f16)(gs * (pk - (hit ? 1.0f : 0.0f))) : (f16)0.f;
                 }
+            // one logarithm per lane (the lane of the pixel's four that holds the labelled class), not one per class
+            if (p_hit >= 0.f && ok[u]) loss += -logf(fmaxf(p_hit, 1.17549435e-38f));
             // dy^T = W . dlogit^T (fp16 operands, fp32 accumulation), rounded to fp16 like the dgrad launch it replaces
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -193,11 +194,10 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
                 if (ok[u] && 16 * ct + 4 * g < a.cs) *reinterpret_cast<f16x4 *>(a.dy + (grp * 64 + u * 16 + p16) * a.cs + 16 * ct + 4 * g) = dh;
             }
             // LDS image for the weight gradient: pixel u * 16 + p16, this lane's 4 channels / 4 classes of every tile
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                f16x4 xs = xh[ct];
-                if (!ok[u]) xs = f16x4{0, 0, 0, 0};
-                *reinterpret_cast<f16x4 *>(s_x + (ct * 64 + u * 16 + p16) * H16 + 4 * g) = xs;
+            if ((g >> 1) < NCT) {                      // slice (8 g) / 16, halfs 8 (g & 1) .. + 7 of the pixel's row
+                f16x8 xs = x8;
+                if (!ok[u]) xs = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<f16x8 *>(s_x + ((g >> 1) * 64 + u * 16 + p16) * H16 + 8 * (g & 1)) = xs;
             }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f16x4 *>(s_g + (kt * 64 + u * 16 + p16) * H16 + 4 * g) = gh[kt];

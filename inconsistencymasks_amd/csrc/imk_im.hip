@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void head_im_sigmoid_kernel(ImkHeadImArgs a, i
 
 // Softmax heads: HeadMfma (imk_head.h) gives every group of 4 lanes the K probabilities of one pixel; a wave takes 64 of
 // the workgroup's 256 pixels (4 units of 16), model after model, and keeps label / agreement per unit in registers.
-template <int NCT, int KT>
+template <int KT>
 __global__ __launch_bounds__(256) void head_im_softmax_kernel(ImkHeadImArgs a, int vec_out, int vec_img) {
     __shared__ __attribute__((aligned(16))) uint8_t s_final[1][BIN_CHUNK];   // MC_CHUNK bytes used
     __shared__ __attribute__((aligned(16))) uint8_t s_im[BIN_CHUNK];
@@ -410,13 +410,13 @@ __global__ __launch_bounds__(256) void head_im_softmax_kernel(ImkHeadImArgs a, i
     int label0[4] = {0, 0, 0, 0};
     bool agree[4] = {true, true, true, true};
     for (int n = 0; n < a.n_models; ++n) {
-        HeadMfma<NCT, KT> h;
+        HeadMfma<KT> h;
         h.load(a.w[n], a.bias[n], a.sc[n], a.sh[n], a.cin, cs, K);
-        f16x4 zr[4][NCT];
+        f16x8 zr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = 64 * wave + 16 * u + p16;
-            h.load_z(a.z[n], (long long)b * hw + p_base + (q < n_px ? q : 0), cs, zr[u]);
+            zr[u] = h.load_z(a.z[n], (long long)b * hw + p_base + (q < n_px ? q : 0), cs);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -523,15 +523,12 @@ int imk_launch_head_im(const ImkHeadImArgs &a, hipStream_t stream) {
     } while (0)
     if (a.softmax) {
         const int kt = (a.K + 15) / 16;
-#define IMK_HIM_K(NCT)                                                                                                      \
-        switch (kt) {                                                                                                       \
-            case 1: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 1>)); break;                                                \
-            case 2: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 2>)); break;                                                \
-            case 3: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 3>)); break;                                                \
-            default: IMK_HIM_LAUNCH((head_im_softmax_kernel<NCT, 4>)); break;                                               \
+        switch (kt) {
+            case 1: IMK_HIM_LAUNCH(head_im_softmax_kernel<1>); break;
+            case 2: IMK_HIM_LAUNCH(head_im_softmax_kernel<2>); break;
+            case 3: IMK_HIM_LAUNCH(head_im_softmax_kernel<3>); break;
+            default: IMK_HIM_LAUNCH(head_im_softmax_kernel<4>); break;
         }
-        if (a.cs <= 16) { IMK_HIM_K(1) } else { IMK_HIM_K(2) }
-#undef IMK_HIM_K
     } else {
         // the reference's ensembles have 2-4 members: 2 and 3 get all their loads hoisted (compile-time N)
 #define IMK_HIM_SIG(CSV, KBV)                                                                                               \
