@@ -2005,6 +2005,13 @@ bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
         plain.wpk2 = nullptr;
         if (imk_conv_gemm_ok(plain)) return false;
     }
+    if (!store_mid && a.epi == EP_RELU && a.ksize == 3 && (a.x.lmode == LM_POOL || a.x.lmode == LM_AFFINE) && a.cout <= 128 &&
+        cout2 <= 128 && imk_pad8(cout2) <= (a.cout > 64 ? 128 : 64)) {     // the GEMM-class chain (imk_conv_gemm_chain_ok, before wpk2 is set)
+        static const bool gc_off = []() { const char *e = getenv("IMK_GEMM_CHAIN"); return e && e[0] == '0'; }();
+        ImkConvArgs plain = a;
+        plain.wpk2 = nullptr;
+        if (!gc_off && !plain.stats_partial && imk_conv_gemm_ok(plain)) return true;
+    }
     const bool pipe_ok = pipe_enabled() && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16;
     if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;
     if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
@@ -2053,6 +2060,7 @@ int imk_launch_conv(const ImkConvArgs &a_in, hipStream_t stream) {
         if (pipe_ok) return a.cout2 > 16 ? IMK_EUNSUPPORTED : launch_conv_pipe_any(a, stream);
         if (!imk_conv_can_chain_tile(a, a.cout2, a.out != nullptr)) return IMK_EUNSUPPORTED;
         if (conv_wide_chain_ok(a)) return launch_conv_wide_chain(a, stream);
+        if (imk_conv_gemm_chain_ok(a)) return imk_launch_conv_gemm(a, stream);
         return launch_conv_mfma(a, stream);
     }
     if (pipe_ok) return launch_conv_pipe_any(a, stream);

@@ -42,9 +42,14 @@ struct GemmGeom {
     int nc8, nc8p, n_pass, nsp, ns_total;     // packed-weight geometry: chunks, chunks per pass, passes, k-steps per pass / in all
     int spp, cps, n_stage, ps;                // passes per stage, chunks per stage, stages, LDS pixel pitch in chunks (odd)
     int dbg;                                  // experiments (IMK_GEMM_DBG): 1 = weight fragments always from k-step 0 (timing only, wrong results)
+    int nc8_2, nc8p_2, ns_2, mt_2;            // CH2: the chained 1x1's k geometry (chunks, chunks per pass, k-steps) and output tiles
 };
 
-template <int LM, bool KS3, int PN, bool NC4>
+// CH2 (inference, round 3): the block's Conv1x1+ReLU as a second GEMM on the output tile while it sits in LDS -- the workgroup
+// holds ALL output channels of its 128 pixels (gy == 1: cout <= BN), so out2 = relu(W2 . tile + b2) needs nothing else: B operand =
+// 16-byte reads of s_out rows (the k order of the 1x1's regular pack), A = that pack from global, result back into s_out and out
+// through the same coalesced sweep.  The 3x3's output is never written: one launch and one tensor round trip less per block.
+template <int LM, bool KS3, int PN, bool NC4, bool CH2 = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGeom gm) {
     constexpr int NT = 256, PM = G_PM, WN = G_WN, TH = G_TH;
     constexpr int BN = 16 * PN * WN;
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     // ---- epilogue ------------------------------------------------------------------------------------------------------
     constexpr int OP = BN + 8;                           // halfs per pixel of the output tile in LDS (17 / 9 chunks: odd)
     f16 *s_out = reinterpret_cast<f16 *>(smem);
-    const int cs_o = a.cs_out;
+    const int cs_o = CH2 ? a.cs_out2 : a.cs_out;
+    f16 *const out_t = CH2 ? a.out2 : a.out;
     {
         float bias[PN][4];
 #pragma unroll
@@ -243,6 +249,46 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
             }
     }
     __syncthreads();
+    if constexpr (CH2) {
+        f32x4 acc2[PN][PM];
+#pragma unroll
+        for (int m = 0; m < PN; ++m)
+#pragma unroll
+            for (int p = 0; p < PM; ++p) acc2[m][p] = f32x4{0, 0, 0, 0};
+        for (int ks = 0; ks < gm.ns_2; ++ks) {
+            int c8 = ks * gm.nc8p_2 + g;
+            if (g >= gm.nc8p_2 || c8 >= gm.nc8_2) c8 = 0;          // zero weights in those k-slots: any finite chunk
+            f16x8 af[PN], bf[PM];
+#pragma unroll
+            for (int m = 0; m < PN; ++m) {
+                const int mt = wn * PN + m;
+                af[m] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (mt < gm.mt_2) af[m] = *reinterpret_cast<const f16x8 *>(a.wpk2 + ((size_t)(mt * gm.ns_2 + ks) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int p = 0; p < PM; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(s_out + ((wm * PM + p) * 16 + n) * OP + c8 * 8);
+#pragma unroll
+            for (int m = 0; m < PN; ++m)
+#pragma unroll
+                for (int p = 0; p < PM; ++p) acc2[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[p], acc2[m][p], 0, 0, 0);
+        }
+        float bias2[PN][4];
+#pragma unroll
+        for (int m = 0; m < PN; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int co = (wn * PN + m) * 16 + 4 * g + r; bias2[m][r] = co < a.cout2 ? a.bias2[co] : 0.f; }
+        __syncthreads();                                 // every wave has read the 3x3's tile
+#pragma unroll
+        for (int m = 0; m < PN; ++m)
+#pragma unroll
+            for (int p = 0; p < PM; ++p) {
+                f16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc2[m][p][r] + bias2[m][r], 0.f);
+                *reinterpret_cast<f16x4 *>(s_out + ((wm * PM + p) * 16 + n) * OP + (wn * PN + m) * 16 + 4 * g) = v;
+            }
+        __syncthreads();
+    }
     IMK_STAMP(5);
     constexpr int CPP = BN / 8, RPI = NT / CPP, IT = G_BM / RPI;   // chunks per pixel, pixels per sweep, sweeps
     const int cj = t % CPP, prow = t / CPP;
@@ -257,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     auto sweep = [&](auto EPI_T, auto STAT_T) {
         constexpr int EPI = decltype(EPI_T)::value;      // EP_RELU / EP_PLAIN / EP_MASK
         constexpr int STAT = decltype(STAT_T)::value;    // 0 none, 1 sum / sum of squares, 2 sum dy / sum dy * z
-        char *ob = const_cast<char *>(pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, pitch)) + cho;
+        char *ob = const_cast<char *>(pix_base(out_t, tc.b, H, W, tc.ty0, tc.tx0, pitch)) + cho;
         const char *mb = EPI == EP_MASK ? pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, pitch) + cho : nullptr;
         const char *zb = STAT == 2 ? pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, pitch) + cho : nullptr;
         f16x8 mk[IT], zz[IT];
@@ -290,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
             }
         }
     };
-    const bool dystat = (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
-    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;
+    const bool dystat = !CH2 && (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
+    const bool want_stats = !CH2 && (((a.epi == EP_RELU) && a.stats_partial) || dystat);
     if (a.epi == EP_RELU) { if (want_stats) sweep(I0{}, I1{}); else sweep(I0{}, I0{}); }
     else if (a.epi == EP_MASK) { if (dystat) sweep(I2{}, I2{}); else sweep(I2{}, I0{}); }
     else { if (dystat) sweep(I1{}, I2{}); else sweep(I1{}, I0{}); }
@@ -339,6 +385,12 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     pn = (g128 * 8 <= g64 * 4) ? 4 : 2;
     static const int force_pn = []() { const char *e = getenv("IMK_GEMM_PN"); return e ? atoi(e) : 0; }();
     if (force_pn == 2 || (force_pn == 4 && mt_total > 4)) pn = force_pn;
+    if (a.wpk2) {            // chained 1x1: one workgroup holds every output channel of its pixels
+        pn = mt_total > 4 ? 4 : 2;
+        const int nc8_2 = a.cs_out / 8;
+        gm.nc8_2 = nc8_2; gm.nc8p_2 = imk_pass_chunks(nc8_2); gm.ns_2 = imk_cdiv_d(nc8_2, gm.nc8p_2);
+        gm.mt_2 = (a.cout2 + 15) / 16;
+    }
     const int bn = 16 * pn * G_WN;
     const int halo = ks3 ? 1 : 0;
     gm.tiles_x = imk_cdiv(a.W, TW); gm.tiles_y = imk_cdiv(a.H, G_TH);
@@ -363,6 +415,18 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     grid = imk_cdiv_d(gm.n_sp, 8) * 8 * gm.gy;
     static const int dbg = []() { const char *e = getenv("IMK_GEMM_DBG"); return e ? atoi(e) : 0; }();
     gm.dbg = dbg;
+    return IMK_OK;
+}
+
+template <int LM>
+int launch_conv_gemm_chain(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t lds, int grid, hipStream_t stream) {
+    if (gm.nc8p == 4) {
+        if (pn == 4) conv_gemm_kernel<LM, true, 4, true, true><<<grid, 256, lds, stream>>>(a, gm);
+        else conv_gemm_kernel<LM, true, 2, true, true><<<grid, 256, lds, stream>>>(a, gm);
+    } else {
+        if (pn == 4) conv_gemm_kernel<LM, true, 4, false, true><<<grid, 256, lds, stream>>>(a, gm);
+        else conv_gemm_kernel<LM, true, 2, false, true><<<grid, 256, lds, stream>>>(a, gm);
+    }
     return IMK_OK;
 }
 
@@ -396,6 +460,18 @@ bool imk_conv_gemm_ok(const ImkConvArgs &a) {
     return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16);
 }
 
+// Conv3x3+ReLU -> Conv1x1+ReLU in one launch of the GEMM-class kernel (inference: no stored intermediate, no statistics): the
+// 3x3 is one this kernel takes, both convs have at most 128 output channels, the 1x1's pack is one k-step per channel pass
+bool imk_conv_gemm_chain_ok(const ImkConvArgs &a) {
+    static const bool off = []() { const char *e = getenv("IMK_GEMM_CHAIN"); return e && e[0] == '0'; }();
+    if (off || !a.wpk2 || a.out || !a.out2 || a.stats_partial || a.epi != EP_RELU || a.ksize != 3) return false;
+    if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
+    if (a.cout > 128 || a.cout2 > 128 || a.cs_out2 > (a.cout > 64 ? 128 : 64)) return false;
+    ImkConvArgs plain = a;
+    plain.wpk2 = nullptr; plain.out = a.out2;
+    return imk_conv_gemm_ok(plain);
+}
+
 int imk_conv_gemm_num_tiles(int B, int H, int W) { return B * imk_cdiv(H, G_TH) * imk_cdiv(W, TW); }
 
 int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream) {
@@ -406,6 +482,14 @@ int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream) {
     if (rc) return rc;
     ImkProfScope prof(PF_CONV_GEMM, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     const bool ks3 = a.ksize == 3;
+    if (a.wpk2) {
+        if (!imk_conv_gemm_chain_ok(a) || gm.gy != 1) return IMK_EUNSUPPORTED;
+        rc = a.x.lmode == LM_POOL ? launch_conv_gemm_chain<LM_POOL>(a, gm, pn, lds, grid, stream)
+                                  : launch_conv_gemm_chain<LM_AFFINE>(a, gm, pn, lds, grid, stream);
+        if (rc) return rc;
+        IMK_LAUNCH_CHECK();
+        return IMK_OK;
+    }
 #define IMK_GEMM_LM(LM) (ks3 ? launch_conv_gemm_k<LM, true>(a, gm, pn, lds, grid, stream) : launch_conv_gemm_k<LM, false>(a, gm, pn, lds, grid, stream))
     switch (a.x.lmode) {
         case LM_RAW: rc = IMK_GEMM_LM(LM_RAW); break;

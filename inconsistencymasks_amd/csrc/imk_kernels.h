@@ -86,6 +86,7 @@ bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
 // GEMM-class kernel for the wide layers (imk_gemm.hip): which launches it takes, its launcher, its statistics rows
 bool imk_conv_gemm_ok(const ImkConvArgs &a);
 int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream);
+bool imk_conv_gemm_chain_ok(const ImkConvArgs &a);      // Conv3x3 -> Conv1x1 in one GEMM-class launch (inference)
 int imk_conv_gemm_num_tiles(int B, int H, int W);
 // algorithmic bytes of a conv launch: its input tensor(s) as the load mode reads them + every tensor it writes / re-reads
 inline double imk_conv_algorithmic_bytes(const ImkConvArgs &a) {
