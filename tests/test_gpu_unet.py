@@ -532,6 +532,41 @@ def test_chained_per_tile_conv_is_bit_identical_to_two_launches(tmp_path):
     assert got[0] == got[1]
 
 
+_CHAIN3_CHILD = r"""
+import hashlib, sys, torch
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd.unet import UNet
+g = torch.Generator(device="cuda").manual_seed(2)
+h = hashlib.sha256()
+for (hh, ww, c, k, alpha, act) in [(64, 80, 3, 9, 1.0, "softmax"), (48, 64, 3, 5, 2.0, "softmax"), (80, 48, 1, 3, 1.0, "sigmoid"),
+                                   (64, 64, 3, 4, 1.5, "softmax")]:
+    x = torch.randint(0, 256, (5, hh, ww, c), dtype=torch.uint8, device="cuda", generator=g)
+    m = UNet(hh, ww, c, k, alpha, act, seed=11)
+    h.update(m.predict_device(x).cpu().numpy().tobytes())
+print("SHA", h.hexdigest())
+"""
+
+
+def test_chained_wide_and_gemm_convs_are_bit_identical_to_two_launches(tmp_path):
+    """Round 3's inference chains -- conv_wide_kernel<..., CHAIN2> (17-32 channel blocks) and conv_gemm_kernel<..., CH2> (blocks up
+    to 128 channels): the block's Conv1x1 computed from the 3x3's output tile while it is on the chip, with the 1x1's regular
+    pack in its regular k order -- against the same convs as two launches each: identical probabilities, bit for bit, at
+    ragged sizes and widths 1 / 1.5 / 2 (one process each: the switches are read once)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "chain3_child.py"
+    script.write_text(_CHAIN3_CHILD.format(root=root))
+    got = []
+    for wide, gemm in (("1", "1"), ("0", "0"), ("1", "0")):
+        env = {**os.environ, "IMK_WIDE_CHAIN": wide, "IMK_GEMM_CHAIN": gemm}
+        if gemm == "0":
+            env["IMK_GEMM_OVER_CHAIN"] = "2"       # the 3x3 and the 1x1 as two GEMM-class launches (not the per-tile chain)
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert got[0] == got[1] == got[2], got
+
+
 _PRE_CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, {root!r})
