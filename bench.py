@@ -38,6 +38,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: see inconsistencymasks_amd/__init__.py
+
 import numpy as np
 import torch
 

@@ -229,10 +229,10 @@ extern "C" int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, voi
     float *head_out = out ? out : reinterpret_cast<float *>(c.base + c.ws.probs);
     OK(run_head(c, t, head_out, y, sv.ctl, stats));
 
-    ensure_side_streams(plan);
     static const int n_side_env = []() { const char *s = getenv("IMK_SIDE_STREAMS"); int v = s ? atoi(s) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && !plan->dbg_single_stream) ? n_side_env : 0, 1LL << 62};
+    const bool side_on = !plan->dbg_single_stream && n_side_env > 0 && ensure_side_streams(plan, n_side_env);
+    Bwd b{c, grads, sv.ctl, stats + 1, side_on ? n_side_env : 0, 1LL << 62};
     {   // Dense gradients and the loss values: batch reduction of the head kernel's per-sample terms
         const ImkLayer &d0 = plan->layers[t.dense[0]];
         const ImkLayer *d1 = nh > 1 ? &plan->layers[t.dense[1]] : nullptr;

@@ -549,37 +549,39 @@ struct Bwd {
 // in bench.py: three teachers + the student = 8 streams on the runtime's 4 hardware queues, the student's side stream
 // landed on the queue of its main stream and the "concurrent" weight gradients ran in line behind barrier packets
 // (1.99 ms per step; 1.73 with GPU_MAX_HW_QUEUES=8 or with this pool).  Streams created here live as long as the process.
+// Only as many as a call needs are created (training: one; an ensemble of three: two): every stream beyond the hardware queues
+// costs concurrency somewhere -- with RCCL's own stream in the process, a second idle pool stream was enough to put the weight
+// gradients in line behind the main chain again (forced one-rank run: 20.6 k instead of 23.7 k images/s; package __init__
+// also raises GPU_MAX_HW_QUEUES to 8 when it is imported before the HIP runtime starts).
 struct ImkSidePool {
-    std::once_flag once;
+    std::mutex mu;
     hipStream_t s[imk_unet_plan::MAX_SIDE] = {};
-    bool ok = false;
 };
-inline ImkSidePool &imk_side_pool() {
+inline hipStream_t imk_side_pool_stream(int i) {
     static ImkSidePool pools[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return pools[dev & 63];
+    ImkSidePool &pool = pools[dev & 63];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (!pool.s[i] && hipStreamCreateWithFlags(&pool.s[i], hipStreamNonBlocking) != hipSuccess) pool.s[i] = nullptr;
+    return pool.s[i];
 }
 
-inline bool ensure_side_streams(const imk_unet_plan *plan) {
+// the plan's events (once) and its first n side streams
+inline bool ensure_side_streams(const imk_unet_plan *plan, int n = 1) {
     std::call_once(plan->side_once, [plan]() {
-        ImkSidePool &pool = imk_side_pool();
-        std::call_once(pool.once, [&pool]() {
-            bool ok = true;
-            for (auto &st : pool.s) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-            pool.ok = ok;
-        });
-        bool ok = pool.ok;
-        static const bool own = []() { const char *e = getenv("IMK_SIDE_POOL"); return e && e[0] == '0'; }();   // A/B: streams per plan (leaked)
-        for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i) {
-            plan->side[i] = pool.s[i];
-            if (own) ok = ok && hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking) == hipSuccess;
+        bool ok = true;
+        for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i)
             ok = ok && hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        }
         for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         plan->side_ok = ok;
     });
-    return plan->side_ok;
+    if (!plan->side_ok) return false;
+    for (int i = 0; i < n && i < imk_unet_plan::MAX_SIDE; ++i) {
+        if (!plan->side[i]) plan->side[i] = imk_side_pool_stream(i);
+        if (!plan->side[i]) return false;
+    }
+    return true;
 }
 
 // ctl / stats: non-null after an optimizer step -- the first packing launch then also closes the step (loss-scale and

@@ -309,7 +309,7 @@ extern "C" int imk_unet_forward_im(const imk_unet_plan *plan, int n_models, cons
     if (n_slabs > n_models) n_slabs = n_models;
     if (n_slabs > max_streams) n_slabs = max_streams;
     static const bool conc_off = []() { const char *e = getenv("IMK_ENSEMBLE_STREAMS"); return e && e[0] == '0'; }();
-    if (n_slabs > 1 && (conc_off || plan->dbg_single_stream || !ensure_side_streams(plan))) n_slabs = 1;
+    if (n_slabs > 1 && (conc_off || plan->dbg_single_stream || !ensure_side_streams(plan, n_slabs - 1))) n_slabs = 1;
     hipStream_t main_stream = (hipStream_t)stream_;
     if (n_slabs > 1) {
         IMK_HIP(hipEventRecord(plan->ev_fork[0], main_stream));
@@ -391,7 +391,6 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b, ol.cin,
                                 imk_pad8(ol.cin), ol.cout, cf.act_out, n_pix, y, sv.ctl, stats, dlogit, loss_partial, stream));
 
-    ensure_side_streams(plan);
     // The weight-gradient kernels run on a side stream, forked after the kernel that produced their gradient operand and
     // joined before the final reduction: nothing on the backward chain depends on them, and they fill the gaps that the
     // latency-bound kernels of the chain leave (1.280 vs 1.365 ms per step with all 24 on the side stream; forking only
@@ -399,7 +398,8 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     static const long long side_px = []() { const char *e = getenv("IMK_SIDE_PIXELS"); return e ? atoll(e) : (1LL << 62); }();
     static const int n_side_env = []() { const char *e = getenv("IMK_SIDE_STREAMS"); int v = e ? atoi(e) : 1;
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
-    Bwd b{c, grads, sv.ctl, stats + 1, (plan->side_ok && side_px > 0 && !plan->dbg_single_stream) ? n_side_env : 0, side_px};
+    const bool side_on = side_px > 0 && !plan->dbg_single_stream && n_side_env > 0 && ensure_side_streams(plan, n_side_env);
+    Bwd b{c, grads, sv.ctl, stats + 1, side_on ? n_side_env : 0, side_px};
     bool loss_done = false;
     auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than the head's kernel)
         if (loss_done || b.n_side <= 0 || b.n_fork <= 0) return IMK_OK;
