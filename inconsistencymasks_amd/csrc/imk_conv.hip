@@ -2089,7 +2089,7 @@ size_t imk_wgrad_partial_floats(int B, int H, int W, int ksize, int cin, int cou
         ns = (size_t)imk_conv_fused_wgrad_rows_max();
     // wide layers: the GEMM-class kernel's split count (whichever kernel runs: the size must not depend on a switch)
     if (imk_wgrad_gemm_wide(imk_pad8(cin), imk_pad8(cout), (long long)B * H * W)) {
-        for (int lm : {(int)LM_RAW, (int)LM_POOL}) {     // the split count depends on the load mode (pooling: smaller groups)
+        for (int lm : {(int)LM_RAW, (int)LM_POOL, (int)LM_AFFINE}) {     // the split count depends on the load mode (pooling: smaller groups; BatchNorm on load: the 3-per-CU form)
             const size_t ng = (size_t)imk_wgrad_gemm_splits(lm, B, H, W, ksize, imk_pad8(cin), imk_pad8(cout));
             if (ns < ng) ns = ng;
         }

@@ -30,8 +30,10 @@ bool gemm_env_on() {
 // bank row), the next tile's global loads in flight in registers during the MFMAs.
 struct WgGemmGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco, gi_n, go_n, fi_per, fo_per; };
 
-template <int LM, bool BNB, bool KS3, int NFI>
-__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGemmGeom gm) {
+// NFO: output-channel tiles a wave accumulates (4; 2 for layers with at most 32 output channels -- the full-resolution 3x3 layers
+// of alpha in (1, 2] and EvalNet's towers: half the accumulators, 3 workgroups per CU instead of 2)
+template <int LM, bool BNB, bool KS3, int NFI, int NFO = 4>
+__global__ __launch_bounds__(256, NFO == 2 ? 3 : 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGemmGeom gm) {
     constexpr int KP = 4 / NFI;                      // waves along the k-steps
     constexpr int TR = NFI == 1 ? 8 : 4;             // tile rows (8 rows for the 1x1 forms too: measured slower, 5.77 vs 5.65 ms)
     constexpr int KS = TR / 2;                       // k-steps per tile
@@ -57,9 +59,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGe
     if (BNB)
         for (int i = t; i < 3 * a.cs_out; i += 256) s_coef[i] = a.dA_coef[i];
 
-    f32x4 acc[4][T], accb = f32x4{0, 0, 0, 0};       // accb: row o = column sums of dA over output tile o (the bias gradient)
+    f32x4 acc[NFO][T], accb = f32x4{0, 0, 0, 0};     // accb: row o = column sums of dA over output tile o (the bias gradient)
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < NFO; ++o)
 #pragma unroll
         for (int tp = 0; tp < T; ++tp) acc[o][tp] = f32x4{0, 0, 0, 0};
 
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGe
                 // 2 kk + (g >> 1), elements 4-7 the pixels 8 further right
                 const int row = 2 * kk + (g >> 1);
                 const int xx = 4 * (g & 1) + qq;
-                f16x8 bf[4];
+                f16x8 bf[NFO];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
+                for (int o = 0; o < NFO; ++o) {
                     const f16 *pb = s_d + ((o * NPD + row * 16 + xx) * H16 + 4 * pp);
                     const h4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb));
                     const h4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(LDS_PTR(h4, pb + 8 * H16));
@@ -181,12 +183,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGe
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { af[e] = (f16)a0[e]; af[4 + e] = (f16)a1[e]; }
 #pragma unroll
-                    for (int o = 0; o < 4; ++o)
+                    for (int o = 0; o < NFO; ++o)
                         if (o < nfo) acc[o][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[o], acc[o][tap], 0, 0, 0);   // uniform
                 }
                 if (do_bias) {                       // column sums of dA -> the bias gradient: A = ones in row o
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
+                    for (int o = 0; o < NFO; ++o) {
                         f16x8 e;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) e[j] = (f16)(i16 == o ? 1.0f : 0.0f);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGe
     const int n_pairs = gm.cit_n * gm.cot_n;
     const size_t split = (size_t)blockIdx.x * KP + kp;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < NFO; ++o) {
         if (o < nfo) {
             float *dst = a.partial + ((split * n_pairs + (size_t)(cit0 + fi) * gm.cot_n + cot0 + o) * (T + 1)) * 256 + lane;
 #pragma unroll
@@ -228,6 +230,11 @@ bool wgemm_env_on() {
     return on && gemm_env_on();
 }
 
+bool wgrad_nfo2_on() {
+    static const bool on = []() { const char *e = getenv("IMK_WGRAD_NFO2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 void plan_wgrad_gemm(int lmode, int B, int H, int W, int ksize, int cs_in, int cs_out, WgGemmPlan &P) {
     WgGemmGeom &gm = P.gm;
     gm.cit_n = (cs_in + 15) / 16; gm.cot_n = (cs_out + 15) / 16;
@@ -248,7 +255,9 @@ void plan_wgrad_gemm(int lmode, int B, int H, int W, int ksize, int cs_in, int c
     // partials -- and the split reduction that reads them back -- outweigh the operands, so a workgroup gets at least
     // IMK_WGRAD_GEMM_TILES pixel tiles (the deep levels then run on fewer workgroups than the chip has slots: they are short)
     static const int min_tiles = []() { const char *e = getenv("IMK_WGRAD_GEMM_TILES"); return e ? atoi(e) : 8; }();
-    int ns = target / (gm.gi_n * gm.go_n);
+    // the two-output-tile form of the 3x3 (wgrad_gemm_kernel<.., 2, 2>) runs 3 workgroups per compute unit
+    const bool nfo2 = wgrad_nfo2_on() && lmode == LM_AFFINE && ksize == 3 && P.nfi_t == 2 && gm.cot_n <= 2;
+    int ns = (nfo2 ? target * 3 / 2 : target) / (gm.gi_n * gm.go_n);
     const int mt = min_tiles * 64 / (tr * 16) > 1 ? min_tiles * 64 / (tr * 16) : 1;       // counted in 64-pixel tiles
     if (ns > gm.n_tiles / mt) ns = gm.n_tiles / mt;
     if (ns < 1) ns = 1;
@@ -266,6 +275,12 @@ bool wgrad_gemm_combo(int lmode, bool bnb, int ksize) {
 template <int LM, bool BNB, bool KS3>
 int launch_wgrad_gemm_k(const ImkWgradArgs &a, const WgGemmPlan &P, hipStream_t stream) {
     const dim3 grid(P.n_split, P.gm.gi_n * P.gm.go_n);
+    if constexpr (LM == LM_AFFINE && KS3 && !BNB) {
+        if (wgrad_nfo2_on() && P.nfi_t == 2 && P.gm.cot_n <= 2) {
+            wgrad_gemm_kernel<LM, BNB, KS3, 2, 2><<<grid, 256, P.lds, stream>>>(a, P.gm);
+            return IMK_OK;
+        }
+    }
     if (P.nfi_t == 4) wgrad_gemm_kernel<LM, BNB, KS3, 4><<<grid, 256, P.lds, stream>>>(a, P.gm);
     else if (P.nfi_t == 2) wgrad_gemm_kernel<LM, BNB, KS3, 2><<<grid, 256, P.lds, stream>>>(a, P.gm);
     else wgrad_gemm_kernel<LM, BNB, KS3, 1><<<grid, 256, P.lds, stream>>>(a, P.gm);
