@@ -289,14 +289,14 @@ int launch_wgrad_gemm_k(const ImkWgradArgs &a, const WgGemmPlan &P, hipStream_t 
 }  // namespace
 
 // wide layers: more than 32 channels on a side (the forward's rule), and a combination that is instantiated
-// Which layers: more than 32 channels on a side; exactly 32 only with >= 2 M pixels (full resolution at alpha = 2: Cityscapes
+// Which layers: more than 32 channels on a side; 24-32 only with >= 2 M pixels (full resolution at alpha = 2: Cityscapes
 // step 6.20 -> 5.98 ms; at half resolution -- alpha = 1 -- the 16 x 16-channel kernel of imk_conv.hip is faster: 2.64 vs 2.69 ms).
 // IMK_WGRAD_GEMM_MIN overrides the channel threshold for every size.
 bool imk_wgrad_gemm_wide(int cs_in, int cs_out, long long pixels) {
     static const int v = []() { const char *e = getenv("IMK_WGRAD_GEMM_MIN"); return e ? atoi(e) : 0; }();
     const int c = cs_in > cs_out ? cs_in : cs_out;
     if (v > 0) return c >= v;
-    return c > 32 || (c == 32 && pixels >= (2ll << 20));
+    return c > 32 || (c >= 24 && pixels >= (2ll << 20));     // (24 ... 31: alpha 1.25 / 1.5 at full resolution: step 4.11 -> 4.05 / 4.29 -> 4.20 ms)
 }
 bool imk_wgrad_gemm_ok(int lmode, bool bnb, int ksize, int cs_in, int cs_out, long long pixels) {
     if (!wgemm_env_on()) return false;
