@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
             for (int k = 0; k < MAX_ITEMS; ++k) {
                 if (it_lds[k] >= 0) {
-                    f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div);
+                    f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div, a.x.u8_c);
                     if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<f16x8 *>(s_stage + it_lds[k]) = v;
                 }

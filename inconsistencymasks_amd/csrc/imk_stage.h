@@ -191,7 +191,7 @@ __device__ __forceinline__ void raw_load(const ImkInput &in, int b, int y, int x
 
 template <int LM>
 __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const float *s_aff, int cs, int c8, int cin,
-                                               float u8_div) {
+                                               float u8_div, int u8_c = 4) {
     if constexpr (LM == LM_RAW) {
         return r.v[0];
     } else if constexpr (LM == LM_AFFINE) {
@@ -224,17 +224,27 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
         return o;
     } else if constexpr (LM == LM_STEM) {
         // x * (1/255) rounds to the same fp16 as x / 255 for all 256 byte values (checked exhaustively)
+        // (this transform is what bounds the inference stem: its VALU is ~85 % busy.  RGB and grey images skip the products of
+        //  the absent 4th / 2nd-4th channel -- their weights are zero -- behind a uniform branch.)
         float xin[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) xin[c] = (float)(f16)((float)r.b[c] * (1.0f / 255.0f));
         const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8, *bias = s_aff + 6 * cs + c8 * 8;
         f16x8 o;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = s_aff[2 * cs + c8 * 8 + j] * xin[0];
+        if (u8_c > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(s_aff[4 * cs + c8 * 8 + j], xin[2], fmaf(s_aff[3 * cs + c8 * 8 + j], xin[1], acc[j]));
+        }
+        if (u8_c > 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(s_aff[5 * cs + c8 * 8 + j], xin[3], acc[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc = fmaf(s_aff[(2 + c) * cs + c8 * 8 + j], xin[c], acc);   // absent channels: zero weights
-            const f16 z = (f16)fmaxf(acc + bias[j], 0.f);                                            // the stem's stored output
+            const f16 z = (f16)fmaxf(acc[j] + bias[j], 0.f);                                         // the stem's stored output
             o[j] = (f16)((float)z * sc[j] + sh[j]);
         }
         return o;
