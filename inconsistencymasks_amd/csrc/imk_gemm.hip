@@ -41,7 +41,6 @@ struct GemmGeom {
     int tiles_x, tiles_y, n_sp, gy, mt_total;
     int nc8, nc8p, n_pass, nsp, ns_total;     // packed-weight geometry: chunks, chunks per pass, passes, k-steps per pass / in all
     int spp, cps, n_stage, ps;                // passes per stage, chunks per stage, stages, LDS pixel pitch in chunks (odd)
-    int dbg;                                  // experiments (IMK_GEMM_DBG): 1 = weight fragments always from k-step 0 (timing only, wrong results)
     int nc8_2, nc8p_2, ns_2, mt_2;            // CH2: the chained 1x1's k geometry (chunks, chunks per pass, k-steps) and output tiles
 };
 
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     }
     const unsigned lane16 = (unsigned)lane * 16u;
     auto loadA = [&](f16x8 (&af)[PN], int F) {
-        const size_t fo = (size_t)(gm.dbg == 1 ? 0 : min(F, ns_total - 1)) * 1024;
+        const size_t fo = (size_t)min(F, ns_total - 1) * 1024;
 #pragma unroll
         for (int m = 0; m < PN; ++m) af[m] = *reinterpret_cast<const f16x8 *>(wu[m] + fo + lane16);
     };
@@ -413,8 +412,6 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
         if (lds < want && want <= 64 * 1024) lds = want;
     }
     grid = imk_cdiv_d(gm.n_sp, 8) * 8 * gm.gy;
-    static const int dbg = []() { const char *e = getenv("IMK_GEMM_DBG"); return e ? atoi(e) : 0; }();
-    gm.dbg = dbg;
     return IMK_OK;
 }
 
