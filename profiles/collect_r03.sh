@@ -8,6 +8,13 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ "$ONLY" = "times" ]; then    # refresh only the step / inference wall times (section 6)
+cd $R
+{ for C in "isic 0.5" "hela 1" "suim 1" "city 1" "city 1.25" "city 1.5" "city 1.75" "city 2" "isic 1.5"; do set -- $C
+    CONFIG=$1 ALPHA=$2 python3 tests/gpu_probe/step_time.py 2>&1 | grep -E "config|train step|inference"; done
+  python3 tests/gpu_probe/evalnet_time.py 2>&1 | tail -3; } > $OUT/configs_step_times_raw.txt
+exit 0
+fi
 # 1. the default bench command (BASELINE configs[1]), plain and under the kernel trace (+stats)
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
