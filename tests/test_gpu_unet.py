@@ -31,6 +31,9 @@ CFGS = {
     # rows that are not a multiple of the tile height (24), one input channel
     "alpha175": dict(h=48, w=32, c=1, k=2, alpha=1.75, act="sigmoid", loss="mse", b=2),
     "tiny16": dict(h=16, w=16, c=3, k=3, alpha=1.0, act="softmax", loss="cce", b=5),       # one tile per image, 1x1 pixels at the bottom
+    # the one-pass softmax head (imk_headf.hip) at the channel strides the other cases miss: 8 (half a tile) and 32 with two class tiles
+    "half_soft": dict(h=32, w=48, c=3, k=5, alpha=0.5, act="softmax", loss="cce", b=3),
+    "alpha2_soft": dict(h=32, w=32, c=3, k=19, alpha=2.0, act="softmax", loss="cce", b=2),
 }
 
 
