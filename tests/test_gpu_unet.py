@@ -373,6 +373,44 @@ def test_cityscapes_im_plus_schedule_batch32(UNet, alpha):
     assert bool(torch.isfinite(m.params).all())
 
 
+_WGRAD_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from inconsistencymasks_amd.unet import UNet
+alpha = float(sys.argv[2])
+h, w, k, b = 208, 416, 35, 32
+g = torch.Generator(device="cuda").manual_seed(3)
+x = torch.randint(0, 256, (b, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+y = torch.randint(0, k, (b, h, w), dtype=torch.uint8, device="cuda", generator=g)
+m = UNet(h, w, 3, k, alpha, "softmax", seed=17)
+m.fwd_bwd(x, y, 1)
+torch.cuda.synchronize()
+np.save(sys.argv[1], m.grads.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("alpha,env", [(2.0, {"IMK_WGRAD_NFO2": "0"}), (1.25, {"IMK_WGRAD_GEMM_MIN": "33"})])
+def test_full_resolution_weight_gradient_forms_agree(tmp_path, alpha, env):
+    """The full-resolution 3x3 weight gradients of the wide configurations take kernel forms that only exist above 2 M pixels
+    (wgrad_gemm_kernel<.., 2, 2>: two output tiles, 768 splits; the GEMM-class kernel from 24 channels): against the forms the
+    small parity cases exercise (four output tiles / the per-pair kernel), on the same batch-32 Cityscapes step, every gradient
+    tensor agrees to fp32 summation-order noise."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "wgrad_child.py"
+    script.write_text(_WGRAD_CHILD.format(root=root))
+    out = []
+    for i, extra in enumerate(({}, env)):
+        f = tmp_path / f"g{i}.npy"
+        r = subprocess.run([sys.executable, str(script), str(f), str(alpha)], env={**os.environ, **extra}, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(np.load(f))
+    a, b = out
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("name", ["isic", "hela"])
 def test_fused_input_block_matches_stored_one(UNet, name):
     """Inference computes the input block (x/255 -> Conv1x1+ReLU -> BN) inside the first encoder conv's load (LM_STEM) instead of
