@@ -2000,17 +2000,21 @@ bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
     // Where the GEMM-class kernel would take the 3x3 (imk_gemm.hip): IMK_GEMM_OVER_CHAIN = 0 chain anyway, 1 two launches when
     // the intermediate is stored anyway (training), 2 always two launches
     static const int over = []() { const char *e = getenv("IMK_GEMM_OVER_CHAIN"); return e ? atoi(e) : 1; }();
+    if (a.epi == EP_RELU && a.ksize == 3 && (a.x.lmode == LM_POOL || a.x.lmode == LM_AFFINE) && a.cout <= 128 &&
+        cout2 <= 128 && imk_pad8(cout2) <= (a.cout > 64 ? 128 : 64)) {     // the GEMM-class chain (imk_conv_gemm_chain_ok, before wpk2 is set)
+        static const bool gc_off = []() { const char *e = getenv("IMK_GEMM_CHAIN"); return e && e[0] == '0'; }();
+        // training (store_mid): IMK_GEMM_CHAIN_TRAIN = 0 off, 2 only where the two convs have the same width (encoder blocks: the
+        // chain's statistics rows are then bit for bit those of the 1x1's own launch), 1 (default) everywhere
+        static const int gct = []() { const char *e = getenv("IMK_GEMM_CHAIN_TRAIN"); return e ? atoi(e) : 1; }();
+        ImkConvArgs plain = a;
+        plain.wpk2 = nullptr;
+        const bool train_ok = gct == 1 || (gct == 2 && imk_pad8(cout2) == a.cs_out);
+        if (!gc_off && (!store_mid || train_ok) && imk_conv_gemm_ok(plain)) return true;
+    }
     if (over == 2 || (over == 1 && store_mid)) {
         ImkConvArgs plain = a;
         plain.wpk2 = nullptr;
         if (imk_conv_gemm_ok(plain)) return false;
-    }
-    if (!store_mid && a.epi == EP_RELU && a.ksize == 3 && (a.x.lmode == LM_POOL || a.x.lmode == LM_AFFINE) && a.cout <= 128 &&
-        cout2 <= 128 && imk_pad8(cout2) <= (a.cout > 64 ? 128 : 64)) {     // the GEMM-class chain (imk_conv_gemm_chain_ok, before wpk2 is set)
-        static const bool gc_off = []() { const char *e = getenv("IMK_GEMM_CHAIN"); return e && e[0] == '0'; }();
-        ImkConvArgs plain = a;
-        plain.wpk2 = nullptr;
-        if (!gc_off && !plain.stats_partial && imk_conv_gemm_ok(plain)) return true;
     }
     const bool pipe_ok = pipe_enabled() && pipe_fits(a) && a.x.cs_in <= 16 && a.cout <= 16;
     if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;

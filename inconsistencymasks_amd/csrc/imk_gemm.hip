@@ -249,6 +249,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     }
     __syncthreads();
     if constexpr (CH2) {
+        if (a.out) {                                     // training: the backward pass reads the 3x3's output -- one coalesced sweep
+            constexpr int CPP1 = BN / 8, RPI1 = NT / CPP1, IT1 = G_BM / RPI1;
+            const int cj1 = t % CPP1, prow1 = t / CPP1;
+            if (cj1 * 8 < a.cs_out) {
+                const unsigned pitch1 = (unsigned)a.cs_out * 2u;
+                char *ob = const_cast<char *>(pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, pitch1)) + cj1 * 16;
+                const int my1 = H - 1 - tc.ty0, mx1 = W - 1 - tc.tx0;
+#pragma unroll
+                for (int k = 0; k < IT1; ++k) {
+                    const int pixel = prow1 + k * RPI1, py = pixel >> 4, px = pixel & 15;
+                    if (py <= my1 && px <= mx1)
+                        *reinterpret_cast<f16x8 *>(ob + __umul24(__umul24(py, W) + px, pitch1)) = *reinterpret_cast<const f16x8 *>(s_out + pixel * OP + cj1 * 8);
+                }
+            }
+        }
         f32x4 acc2[PN][PM];
 #pragma unroll
         for (int m = 0; m < PN; ++m)
@@ -289,7 +304,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
         __syncthreads();
     }
     IMK_STAMP(5);
-    constexpr int CPP = BN / 8, RPI = NT / CPP, IT = G_BM / RPI;   // chunks per pixel, pixels per sweep, sweeps
+    // The tile leaves in sweeps of 16-byte chunks.  BNV = channels a sweep covers = the tile's width, except for a chained 1x1
+    // with at most 64 outputs behind a 128-wide 3x3 (CH2): its sweep is the one its own 64-wide launch would make, so that the
+    // BatchNorm statistics -- per-thread sums over the sweep's pixels, then a fixed-order reduction -- come out bit for bit the same.
+    auto finish = [&](auto BNV_T) {
+    constexpr int BNV = decltype(BNV_T)::value;
+    constexpr int CPP = BNV / 8, RPI = NT / CPP, IT = G_BM / RPI;   // chunks per pixel, pixels per sweep, sweeps
     const int cj = t % CPP, prow = t / CPP;
     const int ch0 = ct0 * 16 + cj * 8;
     const bool ch_live = ch0 < cs_o;
@@ -336,30 +356,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
         }
     };
     const bool dystat = !CH2 && (a.epi != EP_RELU) && a.dystat_z && a.stats_partial;
-    const bool want_stats = !CH2 && (((a.epi == EP_RELU) && a.stats_partial) || dystat);
+    const bool want_stats = ((a.epi == EP_RELU) && a.stats_partial) || dystat;      // CH2: the statistics of the 1x1's output
     if (a.epi == EP_RELU) { if (want_stats) sweep(I0{}, I1{}); else sweep(I0{}, I0{}); }
     else if (a.epi == EP_MASK) { if (dystat) sweep(I2{}, I2{}); else sweep(I2{}, I0{}); }
     else { if (dystat) sweep(I1{}, I2{}); else sweep(I1{}, I0{}); }
     IMK_STAMP(6);
     if (want_stats) {                                    // workgroup-uniform
         __syncthreads();                                 // everyone is done reading the output tile
-        float *s_red = reinterpret_cast<float *>(smem);  // [2][RPI][BN]
+        float *s_red = reinterpret_cast<float *>(smem);  // [2][RPI][BNV]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            s_red[(0 * RPI + prow) * BN + cj * 8 + e] = s1[e];
-            s_red[(1 * RPI + prow) * BN + cj * 8 + e] = s2[e];
+            s_red[(0 * RPI + prow) * BNV + cj * 8 + e] = s1[e];
+            s_red[(1 * RPI + prow) * BNV + cj * 8 + e] = s2[e];
         }
         __syncthreads();
-        for (int i = t; i < 2 * BN; i += NT) {
-            const int which = i / BN, c = i - which * BN;
+        for (int i = t; i < 2 * BNV; i += NT) {
+            const int which = i / BNV, c = i - which * BNV;
             const int co = ct0 * 16 + c;
             if (co < cs_o) {
                 float v = 0.f;
-                for (int r = 0; r < RPI; ++r) v += s_red[(which * RPI + r) * BN + c];
+                for (int r = 0; r < RPI; ++r) v += s_red[(which * RPI + r) * BNV + c];
                 a.stats_partial[(size_t)sp * 2 * cs_o + which * cs_o + co] = v;
             }
         }
     }
+    };
+    if (CH2 && BN == 128 && cs_o <= 64) finish(std::integral_constant<int, 64>{});
+    else finish(std::integral_constant<int, BN>{});
     IMK_STAMP_END(7);
 }
 
@@ -457,11 +480,16 @@ bool imk_conv_gemm_ok(const ImkConvArgs &a) {
     return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16);
 }
 
-// Conv3x3+ReLU -> Conv1x1+ReLU in one launch of the GEMM-class kernel (inference: no stored intermediate, no statistics): the
-// 3x3 is one this kernel takes, both convs have at most 128 output channels, the 1x1's pack is one k-step per channel pass
+// Conv3x3+ReLU -> Conv1x1+ReLU in one launch of the GEMM-class kernel: the 3x3 is one this kernel takes, both convs have at
+// most 128 output channels, the 1x1's pack is one k-step per channel pass.  Inference: no stored intermediate, no statistics;
+// training: the intermediate is stored (one more sweep of the tile) and the BatchNorm statistics are those of the 1x1's output,
+// one row per workgroup over the same 128 pixels, summed in the order of the 1x1's own launch (see `finish`): bit-identical to
+// two launches
 bool imk_conv_gemm_chain_ok(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_GEMM_CHAIN"); return e && e[0] == '0'; }();
-    if (off || !a.wpk2 || a.out || !a.out2 || a.stats_partial || a.epi != EP_RELU || a.ksize != 3) return false;
+    static const bool train_off = []() { const char *e = getenv("IMK_GEMM_CHAIN_TRAIN"); return e && e[0] == '0'; }();
+    if (off || !a.wpk2 || !a.out2 || a.epi != EP_RELU || a.ksize != 3) return false;
+    if ((a.out || a.stats_partial) && train_off) return false;      // training: the intermediate is stored, statistics on the 1x1's output
     if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
     if (a.cout > 128 || a.cout2 > 128 || a.cs_out2 > (a.cout > 64 ? 128 : 64)) return false;
     ImkConvArgs plain = a;
@@ -485,6 +513,7 @@ int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream) {
                                   : launch_conv_gemm_chain<LM_AFFINE>(a, gm, pn, lds, grid, stream);
         if (rc) return rc;
         IMK_LAUNCH_CHECK();
+        if (a.stats_rows) *a.stats_rows = gm.n_sp;
         return IMK_OK;
     }
 #define IMK_GEMM_LM(LM) (ks3 ? launch_conv_gemm_k<LM, true>(a, gm, pn, lds, grid, stream) : launch_conv_gemm_k<LM, false>(a, gm, pn, lds, grid, stream))

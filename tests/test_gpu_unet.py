@@ -574,38 +574,51 @@ def test_chained_per_tile_conv_is_bit_identical_to_two_launches(tmp_path):
 
 
 _CHAIN3_CHILD = r"""
-import hashlib, sys, torch
+import hashlib, sys, numpy as np, torch
 sys.path.insert(0, {root!r})
 from inconsistencymasks_amd.unet import UNet
 g = torch.Generator(device="cuda").manual_seed(2)
 h = hashlib.sha256()
+params = []
 for (hh, ww, c, k, alpha, act) in [(64, 80, 3, 9, 1.0, "softmax"), (48, 64, 3, 5, 2.0, "softmax"), (80, 48, 1, 3, 1.0, "sigmoid"),
                                    (64, 64, 3, 4, 1.5, "softmax")]:
     x = torch.randint(0, 256, (5, hh, ww, c), dtype=torch.uint8, device="cuda", generator=g)
     m = UNet(hh, ww, c, k, alpha, act, seed=11)
     h.update(m.predict_device(x).cpu().numpy().tobytes())
+    # training: the GEMM-class chain stores the intermediate and takes the BatchNorm statistics of the 1x1's output
+    y = (torch.randint(0, k, (5, hh, ww), dtype=torch.uint8, device="cuda", generator=g) if act == "softmax"
+         else (torch.rand((5, hh, ww, k), device="cuda", generator=g) > 0.6).to(torch.uint8))
+    m.fwd_bwd(x, y, 1 if act == "softmax" else 0)      # (gradients, not parameters after Adam steps: Adam's first updates are
+    torch.cuda.synchronize()                           #  lr * sign(g), which turns rounding noise of near-zero gradients into +-lr)
+    params.append(m.grads.cpu().numpy())
 print("SHA", h.hexdigest())
+np.save(sys.argv[1], np.concatenate(params))
 """
 
 
 def test_chained_wide_and_gemm_convs_are_bit_identical_to_two_launches(tmp_path):
     """Round 3's inference chains -- conv_wide_kernel<..., CHAIN2> (17-32 channel blocks) and conv_gemm_kernel<..., CH2> (blocks up
     to 128 channels): the block's Conv1x1 computed from the 3x3's output tile while it is on the chip, with the 1x1's regular
-    pack in its regular k order -- against the same convs as two launches each: identical probabilities, bit for bit, at
-    ragged sizes and widths 1 / 1.5 / 2 (one process each: the switches are read once)."""
+    pack in its regular k order -- against the same convs as two launches each: identical probabilities, bit for bit; and for the
+    GEMM-class chain in TRAINING (intermediate stored, statistics of the 1x1's output) the same gradients, bit for bit.  Ragged sizes, widths 1 / 1.5 / 2 (one process each: the switches are read once)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "chain3_child.py"
     script.write_text(_CHAIN3_CHILD.format(root=root))
-    got = []
-    for wide, gemm in (("1", "1"), ("0", "0"), ("1", "0")):
+    got, par = [], []
+    for i, (wide, gemm) in enumerate((("1", "1"), ("0", "0"), ("1", "0"))):
         env = {**os.environ, "IMK_WIDE_CHAIN": wide, "IMK_GEMM_CHAIN": gemm}
         if gemm == "0":
             env["IMK_GEMM_OVER_CHAIN"] = "2"       # the 3x3 and the 1x1 as two GEMM-class launches (not the per-tile chain)
-        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        f = tmp_path / f"params{i}.npy"
+        r = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+        par.append(np.load(f))
     assert got[0] == got[1] == got[2], got
+    # Training: the chain's BatchNorm statistics are per-workgroup sums over the same 128 pixels in the same order as the 1x1's own
+    # launch makes them (a 64-wide 1x1 behind a 128-wide 3x3 sweeps its tile the 64-wide way): gradients bit for bit.
+    assert np.array_equal(par[1], par[2]) and np.array_equal(par[0], par[1])
 
 
 _PRE_CHILD = r"""
