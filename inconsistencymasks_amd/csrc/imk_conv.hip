@@ -995,7 +995,8 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
             const int co = 16 * m + 4 * g + r;
             bias[m][r] = (EPI == EP_RELU && a.bias && co < a.cout) ? a.bias[co] : 0.f;
         }
-    const bool want_stats = !CHAIN2 && (DYSTAT || ((EPI == EP_RELU) && a.stats_partial));
+    const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);      // CHAIN2 (training): statistics of the 1x1's output
+    const int cs_st = CHAIN2 ? a.cs_out2 : a.cs_out;                               // channels of the tensor the statistics describe
     bool lane_out[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) lane_out[m] = 16 * m + 4 * g < a.cs_out;      // this lane's 4 channels exist in the output tensor
@@ -1058,15 +1059,19 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
         const char *b_mk = EPI == EP_MASK ? pix_base(a.mask, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
         const char *b_zq = DYSTAT ? pix_base(a.dystat_z, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
         unsigned o1[P];        // byte offset of the lane's pixels in the tensor this launch writes (CHAIN2: the 1x1's output)
+        unsigned o_mid[P];     // CHAIN2 in training: the same pixels in the 3x3's own output tensor
+        const char *b_mid = (CHAIN2 && a.out) ? pix_base(a.out, tc.b, H, W, tc.ty0, tc.tx0, cso_b) : nullptr;
         bool inb[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if constexpr (FULL) {
                 o1[p] = CHAIN2 ? (unsigned)((wave * 4 + p) * W + n) * cso2_b : o1c[p]; inb[p] = true;
+                o_mid[p] = o1c[p];
             } else {        // partial tiles clamp the coordinates used for LOADS (stores are guarded)
                 const int my = H - 1 - tc.ty0, mx = W - 1 - tc.tx0, r = wave * 4 + p;
                 inb[p] = r <= my && n <= mx;
                 o1[p] = __umul24(__umul24(min(r, my), W) + min(n, mx), CHAIN2 ? cso2_b : cso_b);
+                o_mid[p] = __umul24(__umul24(min(r, my), W) + min(n, mx), cso_b);
             }
         }
         f16x4 mk[MT][P], zq[MT][P];
@@ -1115,6 +1120,8 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                         for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[m < MT ? m : 0][p][r] + bias[m < MT ? m : 0][r], 0.f);
                     }
                     *reinterpret_cast<f16x4 *>(s_mid + (p * 16 + n) * MIDP + 16 * m + 4 * g) = v;
+                    if (a.out && m < MT && (FULL || inb[p]) && lane_out[m < MT ? m : 0])     // training: the backward pass reads the 3x3's output
+                        *reinterpret_cast<f16x4 *>(const_cast<char *>(b_mid) + o_mid[p] + 32 * m + 8 * g) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1129,7 +1136,13 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
                         f16x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(d[r] + bias2[m][r], 0.f);
-                        if ((FULL || inb[p]) && lane_out2[m]) *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p] + 32 * m + 8 * g) = v;
+                        if ((FULL || inb[p]) && lane_out2[m]) {
+                            *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p] + 32 * m + 8 * g) = v;
+                            if (want_stats && m < MT) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[m < MT ? m : 0][r] += f; s2[m < MT ? m : 0][r] += f * f; }
+                            }
+                        }
                     }
                 }
             }
@@ -1181,10 +1194,10 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
         __syncthreads();
         if (t < 2 * 16 * MT) {
             const int which = t / (16 * MT), c = t - which * 16 * MT;
-            if (c < a.cs_out) {
+            if (c < cs_st) {
                 const float v = (s_red[(0 * 2 + which) * 16 * MT + c] + s_red[(1 * 2 + which) * 16 * MT + c]) +
                                 (s_red[(2 * 2 + which) * 16 * MT + c] + s_red[(3 * 2 + which) * 16 * MT + c]);
-                a.stats_partial[(size_t)blockIdx.x * 2 * a.cs_out + which * a.cs_out + c] = v;
+                a.stats_partial[(size_t)blockIdx.x * 2 * cs_st + which * cs_st + c] = v;
             }
         }
     }
@@ -1908,7 +1921,9 @@ static bool conv_wide_ok(const ImkConvArgs &a) {
 // Conv3x3+ReLU -> Conv1x1+ReLU in one launch of the wide kernel (inference: the intermediate is not stored, no statistics)
 static bool conv_wide_chain_ok(const ImkConvArgs &a) {
     static const bool off = []() { const char *e = getenv("IMK_WIDE_CHAIN"); return e && e[0] == '0'; }();
-    if (off || !a.wpk2 || a.out || a.stats_partial || a.epi != EP_RELU || a.ksize != 3) return false;
+    static const bool train_off = []() { const char *e = getenv("IMK_WIDE_CHAIN_TRAIN"); return e && e[0] == '0'; }();
+    if (off || !a.wpk2 || a.epi != EP_RELU || a.ksize != 3) return false;
+    if ((a.out || a.stats_partial) && (train_off || a.cout2 > a.cout)) return false;   // training: intermediate stored, statistics of the 1x1's output
     if (a.x.cs_in < 16 || a.x.cs_in > 32 || a.cout > 32 || a.cout2 > 32 || (a.x.cs_in <= 16 && a.cout <= 16)) return false;
     if (a.x.lmode != LM_AFFINE) return false;     // (the pooled-input form, alpha 1's second encoder block, gains nothing: 1.170 vs 1.166 ms)
     ImkConvArgs plain = a;
@@ -2020,7 +2035,11 @@ bool imk_conv_can_chain_tile(const ImkConvArgs &a, int cout2, bool store_mid) {
     if (pipe_ok || a.epi != EP_RELU || a.ksize != 3 || a.cout > 64 || cout2 > 64) return false;
     if (a.x.lmode != LM_POOL && a.x.lmode != LM_AFFINE) return false;
     const bool wide = a.x.cs_in <= 32 && a.cout <= 32 && a.x.lmode != LM_POOL;     // conv_wide_kernel's layers
-    if (mode == 1 && wide && store_mid && (long long)a.B * imk_cdiv(a.H, 16) * imk_cdiv(a.W, TW) > 2048) return false;
+    // (large launches of these layers in training: two conv_wide launches beat the per-tile chain; the persistent kernel's own
+    //  chain -- conv_wide_kernel<..., CHAIN2>, round 3 -- beats both where it applies)
+    static const bool wct_off = []() { const char *e = getenv("IMK_WIDE_CHAIN_TRAIN"); return e && e[0] == '0'; }();
+    const bool wide_chain = !wct_off && wide && a.x.lmode == LM_AFFINE && a.x.cs_in >= 16 && cout2 <= a.cout && pipe_fits(a);
+    if (mode == 1 && wide && store_mid && !wide_chain && (long long)a.B * imk_cdiv(a.H, 16) * imk_cdiv(a.W, TW) > 2048) return false;
     const int mt1 = (a.cout + 15) / 16, mt2 = (cout2 + 15) / 16, mt = (mt1 <= 2 && mt2 <= 2) ? 2 : 4;
     return mt1 <= mt && mt2 <= mt && conv_tile_h(a.x.cs_in, 3) == 16;
 }
