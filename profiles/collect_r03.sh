@@ -15,6 +15,16 @@ cd $R
   python3 tests/gpu_probe/evalnet_time.py 2>&1 | tail -3; } > $OUT/configs_step_times_raw.txt
 exit 0
 fi
+if [ "$ONLY" = "pmc" ]; then      # HBM traffic passes for the other configurations (bench.py reads r03_pmc_traffic_<config>.csv)
+for CFG in suim cityscapes hela; do
+  mkdir -p $OUT/cfg_$CFG
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/cfg_$CFG/pmc_$C -- python3 $R/bench.py --config $CFG --steps 1 --no-cpu-baseline --no-prof > /dev/null 2> $OUT/cfg_$CFG/pmc_$C.err
+  done
+  python3 $R/profiles/summarize.py $OUT/cfg_$CFG
+done
+exit 0
+fi
 # 1. the default bench command (BASELINE configs[1]), plain and under the kernel trace (+stats)
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err

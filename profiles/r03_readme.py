@@ -73,7 +73,7 @@ def main():
 |---|---|
 | `r03_bench.json`, `r03_bench_under_rocprof.json` | the default command `python bench.py` (N = 1, BASELINE configs[1]), plain and under `rocprofv3 --kernel-trace --stats` |
 | `r03_rocprofv3_kernel_stats_raw.csv`, `r03_bench_kernel_stats.csv` | rocprofv3's kernel statistics of that run, raw and with shortened names |
-| `r03_pmc_traffic.csv`, `r03_pmc_traffic_cityscapes_a2.csv` | `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (separate runs), MB per launch per kernel, raw and corrected for gfx950; `bench.py` reads `roofline.traffic` from the file of its configuration |
+| `r03_pmc_traffic.csv`, `r03_pmc_traffic_{suim,cityscapes,hela,cityscapes_a2}.csv` | `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (separate runs), MB per launch per kernel, raw and corrected for gfx950; `bench.py` reads `roofline.traffic` from the file of its configuration |
 | `r03_configs_bench_{suim,cityscapes,hela,cityscapes_a2}.json` | `python bench.py --config ... [--alpha 2]`: the other BASELINE shapes, same line |
 | `r03_configs_kernel_stats_*.csv` | rocprofv3 kernel statistics of those runs |
 | `r03_configs_step_times.txt` | `tests/gpu_probe/step_time.py` / `evalnet_time.py`: wall time of a training step (batch 32) and a 128-image inference call, all shapes and the IM+ width schedule |
