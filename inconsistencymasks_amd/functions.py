@@ -115,8 +115,21 @@ def write_png_async(path, arr):
     if _WRITE_POOL is None:
         import atexit
         _WRITE_POOL = ThreadPoolExecutor(max_workers=_IO_THREADS)
-        atexit.register(flush_writes)
+        atexit.register(_flush_at_exit)
     _PENDING.append(_WRITE_POOL.submit(write_png, path, arr))
+
+
+def _flush_at_exit():
+    """the interpreter ignores exceptions of atexit handlers (the process would still exit 0 with files missing): a failed write
+    that only surfaces here ends the process with status 1"""
+    try:
+        flush_writes()
+    except BaseException:      # noqa: BLE001 -- report and fail, whatever it was
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
 
 
 def flush_writes():

@@ -461,3 +461,15 @@ def test_position_contour_centres_known_answers():
     two[8:13, 8:13] = 0
     two[20:31, 30:41] = 255
     assert sorted(F.get_pos_contours(two, erode_kernel=0)) == [(11, 11), (11, 11), (36, 26)]
+
+
+def test_failed_background_png_write_fails_the_process(tmp_path):
+    """write_png_async + interpreter exit: a write that fails in the background (here: the target directory does not exist) must not
+    end in exit status 0 -- atexit handlers' exceptions are ignored by the interpreter, so the handler exits itself."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from inconsistencymasks_amd import functions as F\n"
+            "F.write_png_async(%r, np.zeros((4, 4), np.uint8))\n") % (root, str(tmp_path / "missing_dir" / "x.png"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
