@@ -87,3 +87,15 @@ def test_gather_pairs_is_an_indexed_copy_with_the_parsers_mask_arithmetic(planes
     ids = torch.randint(0, 35, (37, 1, H, W), dtype=torch.uint8, device="cuda", generator=g)
     _, gi = F.gather_pairs(idx, mask_planar=ids)
     assert torch.equal(gi[..., 0], ids[idx][:, 0])
+
+
+@pytest.mark.gpu
+def test_gather_pairs_more_rows_than_one_launch_takes():
+    """imk_gather_pairs carries the row index on gridDim.y (<= 65535 rows per call); the Python wrapper cuts longer index lists."""
+    import torch
+    from inconsistencymasks_amd import functions as F
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randint(0, 256, (300, 4, 4, 1), dtype=torch.uint8, device="cuda", generator=g)
+    idx = torch.randint(0, 300, (70001,), device="cuda", generator=g)
+    gx, _ = F.gather_pairs(idx, img=x)
+    assert torch.equal(gx, x[idx])
