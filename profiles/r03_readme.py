@@ -80,6 +80,7 @@ def main():
 | `r03_step_timeline_*.txt`, `r03_step_timeline_single_stream_*.txt` | kernel-by-kernel timeline of one step and one inference call (two streams / every kernel alone) for ISIC, SUIM, Cityscapes alpha 1 and 2 |
 | `r03_sq_counters_{isic,city_a2}.csv` | SQ counters per kernel |
 | `r03_bench_2ranks_one_gpu_gloo.json` | `IMK_BENCH_ONE_GPU=1 IMK_BENCH_BACKEND=gloo python bench.py --gpus 2`: the self-launching strong-scaling path with two ranks time-slicing ONE GPU (functional check: `n_gpus` 2, `sharding_check.equals_sum_over_ranks` true; its throughput means nothing).  The RCCL path on one rank (`IMK_FORCE_DIST=1`) gives 23.45 k images/s against 23.93 k without the process group |
+| `r03_full_driver_run.txt` | `tests/gpu_probe/full_driver_run.py`: `ISIC_2018/09_ISIC_2018_IM.py` through PNG directories at the dataset's real size: **34.2 s** per generation of 5 candidates x 50 epochs (35.3 s in round 2, 58.8 s in round 1) |
 | `r03_dp_convergence.txt` | data-parallel convergence of the ISIC toy driver at world 1 / 2 / 4 / 8 (emulated), with the BatchNorm-momentum finding |
 """)
     out.append(f"""Headline (`r03_bench.json`): **{b['value']:.0f} images/s per IM generation on 1 GPU** -- {b['ms_per_step']} ms per generation =
