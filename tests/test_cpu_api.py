@@ -473,3 +473,15 @@ def test_failed_background_png_write_fails_the_process(tmp_path):
             "F.write_png_async(%r, np.zeros((4, 4), np.uint8))\n") % (root, str(tmp_path / "missing_dir" / "x.png"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+
+
+def test_package_import_raises_the_hardware_queue_limit():
+    """More streams than the HIP runtime's hardware queues serialise "concurrent" work (profiles/README.md, round 3): importing the
+    package before the first HIP call sets GPU_MAX_HW_QUEUES=8 unless the caller chose a value."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import inconsistencymasks_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
