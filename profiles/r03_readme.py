@@ -38,6 +38,12 @@ def step_times():
     return out
 
 
+def rocprof_avg():
+    rows = [x for x in csv.DictReader(open(os.path.join(HERE, "r03_bench_kernel_stats.csv")))
+            if x["kernel"].startswith("conv_pipe_kernel") or x["kernel"].startswith("conv_wide_kernel")]
+    return 1000.0 * sum(float(x["total_ms"]) for x in rows) / max(sum(int(x["calls"]) for x in rows), 1)
+
+
 def fam_table(d, top=12):
     r = d["roofline"]
     fam = r["all_families"]
@@ -90,6 +96,10 @@ not a tuned CPU library).  Round 2 ended at 23 316 (100.14 ms).  `cpu_baseline.p
 decisions flip, {ps['im_pixels_differing']} of {ps['im_pixels_total']} IM pixels differ.  `roofline.kernel` = `{r['kernel']}`: {r['achieved']} {r['unit']} = **{r['frac']} of peak** in
 the timed region ({r['avg_us_per_launch']} us per launch), HBM traffic {(r['traffic'] or 0) / 1e6:.1f} MB per launch (`{(r.get('traffic_source') or '').split(' ')[0]}`);
 host time to enqueue one training step {r['step']['train_step']['host_enqueue_ms_per_step']} ms (GPU: {r['step']['train_step']['ms']}).
+Agreement with rocprofv3: over the whole process the family's event-bracketed average is {r['avg_us_per_launch_whole_process']} us per launch
+(`roofline.avg_us_per_launch_whole_process`; {(load('r03_bench_under_rocprof.json') or b)['roofline']['avg_us_per_launch_whole_process']} in the traced run), `r03_bench_kernel_stats.csv` gives {rocprof_avg():.2f} us for the same
+launches (`conv_pipe_kernel` + `conv_wide_kernel` rows): HIP events bracket the kernel AND the ~3.5-4 us launch boundary in front of
+it on its stream, the tracer's begin / end timestamps only the kernel.
 """)
     out.append(fam_table(b))
     out.append("""### The other BASELINE shapes (`bench.py --config`)
