@@ -443,7 +443,7 @@ constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
 // operand layout per pixel).
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
-                                                        unsigned magic_tx, int grid_q, int grid_r) {
+                                                        unsigned magic_tx, ImkWalk wk) {
     static_assert(PRE == 0 || (WG == 0 && EPI == EP_RELU && !DYSTAT && (LM == LM_U8 || LM == LM_UPADD)), "pre-stage: inference forward only");
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
@@ -629,8 +629,13 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         o2c[p] = lp * cso2_b + co0 * 2;
     }
 
-    int tile = blockIdx.x;                // < n_tiles: the grid never exceeds the tile count
-    PTile tc = ptile_at(tile / per_img, tile % per_img, tiles_x, magic_tx);
+    // this workgroup's tiles: tile, tile + wk.step, ... inside its group's range (ImkWalk, imk_stage.h); a workgroup without a
+    // tile (possible when the ranges are uneven) prefetches the launch's last tile and writes zero statistics rows
+    const int wgrp = blockIdx.x & ((1 << wk.shift) - 1);
+    int tile = wgrp * wk.chunk + (int)(blockIdx.x >> wk.shift);
+    const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
+    const int tile0 = min(tile, n_tiles - 1);
+    PTile tc = ptile_at(tile0 / per_img, tile0 % per_img, tiles_x, magic_tx);
     issue(tc);
     stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
     if constexpr (WG == 3) {              // BatchNorm of the conv's input (LM_RAW leaves the table free)
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in; nothing older is pending in the loop
     __syncthreads();                      // affine table visible
-    while (tile < n_tiles) {
+    while (tile < tile_end) {
         // registers -> LDS (BN / pool / up+add / u8 conversion applied here)
         if constexpr (U8ROWS) {
             if (t < u8_nseg) *reinterpret_cast<uint4 *>(s_u8 + t * 16) = rowseg;
@@ -709,8 +714,8 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 else zq[p] = *reinterpret_cast<const f16x4 *>(b_zq + o1l[p]);
             }
         }
-        const int next = tile + gridDim.x;
-        const PTile tn = next < n_tiles ? ptile_next(tc, grid_q, grid_r, per_img, tiles_x, magic_tx) : tc;
+        const int next = tile + wk.step;
+        const PTile tn = next < tile_end ? ptile_next(tc, wk.q, wk.r, per_img, tiles_x, magic_tx) : tc;
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         if constexpr (PRE) {
             // rows / columns of the halo tile that lie inside the image (the 3x3 pads its INPUT with zeros, not the 1x1's)
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 // chain (conv_mfma_kernel<..., CHAIN>) for these widths: persistent workgroups, next tile's loads in flight, weights staged once.
 template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL, bool CHAIN2 = false>
 __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
-                                                        unsigned magic_tx, int grid_q, int grid_r) {
+                                                        unsigned magic_tx, ImkWalk wk) {
     constexpr int P = 4;
     constexpr int PS = NC8 | 1;
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
@@ -1039,13 +1044,18 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
 #pragma unroll
     for (int p = 0; p < P; ++p) o1c[p] = (unsigned)((wave * 4 + p) * W + n) * cso_b;
 
-    int tile = blockIdx.x;                // < n_tiles: the grid never exceeds the tile count
-    PTile tc = ptile_at(tile / per_img, tile % per_img, tiles_x, magic_tx);
+    // this workgroup's tiles: tile, tile + wk.step, ... inside its group's range (ImkWalk, imk_stage.h); a workgroup without a
+    // tile (possible when the ranges are uneven) prefetches the launch's last tile and writes zero statistics rows
+    const int wgrp = blockIdx.x & ((1 << wk.shift) - 1);
+    int tile = wgrp * wk.chunk + (int)(blockIdx.x >> wk.shift);
+    const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
+    const int tile0 = min(tile, n_tiles - 1);
+    PTile tc = ptile_at(tile0 / per_img, tile0 % per_img, tiles_x, magic_tx);
     issue(tc);
     stage_affine_table(a.x, s_aff);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): weights, biases and the first tile are in
     __syncthreads();                      // affine table and weights visible
-    while (tile < n_tiles) {
+    while (tile < tile_end) {
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
             if (it_lds[k] >= 0) {
@@ -1087,8 +1097,8 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
 #pragma unroll
                 for (int p = 0; p < P; ++p) zq[m][p] = *reinterpret_cast<const f16x4 *>(b_zq + o1[p] + (lane_out[m] ? 32 * m + 8 * g : 0));
         }
-        const int next = tile + gridDim.x;
-        const PTile tn = next < n_tiles ? ptile_next(tc, grid_q, grid_r, per_img, tiles_x, magic_tx) : tc;
+        const int next = tile + wk.step;
+        const PTile tn = next < tile_end ? ptile_next(tc, wk.q, wk.r, per_img, tiles_x, magic_tx) : tc;
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         f32x4 acc[MT][P];
 #pragma unroll
@@ -1210,7 +1220,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
 
 // LM = how the conv's input is materialised (same modes as the forward).  Persistent over tiles with the next
 // tile's global loads issued into registers before the MFMAs of the current one (same scheme as conv_pipe_kernel).
-struct ImkWgradGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco; };
+struct ImkWgradGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco; ImkWalk wk; };
 
 // bx = split (walks tiles bx, bx + nbx, ...), by = (input-channel tile, output-channel tile) pair of nby
 // The prefetch loads are unconditional (clamped coordinates, idle slots repeat slot 0) and BNB (BatchNorm backward on the
@@ -1312,10 +1322,15 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
         }
     };
 
-    int tile = bx;
+    // this split's tiles: an XCD-aware walk over the split index (ImkWalk, imk_stage.h; nbx is a multiple of 8 there, so
+    // bx & 7 is the block's XCD group whatever by is)
+    const ImkWalk wk = gm.wk;
+    const int wgrp = bx & ((1 << wk.shift) - 1);
+    int tile = wgrp * wk.chunk + (bx >> wk.shift);
+    const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
     issue(tile < n_tiles ? tile : n_tiles - 1);
     __syncthreads();   // affine table visible
-    while (tile < n_tiles) {
+    while (tile < tile_end) {
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             if (x_lds[k] >= 0) {
@@ -1342,8 +1357,8 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
             *reinterpret_cast<f16x8 *>(s_d + d_lds[k]) = v;
         }
         __syncthreads();
-        const int next = tile + nbx;
-        issue(next < n_tiles ? next : tile);     // in flight during the MFMAs below (the last one re-reads this tile)
+        const int next = tile + wk.step;
+        issue(next < tile_end ? next : tile);    // in flight during the MFMAs below (the last one re-reads this tile)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 2 * (wave + 4 * kk);          // tile rows r0, r0+1 form this k-step's 32 pixels
@@ -1780,8 +1795,9 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
+    const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
     ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -1877,8 +1893,9 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
+    const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
     ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), grid / (tiles_x * tiles_y), grid % (tiles_x * tiles_y));
+    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -2139,8 +2156,13 @@ static int plan_wgrad(const ImkWgradArgs &a, WgradLaunch &L) {
     size_t lds = ((size_t)18 * 18 + 256) * WG_STRIDE_H * sizeof(f16) + (4 * (size_t)a.x.cs_in + 3 * (size_t)a.cs_out) * sizeof(float);
     const size_t red = 4 * (size_t)(a.ksize == 3 ? 10 : 2) * 256 * sizeof(float);     // the four waves' accumulators at the end
     if (lds < red) lds = red;
-    L.gm = ImkWgradGeom{tiles_x, tiles_y, a.B * tiles_x * tiles_y, cit_n, cot_n, a.x.cs_in / 8, a.cs_out / 8};
+    L.gm = ImkWgradGeom{tiles_x, tiles_y, a.B * tiles_x * tiles_y, cit_n, cot_n, a.x.cs_in / 8, a.cs_out / 8, ImkWalk{}};
     L.gx = a.n_split; L.gy = cit_n * cot_n; L.lds = lds;
+    {   // the split count is the caller's (one partial row per split): the XCD-aware walk only where it is a multiple of 8
+        int g = a.n_split;
+        L.gm.wk = imk_walk_make(g, L.gm.n_tiles, tiles_x * tiles_y);
+        if (g != a.n_split) { g = a.n_split; L.gm.wk = ImkWalk{L.gm.n_tiles, 0, g, 0, 0}; }
+    }
     return IMK_OK;
 }
 

@@ -3,6 +3,7 @@
 // BatchNorm, max-pool, upsample + add, x/255 or the BatchNorm backward applied on load (ImkLoadMode) -- and the
 // (scalar tile base) + (32-bit lane offset) address arithmetic.
 #pragma once
+#include <cstdlib>
 #include "imk_kernels.h"
 #include "imk_elem.h"
 
@@ -282,6 +283,28 @@ __device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid
     if (r >= per_img) { r -= per_img; ++b; }
     return ptile_at(b, r, tiles_x, magic_tx);
 }
+// Persistent walk over the tiles of a launch, XCD-aware (round 4).  Workgroups are dealt round-robin over the 8 XCDs (blocks b
+// and b + 8 share one: MI355X_MICROARCH.md, "Workgroup dispatch"), each XCD has its own 4 MiB L2, and a plain walk
+// (tile = block, block + grid, ...) hands neighbouring tiles to DIFFERENT XCDs -- every halo row / column of a 3x3 input was
+// then fetched through the fabric by each of its 2-4 tiles (FETCH_SIZE 1.4-1.6x the algorithmic bytes on the full-resolution
+// launches, profiles/r03_pmc_traffic.csv).  Here group g = block & (2^shift - 1) owns the contiguous tile range
+// [g * chunk, (g + 1) * chunk) and its workgroups (block >> shift = 0 .. step - 1) sweep it together, a band of `step`
+// neighbouring tiles per iteration: the halo re-reads are hits in that XCD's L2.  shift = 0 is the plain walk.  Placement is a
+// matter of speed only; any block -> XCD map gives the same results.
+struct ImkWalk { int chunk, shift, step, q, r; };      // q, r: step = q images + r tiles
+inline ImkWalk imk_walk_make(int &grid, int n_tiles, int per_img) {
+    static const bool off = []() { const char *e = getenv("IMK_XCD_WALK"); return e && e[0] == '0'; }();
+    ImkWalk w{};
+    if (!off && grid >= 64 && n_tiles >= 64) {
+        grid &= ~7;
+        w.shift = 3; w.chunk = (n_tiles + 7) / 8; w.step = grid / 8;
+    } else {
+        w.shift = 0; w.chunk = n_tiles; w.step = grid;
+    }
+    w.q = w.step / per_img; w.r = w.step % per_img;
+    return w;
+}
+
 // base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)
 __device__ __forceinline__ const char *pix_base(const void *ptr, int b, int hh, int ww, int y, int x, unsigned pitch_b) {
     return reinterpret_cast<const char *>(ptr) + ((long long)(b * hh + y) * ww + x) * (long long)pitch_b;
