@@ -344,13 +344,9 @@ def main():
     ap.add_argument("--prof-period", type=int, default=61, help="time every k-th hooked kernel launch with HIP events")
     ap.add_argument("--pretrain-steps", type=int, default=300)
     ap.add_argument("--bn-settle-steps", type=int, default=600)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (isic, 1 GPU) only: skip the short runs of the other BASELINE shapes appended as other_configs")
     args = ap.parse_args()
-    cfg = dict(CONFIGS[args.config])
-    if args.alpha is not None:
-        cfg["alpha"] = args.alpha
-        cfg["workload"] += f" [--alpha {args.alpha}]"
-    H, W, C, K, ALPHA, N_MODELS, ACT, LOSS = (cfg[k] for k in ("h", "w", "c", "k", "alpha", "n_models", "act", "loss"))
-    binary = ACT == "sigmoid"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -387,6 +383,49 @@ def main():
         import ctypes as _ct
         _ct.CDLL(None).fflush(None)            # ... and flushed now, so that the JSON line below stays the LAST line of stdout
     n_gpus = dist.get_world_size() if use_dist else 1
+    env = dict(rank=rank, world=world, dev=dev, dist=dist, use_dist=use_dist, n_gpus=n_gpus)
+    out = run_config(args, args.config, args.alpha, env, primary=True)
+    # The other BASELINE shapes (configs[2..4] and the last IM+ width), two generations each, so that the one default command
+    # times them too: same generation(), same line fields (value, ms_per_step, stage_ms, roofline).  Only for the plain default
+    # run -- an explicit --config / --alpha / --images run stays what was asked for.
+    default_run = (world == 1 and not use_dist and args.config == "isic" and args.alpha is None and args.images is None
+                   and args.labeled is None and not args.no_other_configs)
+    if default_run:
+        others = {}
+        for key, name, alpha in (("suim", "suim", None), ("cityscapes", "cityscapes", None), ("hela", "hela", None),
+                                 ("cityscapes_a2", "cityscapes", 2.0)):
+            a2 = argparse.Namespace(**vars(args))
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.infer_batch, a2.step_events = 2, 1, True, None, False
+            t0 = time.perf_counter()
+            try:
+                o = run_config(a2, name, alpha, env, primary=False)
+                r = o["roofline"]
+                others[key] = {"value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"],
+                               "stage_ms": o["stage_ms"], "workload": o["config"]["workload"], "alpha": o["config"]["alpha"],
+                               "epoch_steps": o["config"].get("epoch_steps"), "n_models": o["config"]["n_models"],
+                               "train_step_ms": r["step"]["train_step"]["ms"],
+                               "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                  "traffic_source", "frac_rocprof", "avg_us_per_launch")},
+                               "wall_s": round(time.perf_counter() - t0, 1)}
+            except Exception as e:      # the headline must survive a failure here; the failure is reported, not hidden
+                others[key] = {"error": f"{type(e).__name__}: {e}"}
+        out["other_configs"] = others
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_config(args, config_name, alpha, env, primary):
+    """One bench line (dict, on rank 0; None elsewhere) for BASELINE shape `config_name` at width `alpha` (None: the shape's own)."""
+    rank, world, dev, dist, use_dist, n_gpus = (env[k] for k in ("rank", "world", "dev", "dist", "use_dist", "n_gpus"))
+    cfg = dict(CONFIGS[config_name])
+    if alpha is not None:
+        cfg["alpha"] = alpha
+        cfg["workload"] += f" [--alpha {alpha:g}]"
+    H, W, C, K, ALPHA, N_MODELS, ACT, LOSS = (cfg[k] for k in ("h", "w", "c", "k", "alpha", "n_models", "act", "loss"))
+    binary = ACT == "sigmoid"
     strong = args.scaling == "strong"
 
     import ctypes
@@ -448,6 +487,8 @@ def main():
         models.append(m)
     ens = F.EnsembleIM(models)
     student = UNet(H, W, C, K, ALPHA, ACT, seed=7, device=dev)
+    bn_rule, bn_mom = F.dp_bn_momentum_rule(world)      # > 1 rank: 0.99^N unless IMK_DP_BN_MOMENTUM=reference (functions.py)
+    student.set_bn_momentum(bn_mom)
     init_params = student.params.clone()
     gen_perm = torch.Generator(device=dev).manual_seed(42 + rank)
     fwd_flops = conv_flops_per_image(student, cfg)
@@ -549,6 +590,12 @@ def main():
     barrier()
     setup_prof = prof_collect()
     rec = []
+    # For rocprofv3 cross-checks (profiles/summarize.py): a marker dispatch either side of the timed region -- outside the clock --
+    # and, inside it, the library's per-kernel-name sums of launches and algorithmic bytes
+    if primary and not args.no_prof:
+        prof.totals(True)
+        Profiler.mark(1)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     # Sampling: an event record is a barrier packet on the stream (~5 us before the next kernel starts), so bracketing
     # every launch costs ~10 % of a training step; every 61st hooked launch (prime, coprime to the ~135 launches of a
@@ -557,6 +604,11 @@ def main():
         totals = generation(rec)
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_totals = None
+    if primary and not args.no_prof:
+        Profiler.mark(2)
+        kernel_totals = prof.totals_dump()
+        prof.totals(False)
     pc, pms, pby, pfl = prof_collect()
     prof.set_period(0)
     # host cost of enqueueing a step (fwd_bwd + all-reduce + adamw), outside the timed region: from an idle device, 8 steps at
@@ -621,8 +673,8 @@ def main():
     try:
         import csv
         fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
-        tag = "" if args.config == "isic" and args.alpha is None else f"_{args.config}" + (f"_a{args.alpha:g}" if args.alpha is not None else "")
-        for name in (f"r03_pmc_traffic{tag}.csv",) + (("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if not tag else ()):
+        tag = "" if config_name == "isic" and alpha is None else f"_{config_name}" + (f"_a{alpha:g}" if alpha is not None else "")
+        for name in (f"r04_pmc_traffic{tag}.csv", f"r03_pmc_traffic{tag}.csv") + (("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if not tag else ()):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -632,6 +684,24 @@ def main():
                 traffic = round(1e6 * sum(int(r["launches"]) * float(r["hbm_MB_per_launch_corrected(2*fetch+write)"]) for r in rows) / nl)
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, launch-weighted mean)"
                 break
+    except Exception:
+        pass
+    # The same fraction from rocprofv3's own durations: the family's launches INSIDE the timed region of the committed kernel trace
+    # of this command (profiles/summarize.py cuts the trace at the marker dispatches) against this run's algorithmic bytes / flops
+    frac_rocprof, rocprof_src, rocprof_us = None, None, None
+    try:
+        import csv
+        path = os.path.join(ROOT, "profiles", "r04_timed_region_kernel_stats.csv")
+        if primary and os.path.exists(path) and pc[v]:
+            fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
+            fams = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook
+            rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(fams)]
+            calls = sum(int(r["calls"]) for r in rows)
+            if calls:
+                rocprof_us = sum(int(r["calls"]) * float(r["avg_us"]) for r in rows) / calls
+                per_launch = (pfl[v] if mfma_bound else pby[v]) / pc[v]
+                frac_rocprof = round(per_launch / rocprof_us / (1e6 if mfma_bound else 1e3) / peak, 4)
+                rocprof_src = "profiles/r04_timed_region_kernel_stats.csv (rocprofv3 --kernel-trace of this command, dispatches between the timed region's markers)"
     except Exception:
         pass
     whole_n = setup_prof[0][v] + pc[v]
@@ -658,6 +728,8 @@ def main():
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": FAMILIES[v], "achieved": round(achieved, 1), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
+                "frac_rocprof": frac_rocprof, "rocprof_avg_us_per_launch": round(rocprof_us, 2) if rocprof_us else None,
+                "frac_rocprof_source": rocprof_src,
                 "avg_us_per_launch_whole_process": round(1000 * whole_ms / max(whole_n, 1), 2),
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
                 "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
@@ -707,6 +779,7 @@ def main():
                  "frac_of_hbm_peak": round(im_bytes / im_ms / 1e6 / HBM_PEAK_GBS, 4),
                  "bytes_per_launch": im_bytes, "ms_per_launch": round(im_ms, 4)}
 
+    out = None
     if rank == 0:
         n_images = U_total if strong else U_total * world
         out = {
@@ -716,27 +789,30 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": cfg["workload"], "name": args.config, "alpha": ALPHA, "shape": [H, W, C], "outputs": K,
+            "config": {"workload": cfg["workload"], "name": config_name, "alpha": ALPHA, "shape": [H, W, C], "outputs": K,
                        "unlabeled_images": n_images, "unlabeled_images_per_gpu": U,
                        "labeled_images": L_total if strong else L_total * world,
                        "n_models": N_MODELS, "infer_batch": infer_batch, "train_batch_per_gpu": BATCH,
                        "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                       "bn_momentum": {"rule": bn_rule, "value": round(bn_mom, 6)},
                        "process_group": (os.environ.get("IMK_BENCH_BACKEND", "nccl") + (" (forced, 1 rank)" if world == 1 else "")) if use_dist else None,
                        **{k: v for k, v in info.items() if k != "n_train"}},
             "stage_ms": {"ensemble_infer_plus_im": round(t_inf, 2), "train_epoch": round(t_ep, 2)},
             "roofline": roofline,
             "im_kernel": im_kernel,
         }
+        if kernel_totals:
+            out["timed_region_kernel_totals"] = {k: {"launches": t["launches"], "MB_per_launch": round(t["bytes"] / max(t["launches"], 1) / 1e6, 3),
+                                                     "GFLOP_per_launch": round(t["flops"] / max(t["launches"], 1) / 1e9, 4)}
+                                                 for k, t in sorted(kernel_totals.items())}
         if sharding_check:
             out["sharding_check"] = sharding_check
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is a 1-GPU-run item (rank 0 only)
             out["cpu_baseline"] = cpu_baseline(cfg, U_total, L_total, fwd_flops)
             out["cpu_baseline"]["parity_sample"] = parity_sample(cfg, models, x_unl)
             out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    prof.close()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

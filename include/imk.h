@@ -296,6 +296,7 @@ IMK_API int imk_evalnet_tensor_info(const imk_unet_plan *plan, int batch, int mo
  * N times fewer optimizer steps per epoch: 0.99^N keeps the moving average's memory the same in SAMPLES (functions.py of this
  * repository: IMK_DP_BN_MOMENTUM=scaled; off by default, it is a deviation from the reference's recipe). */
 IMK_API int imk_unet_plan_set_bn_momentum(imk_unet_plan *plan, float momentum);
+IMK_API int imk_unet_plan_get_bn_momentum(const imk_unet_plan *plan, float *momentum);
 
 /* Debug / measurement switches of ONE plan (U-Net or EvalNet); -1 leaves a switch as it is.  The library keeps no global state:
  * the caller owns the plan and these two flags in it.
@@ -305,6 +306,18 @@ IMK_API int imk_unet_plan_set_bn_momentum(imk_unet_plan *plan, float momentum);
  *   single_stream = 1: every kernel runs on the caller's stream (no side stream for the weight gradients, the ensemble's models
  *     back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
 IMK_API int imk_unet_plan_debug(imk_unet_plan *plan, int materialize, int single_stream);
+
+/* Runtime environment checks.  imk_runtime_warnings() returns a bit mask of conditions the library has noticed so far in this
+ * process (it also prints each once to stderr):
+ *   IMK_WARN_HW_QUEUES  a side stream was requested (training step, ensemble forward) while GPU_MAX_HW_QUEUES is unset or
+ *                       below 8: the HIP runtime's default of 4 hardware queues lets a side stream share the queue of the
+ *                       stream it should run beside (measured: -14 % per generation).  Export GPU_MAX_HW_QUEUES=8 before the
+ *                       first HIP call of the process (the Python package does so at import).
+ * imk_unet_plan_side_stream returns side stream i (0 .. 1) of `plan` as a hipStream_t, creating it if needed -- the streams
+ * belong to ONE pool per device shared by every plan (U-Net or EvalNet) of the process. */
+#define IMK_WARN_HW_QUEUES 1
+IMK_API int imk_runtime_warnings(void);
+IMK_API int imk_unet_plan_side_stream(const imk_unet_plan *plan, int i, void **stream_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of every kernel family of the path, on the stream the
@@ -326,7 +339,17 @@ typedef struct imk_prof imk_prof;   /* opaque, host memory */
 IMK_API int imk_prof_create(int period, imk_prof **out);
 IMK_API void imk_prof_destroy(imk_prof *ctx);
 IMK_API int imk_prof_bind(imk_prof *ctx);              /* ctx or NULL (unbind) for the calling thread */
+IMK_API int imk_prof_unbind(imk_prof *ctx);            /* unbinds the calling thread only if `ctx` is what it has bound (1 if it did, else 0) */
 IMK_API int imk_prof_set_period(imk_prof *ctx, int period);
+/* Totals for rocprofv3 cross-checks: while enabled, EVERY hooked launch of the bound thread adds its launch count, algorithmic
+ * bytes and flops to a per-kernel-name sum (the conv_pipe / conv_wide families by template variant, spelled as rocprofv3 prints
+ * them; the others by family).  imk_prof_totals_enable(ctx, on) clears the sums and switches them on / off;
+ * imk_prof_totals_dump writes "name;launches;bytes;flops" lines into buf (cap bytes) and returns the size needed.
+ * imk_prof_mark enqueues an empty marker kernel (imk_mark_kernel, 64 * id work-items) on `stream`: bench.py brackets its timed
+ * region with ids 1 and 2 so that profiles/summarize.py can cut a kernel trace there. */
+IMK_API int imk_prof_totals_enable(imk_prof *ctx, int on);
+IMK_API int64_t imk_prof_totals_dump(imk_prof *ctx, char *buf, int64_t cap);
+IMK_API int imk_prof_mark(int id, void *stream);
 IMK_API int imk_prof_collect(imk_prof *ctx, int64_t *count, double *ms, double *bytes, double *flops);
 
 #ifdef __cplusplus

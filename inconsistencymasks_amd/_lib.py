@@ -79,9 +79,16 @@ SIGNATURES = {
     "imk_eval_soft_sums": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "imk_unet_plan_debug": (c_int, [c_void_p, c_int, c_int]),
     "imk_unet_plan_set_bn_momentum": (c_int, [c_void_p, c_float]),
+    "imk_unet_plan_get_bn_momentum": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
     "imk_prof_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "imk_prof_destroy": (None, [c_void_p]),
     "imk_prof_bind": (c_int, [c_void_p]),
+    "imk_prof_unbind": (c_int, [c_void_p]),
+    "imk_prof_totals_enable": (c_int, [c_void_p, c_int]),
+    "imk_prof_totals_dump": (c_int64, [c_void_p, ctypes.c_char_p, c_int64]),
+    "imk_prof_mark": (c_int, [c_int, c_void_p]),
+    "imk_runtime_warnings": (c_int, []),
+    "imk_unet_plan_side_stream": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "imk_prof_set_period": (c_int, [c_void_p, c_int]),
     "imk_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_double)]),

@@ -45,12 +45,17 @@ enum ImkProfFamily {
     PF_COUNT = 18
 };
 // Returns a slot >= 0 when this launch is sampled (an event was recorded on `stream`), else -1.
-int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream, double flops = 0.0);
+// variant: the launched kernel's name as rocprofv3 prints it (template arguments included) where a family has several variants
+// of very different cost (conv_pipe / conv_wide); nullptr = the family's name.  With totals enabled (imk_prof_totals_enable) the
+// bound context sums launches / algorithmic bytes / flops of EVERY hooked launch per such name -- what profiles/summarize.py
+// divides by rocprofv3's own per-kernel durations.
+int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream, double flops = 0.0, const char *variant = nullptr);
 void imk_prof_end(int slot, hipStream_t stream);
 struct ImkProfScope {
     int slot;
     hipStream_t stream;
-    ImkProfScope(int family, double bytes, hipStream_t s, double flops = 0.0) : slot(imk_prof_begin(family, bytes, s, flops)), stream(s) {}
+    ImkProfScope(int family, double bytes, hipStream_t s, double flops = 0.0, const char *variant = nullptr)
+        : slot(imk_prof_begin(family, bytes, s, flops, variant)), stream(s) {}
     ~ImkProfScope() { if (slot >= 0) imk_prof_end(slot, stream); }
     ImkProfScope(const ImkProfScope &) = delete;
     ImkProfScope &operator=(const ImkProfScope &) = delete;

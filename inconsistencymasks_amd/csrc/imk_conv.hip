@@ -1607,10 +1607,22 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 }
 
 // ---- optional per-launch event timing (bench.py roofline) ---------------------------------------------
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
 #include <new>
+#include <string>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int variant; double bytes, flops; };
+struct ProfTot { long long launches = 0; double bytes = 0, flops = 0; };
+const char *const kFamilyNames[PF_COUNT] = {
+    "conv_mfma_kernel<16, 1>", "conv_mfma_kernel<16, 2>", "conv_mfma_kernel<16, 4>", "conv_mfma_kernel<8, 1>", "conv_mfma_kernel<8, 2>",
+    "conv_mfma_kernel<8, 4>", "conv_pipe_kernel", "wgrad_mfma_kernel", "bn_bwd_prep_kernel", "bn_bwd_coef_kernel", "bn_finalize_kernel",
+    "wgf_stage1+2_kernel", "head_kernel", "head_loss_kernel", "step_tail", "im_kernel", "conv_gemm_kernel", "wgrad_gemm_kernel"};
+// marker dispatch for kernel traces: its grid size (64 * id work-items) carries the id
+__global__ void imk_mark_kernel(int id) { (void)id; }
 }  // namespace
 // Measurement context (include/imk.h: imk_prof_*): owned by the caller, bound to the thread that launches -- the library itself
 // keeps no mutable global, only this per-thread binding
@@ -1619,6 +1631,8 @@ struct imk_prof {
     long counter = 0;
     std::vector<ProfRec> recs;         // recorded launches since the last collect
     std::vector<hipEvent_t> pool;      // recycled events
+    bool totals_on = false;            // sum every hooked launch per kernel name (imk_prof_totals_*)
+    std::map<std::string, ProfTot> totals;
     hipEvent_t event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e;
@@ -1644,10 +1658,15 @@ extern "C" void imk_prof_destroy(imk_prof *p) {
     delete p;
 }
 extern "C" int imk_prof_bind(imk_prof *p) { t_prof = p; return IMK_OK; }
+extern "C" int imk_prof_unbind(imk_prof *p) { if (p && t_prof == p) { t_prof = nullptr; return 1; } return 0; }
 extern "C" int imk_prof_set_period(imk_prof *p, int period) { IMK_CHECK_ARG(p && period >= 0); p->period = period; return IMK_OK; }
 
-int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops) {
+int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops, const char *variant) {
     imk_prof *p = t_prof;
+    if (p && p->totals_on && family >= 0 && family < PF_COUNT) {
+        ProfTot &t = p->totals[variant ? variant : kFamilyNames[family]];
+        t.launches += 1; t.bytes += bytes; t.flops += flops;
+    }
     if (!p || p->period <= 0 || (p->counter++ % p->period) != 0) return -1;
     ProfRec pr{p->event(), p->event(), family, bytes, flops};
     if (hipEventRecord(pr.e0, stream) != hipSuccess) { p->pool.push_back(pr.e0); p->pool.push_back(pr.e1); return -1; }
@@ -1657,6 +1676,36 @@ int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops) {
 void imk_prof_end(int slot, hipStream_t stream) {
     imk_prof *p = t_prof;
     if (p && slot >= 0 && slot < (int)p->recs.size()) (void)hipEventRecord(p->recs[slot].e1, stream);
+}
+
+extern "C" int imk_prof_totals_enable(imk_prof *p, int on) {
+    IMK_CHECK_ARG(p);
+    p->totals.clear();
+    p->totals_on = on != 0;
+    return IMK_OK;
+}
+// "name;launches;bytes;flops\n" per kernel name; returns the bytes needed incl. the terminating 0 (call again if > cap)
+extern "C" int64_t imk_prof_totals_dump(imk_prof *p, char *buf, int64_t cap) {
+    if (!p) return IMK_EINVAL;
+    std::string out;
+    char line[160];
+    for (auto &kv : p->totals) {
+        snprintf(line, sizeof line, ";%lld;%.0f;%.0f\n", kv.second.launches, kv.second.bytes, kv.second.flops);
+        out += kv.first; out += line;
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, out.size());
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+// A marker dispatch on `stream` (kernel imk_mark_kernel, grid size 64 * id): lets a kernel trace be cut at the timed region
+extern "C" int imk_prof_mark(int id, void *stream) {
+    IMK_CHECK_ARG(id > 0 && id < 65536);
+    imk_mark_kernel<<<id, 64, 0, (hipStream_t)stream>>>(id);
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
 }
 
 extern "C" int imk_prof_collect(imk_prof *p, int64_t *count, double *ms, double *bytes, double *flops) {
@@ -1796,7 +1845,13 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
+    static const std::string vname = []() {     // as rocprofv3 prints the instantiation
+        char b[128];
+        snprintf(b, sizeof b, "conv_pipe_kernel<%d, %d, %d, %s, %d, %s, %s, %d, %d>", LM, NC8, CHAIN, PAIR ? "true" : "false", EPI,
+                 DYSTAT ? "true" : "false", FULL ? "true" : "false", WG, PRE);
+        return std::string(b);
+    }();
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -1894,7 +1949,13 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
+    static const std::string vname = []() {
+        char b[128];
+        snprintf(b, sizeof b, "conv_wide_kernel<%d, %d, %d, %d, %s, %s, %s>", LM, NC8, MT, EPI, DYSTAT ? "true" : "false",
+                 FULL ? "true" : "false", CHAIN2 ? "true" : "false");
+        return std::string(b);
+    }();
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
     kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;

@@ -178,3 +178,8 @@ struct ImkWgFinalJob {
 struct ImkWgFinalJobs { ImkWgFinalJob j[IMK_WGF_MAX_JOBS]; int n, total_work1, total_tiles; };
 int imk_wgf_add_job(ImkWgFinalJobs &jobs, float *partial, int n_split, int ksize, int cin, int cout, float *dw, float *db);
 int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_scale_ptr, float *found_inf, hipStream_t stream);
+
+// Side streams (training: weight gradients; ensemble inference: one model per stream): ONE pool per device for the whole
+// process, defined in imk_unet.hip.  Stream i of the calling thread's current device, created on first use; nullptr on failure.
+// The first creation also checks GPU_MAX_HW_QUEUES (imk_runtime_warnings, include/imk.h).
+hipStream_t imk_side_pool_stream(int i);

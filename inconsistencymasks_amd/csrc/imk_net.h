@@ -553,20 +553,8 @@ struct Bwd {
 // costs concurrency somewhere -- with RCCL's own stream in the process, a second idle pool stream was enough to put the weight
 // gradients in line behind the main chain again (forced one-rank run: 20.6 k instead of 23.7 k images/s; package __init__
 // also raises GPU_MAX_HW_QUEUES to 8 when it is imported before the HIP runtime starts).
-struct ImkSidePool {
-    std::mutex mu;
-    hipStream_t s[imk_unet_plan::MAX_SIDE] = {};
-};
-inline hipStream_t imk_side_pool_stream(int i) {
-    static ImkSidePool pools[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ImkSidePool &pool = pools[dev & 63];
-    std::lock_guard<std::mutex> lock(pool.mu);
-    if (!pool.s[i] && hipStreamCreateWithFlags(&pool.s[i], hipStreamNonBlocking) != hipSuccess) pool.s[i] = nullptr;
-    return pool.s[i];
-}
-
+// The pool itself lives in ONE translation unit (imk_unet.hip: imk_side_pool_stream, declared in imk_kernels.h): this header is
+// included by imk_unet.hip and imk_evalnet.hip, and a pool per translation unit gave an IM++ process two sets of streams.
 // the plan's events (once) and its first n side streams
 inline bool ensure_side_streams(const imk_unet_plan *plan, int n = 1) {
     std::call_once(plan->side_once, [plan]() {

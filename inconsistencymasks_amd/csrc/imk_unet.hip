@@ -2,6 +2,8 @@
 // imk_elem.hip: topology, workspace layout, batched inference, ensemble inference + IM, and the training step
 // (forward with batch statistics, loss, backward, AdamW).  The layer-level helpers are shared with EvalNet (imk_net.h).
 // Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
+#include <atomic>
+#include <cstdio>
 #include "imk_net.h"
 #include "imk_head.h"
 
@@ -165,6 +167,42 @@ bool cfg_ok(const imk_unet_cfg *c) {
 }  // namespace
 
 // =====================================================================================================
+// The process-wide side-stream pool (see imk_net.h: why one pool and not one pair of streams per plan).
+static std::atomic<int> g_runtime_warnings{0};
+hipStream_t imk_side_pool_stream(int i) {
+    struct Pool { std::mutex mu; hipStream_t s[imk_unet_plan::MAX_SIDE] = {}; };
+    static Pool pools[64];
+    if (i < 0 || i >= imk_unet_plan::MAX_SIDE) return nullptr;
+    // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read when it starts.  With fewer than 8, a
+    // side stream can land on the queue of the stream it is meant to run beside and the "concurrent" weight gradients queue up
+    // behind barrier packets (-14 % on the ISIC generation with an RCCL stream in the process).  The Python package
+    // exports 8 before the runtime starts; a bare C-ABI caller is told here, once.
+    static std::once_flag hwq_once;
+    std::call_once(hwq_once, []() {
+        const char *e = getenv("GPU_MAX_HW_QUEUES");
+        if (!e || atoi(e) < 8) {
+            g_runtime_warnings.fetch_or(IMK_WARN_HW_QUEUES);
+            fprintf(stderr, "libimk: GPU_MAX_HW_QUEUES=%s (< 8): side streams may serialise behind the caller's stream; "
+                            "export GPU_MAX_HW_QUEUES=8 before the HIP runtime starts\n", e ? e : "unset");
+        }
+    });
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Pool &pool = pools[dev & 63];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (!pool.s[i] && hipStreamCreateWithFlags(&pool.s[i], hipStreamNonBlocking) != hipSuccess) pool.s[i] = nullptr;
+    return pool.s[i];
+}
+
+extern "C" int imk_runtime_warnings(void) { return g_runtime_warnings.load(); }
+
+extern "C" int imk_unet_plan_side_stream(const imk_unet_plan *plan, int i, void **stream_out) {
+    IMK_CHECK_ARG(plan && stream_out && i >= 0 && i < imk_unet_plan::MAX_SIDE);
+    if (!ensure_side_streams(plan, i + 1)) return IMK_EINVAL;
+    *stream_out = (void *)plan->side[i];
+    return IMK_OK;
+}
+
 extern "C" int imk_unet_plan_create(const imk_unet_cfg *cfg, imk_unet_plan **out) {
     IMK_CHECK_ARG(out);
     if (!cfg_ok(cfg)) return IMK_EINVAL;
@@ -210,6 +248,12 @@ extern "C" int imk_unet_layer_info(const imk_unet_plan *plan, int idx, imk_layer
 extern "C" int imk_unet_plan_set_bn_momentum(imk_unet_plan *plan, float momentum) {
     IMK_CHECK_ARG(plan && momentum >= 0.f && momentum < 1.f);
     plan->bn_momentum = momentum;
+    return IMK_OK;
+}
+
+extern "C" int imk_unet_plan_get_bn_momentum(const imk_unet_plan *plan, float *momentum) {
+    IMK_CHECK_ARG(plan && momentum);
+    *momentum = plan->bn_momentum;
     return IMK_OK;
 }
 

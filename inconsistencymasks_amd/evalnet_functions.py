@@ -347,7 +347,7 @@ def load_evalnet(path, device="cuda"):
         meta = f.metadata()
         sd = {k: f.get_tensor(k) for k in f.keys()}
     m = EvalNet(int(meta["h"]), int(meta["w"]), int(meta["ca"]), int(meta["cb"]), int(meta["n_out"]), float(meta["alpha"]),
-                bool(int(meta["two_heads"])), bool(int(meta["normalize_a"])), bool(int(meta["normalize_b"])), device=device,
+                bool(int(meta["two_heads"])), bool(int(meta["normalize_a"])), bool(int(meta["normalize_b"])), seed=0, device=device,
                 b_onehot=bool(int(meta.get("b_onehot", "0"))))
     m.load_state_dict(sd)
     return m

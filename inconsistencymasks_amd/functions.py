@@ -545,7 +545,20 @@ def gather_pairs(idx, img=None, mask_planar=None, div255=False, mul=None):
     (parse_image_ISIC_2018 / parse_image_hela, functions.py:975, 1001-1011).  Returns (img_out, mask_out); absent ones are None."""
     idx = idx.to(torch.int64).contiguous()
     n = int(idx.shape[0])
+    # the kernel copies bytes: rows of uint8, densely laid out (a float or strided set would be gathered silently wrong)
+    for name, t in (("img", img), ("mask_planar", mask_planar), ("mul", mul)):
+        if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous()):
+            raise ValueError(f"gather_pairs: {name} must be a contiguous uint8 tensor, got {t.dtype}, contiguous={t.is_contiguous()}")
+    if mask_planar is not None and mask_planar.dim() != 4:
+        raise ValueError("gather_pairs: mask_planar must be [N, P, H, W]")
     out_i = out_m = None
+    if n == 0:      # correctly shaped empty results
+        if img is not None:
+            out_i = torch.empty((0,) + tuple(img.shape[1:]), dtype=torch.uint8, device=img.device)
+        if mask_planar is not None:
+            N, P, H, W = mask_planar.shape
+            out_m = torch.empty((0, H, W, P), dtype=torch.uint8, device=mask_planar.device)
+        return out_i, out_m
     for lo in range(0, n, 65535):          # the row index rides on gridDim.y
         hi = min(n, lo + 65535)
         if img is not None:
@@ -641,15 +654,28 @@ def _grad_allreduce(model):
     return 1.0 / d.get_world_size()
 
 
-def _dp_bn_momentum(model):
-    """Data-parallel runs keep the reference's per-GPU batch of 32, so an epoch has N times fewer optimizer steps -- and Keras'
+def dp_bn_momentum_rule(world=None):
+    """(rule name, momentum) of the BatchNorm moving statistics for a run of `world` ranks.
+
+    Data-parallel runs keep the reference's per-GPU batch of 32, so an epoch has N times fewer optimizer steps -- and Keras'
     BatchNorm moving statistics (momentum 0.99 PER STEP) need ~500 steps to forget their initial values: at 8 ranks that is the
     whole 50-epoch schedule, and the validation metric that picks the checkpoint lags (profiles/r03_dp_convergence.txt: val IoU
-    0.989 instead of 0.9998 after 50 epochs, ~0 until epoch 20).  IMK_DP_BN_MOMENTUM=scaled uses 0.99^N, i.e. the same memory
-    in SAMPLES as the single-GPU recipe.  Off by default: it departs from the reference's recipe (unet.py:7 leaves the default)."""
-    _, world = _rank_world()
-    if world > 1 and os.environ.get("IMK_DP_BN_MOMENTUM", "").lower() == "scaled":
-        model.set_bn_momentum(0.99 ** world)
+    0.989 instead of 0.9998 after 50 epochs, ~0 until epoch 20).  With more than one rank the default is therefore "scaled":
+    momentum 0.99^N, the same memory in SAMPLES as the single-GPU recipe (0.9994 at 8 ranks).  IMK_DP_BN_MOMENTUM=reference
+    keeps Keras' 0.99 per step at any world size (unet.py:7 leaves the layer's default); "scaled" can be forced the same way.
+    One rank is always the reference's recipe."""
+    if world is None:
+        _, world = _rank_world()
+    mode = os.environ.get("IMK_DP_BN_MOMENTUM", "").lower()
+    if mode not in ("", "scaled", "reference"):
+        raise ValueError(f"IMK_DP_BN_MOMENTUM={mode!r}: expected 'scaled' or 'reference'")
+    if world > 1 and mode != "reference":
+        return "scaled", 0.99 ** world
+    return "reference", 0.99
+
+
+def _dp_bn_momentum(model):
+    model.set_bn_momentum(dp_bn_momentum_rule()[1])
 
 
 def fit(model, loader, steps_per_epoch, epochs, loss_kind, on_epoch_end=None, lr=None, wd=None):
@@ -688,8 +714,10 @@ def load_model(path, custom_objects=None, device="cuda"):
     with safe_open(path, framework="pt") as f:
         meta = f.metadata()
         sd = {k: f.get_tensor(k) for k in f.keys()}
+    # a fixed seed: the initialisation is overwritten below, and an unseeded UNet() under data parallelism broadcasts its seed
+    # (a collective) -- a checkpoint load must not block on the other ranks
     m = UNet(int(meta["h"]), int(meta["w"]), int(meta["c_in"]), int(meta["n_out"]), float(meta["alpha"]),
-             meta["act_out"], device=device)
+             meta["act_out"], seed=0, device=device)
     m.load_state_dict(sd)
     return m
 

@@ -219,6 +219,10 @@ def run(dataset, approach="IM"):
                         os.rename(os.path.join(model_dir, f"{row[0]}.h5"), os.path.join(model_dir, f"{row[0][:-2]}_topK_{i}.h5"))
                     os.makedirs(csv_dir, exist_ok=True)
                     with open(os.path.join(csv_dir, f"results_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
+                        if world > 1:       # one rank writes exactly the reference's file; a data-parallel run says what differed
+                            rule, mom = F.dp_bn_momentum_rule(world)
+                            f.write(f"# data parallel: {world} ranks x batch {batch} per rank, BatchNorm momentum rule '{rule}' = {mom:.6f} "
+                                    "(IMK_DP_BN_MOMENTUM; functions.dp_bn_momentum_rule)\n")
                         wr = csv.writer(f, delimiter=";")
                         wr.writerow(ds["header"])
                         wr.writerows(rows)

@@ -134,6 +134,12 @@ class UNet:
         """momentum of the BatchNorm moving statistics in training steps (Keras default 0.99)"""
         check(lib.imk_unet_plan_set_bn_momentum(self.plan.ptr, float(momentum)), "imk_unet_plan_set_bn_momentum")
 
+    def get_bn_momentum(self):
+        """the momentum the plan's training steps use (read back from the library)"""
+        m = ctypes.c_float()
+        check(lib.imk_unet_plan_get_bn_momentum(self.plan.ptr, ctypes.byref(m)), "imk_unet_plan_get_bn_momentum")
+        return float(m.value)
+
     # ---- parameters -------------------------------------------------------------------------------
     def ready_for_inference(self):
         """training steps re-pack the conv weights but leave the folded BN statistics stale: refresh if needed"""
@@ -274,7 +280,11 @@ class UNet:
 def get_unet(i_height, i_width, i_channels, num_outputmasks, alpha, actifu, actifuout, ks=3, kernel_ini="he_normal",
              dropout_rate_encoder=0, dropout_rate_decoder=0, dropout_rate_bottleneck=0, seed=None, device="cuda"):
     """Same positional signature as the reference's unet.get_unet (unet.py:46).  Only what every shipped
-    config uses is supported by the kernels: relu hidden activation, 3x3 kernels, he_normal, no dropout."""
+    config uses is supported by the kernels: relu hidden activation, 3x3 kernels, he_normal, no dropout.
+
+    Data parallel: with `seed=None` and an initialised torch.distributed process group of more than one rank this call is a
+    COLLECTIVE (rank 0 draws the seed and broadcasts it, so the replicas start equal): every rank must make it, in the same
+    order.  Pass a seed to build a model on one rank only; checkpoint loads (functions.load_model) never communicate."""
     if actifu != "relu":
         raise NotImplementedError("hidden activation other than relu is not used by any reference config")
     if ks != 3 or kernel_ini != "he_normal":

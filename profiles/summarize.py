@@ -5,13 +5,21 @@ per-dispatch CSVs are tens of MB and are deleted afterwards).
   pmc_traffic.csv       : per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch as reported (KB -> MB), and the
                           gfx950-corrected HBM bytes per launch (FETCH x 2 for wide coalesced reads + WRITE;
                           MI355X_MICROARCH.md, section HBM)
+  timed_region_kernel_stats.csv (round 4): the dispatches BETWEEN bench.py's two marker kernels (imk_mark_kernel with 64 and
+                          128 work-items: the timed region), per kernel variant: calls, average us from rocprofv3's own begin /
+                          end timestamps, and -- joined from the bench line of the traced run (bench_traced.json:
+                          timed_region_kernel_totals, the library's own sums over every launch) -- algorithmic MB and GFLOP per
+                          launch, hence GB/s, TFLOP/s and the fraction of the 8 TB/s / 2.5 PFLOP/s peak without any HIP-event bracket
 """
 import collections
 import csv
 import glob
+import json
 import os
 import re
 import sys
+
+HBM_PEAK_GBS, MFMA_PEAK_TFLOPS = 8000.0, 2500.0
 
 
 def short(n):
@@ -19,7 +27,7 @@ def short(n):
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-zA-Z_0-9]+?)(I|E)", n)
     if m:
         return m.group(1)
-    return n.split("(")[0][:48]
+    return n.split("(")[0][:90]
 
 
 def main(out):
@@ -36,6 +44,7 @@ def main(out):
             w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 w.writerow([k, v[0], round(v[1] / 1e6, 3), round(v[1] / v[0] / 1e3, 3), round(100 * v[1] / tot, 2)])
+    timed_region(out)
     tr = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(out, f"pmc_{cname}", "*", "*_counter_collection.csv"))
@@ -70,6 +79,52 @@ def main(out):
     for big in glob.glob(os.path.join(out, "*", "*", "*_kernel_trace.csv")) + \
             glob.glob(os.path.join(out, "*", "*", "*_counter_collection.csv")):
         os.remove(big)
+
+
+def timed_region(out):
+    traces = glob.glob(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
+    if not traces:
+        return
+    rows = []
+    for f in traces:     # one file per process; the bench is the one with the markers
+        rr = list(csv.DictReader(open(f)))
+        if any("imk_mark_kernel" in r["Kernel_Name"] for r in rr):
+            rows = rr
+            break
+    marks = {int(r["Grid_Size_X"]) // 64: r for r in rows if "imk_mark_kernel" in r["Kernel_Name"]}
+    if 1 not in marks or 2 not in marks:
+        return
+    t0, t1 = int(marks[1]["End_Timestamp"]), int(marks[2]["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1:
+            k = short(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    totals = {}
+    try:
+        line = [l for l in open(os.path.join(out, "bench_traced.json")).read().splitlines() if l.startswith("{")][-1]
+        totals = json.loads(line).get("timed_region_kernel_totals", {})
+    except Exception:
+        pass
+    # the library sums some families under one name (wgf_stage1 + wgf_stage2, the step tail, the conv_mfma variants by tile): those
+    # rows carry no bytes here; conv_pipe / conv_wide (the dominant family) match by their full template names
+    tot_ns = sum(v[1] for v in agg.values())
+    with open(os.path.join(out, "timed_region_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent_of_kernel_time", "algorithmic_MB_per_launch", "GFLOP_per_launch",
+                    "GBps", "frac_of_8TBps", "TFLOPs", "frac_of_2.5PFLOPs", "region_ms"])
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            avg_us = v[1] / v[0] / 1e3
+            t = totals.get(k)      # exact kernel name only: a family-wide average would misprice its variants
+            if t and t.get("launches"):
+                mb, gf = t["MB_per_launch"], t["GFLOP_per_launch"]
+                gbps, tf = mb / avg_us * 1e3, gf / avg_us * 1e3
+                extra = [mb, gf, round(gbps, 1), round(gbps / HBM_PEAK_GBS, 4), round(tf, 1), round(tf / MFMA_PEAK_TFLOPS, 4)]
+            else:
+                extra = ["", "", "", "", "", ""]
+            w.writerow([k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), round(100 * v[1] / max(tot_ns, 1), 2)] + extra +
+                       [round((t1 - t0) / 1e6, 3)])
 
 
 if __name__ == "__main__":

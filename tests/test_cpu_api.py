@@ -485,3 +485,20 @@ def test_package_import_raises_the_hardware_queue_limit():
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
+
+
+def test_dp_bn_momentum_rule(monkeypatch):
+    """One rank: Keras' 0.99 per step.  More ranks: 0.99^N by default (the moving statistics keep their memory in samples;
+    profiles/r03_dp_convergence.txt), 0.99 again under IMK_DP_BN_MOMENTUM=reference."""
+    from inconsistencymasks_amd import functions as F
+    monkeypatch.delenv("IMK_DP_BN_MOMENTUM", raising=False)
+    assert F.dp_bn_momentum_rule(1) == ("reference", 0.99)
+    name, m = F.dp_bn_momentum_rule(8)
+    assert name == "scaled" and abs(m - 0.99 ** 8) < 1e-12
+    monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "reference")
+    assert F.dp_bn_momentum_rule(8) == ("reference", 0.99)
+    monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "scaled")
+    assert F.dp_bn_momentum_rule(1) == ("reference", 0.99) and F.dp_bn_momentum_rule(2)[0] == "scaled"
+    monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "bogus")
+    with pytest.raises(ValueError):
+        F.dp_bn_momentum_rule(2)

@@ -9,6 +9,8 @@ hot-path script sets (`mixed_float16`, ISIC_2018/09_ISIC_2018_IM.py:16), gives i
 biases, and records
   * the weights in `model.get_weights()` order,
   * a seeded uint8 batch and `model.predict` on it (functions.py:3157),
+  * the output of every Conv2D layer on that batch (`act_<our layer name>`: the post-ReLU, pre-BatchNorm tensors this
+    repository stores, mapped by creation order like the weights) -- a first mismatch can then be localised layer by layer,
   * the weights after `--steps` steps of `model.fit` with `tfa.optimizers.AdamW(learning_rate=LR, weight_decay=WD)` and the
     script's loss ('mse' / CategoricalCrossentropy()), batch by batch in file order (functions.py:207-218), and the
     per-step losses,
@@ -76,6 +78,15 @@ def main(argv=None):
             y = rng.integers(0, cs["k"], (b * steps, cs["h"], cs["w"])).astype(np.uint8)
             target, loss = np.eye(cs["k"], dtype=np.float32)[y], tf.keras.losses.CategoricalCrossentropy()
         probs = model.predict(x[:b], batch_size=b, verbose=0).astype(np.float32)
+        # every conv's output (what libimk stores: post-ReLU, pre-BatchNorm), keyed by OUR layer names through the creation-order map
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import keras_h5_to_safetensors as K
+        table = K.layer_table(cs["c"], cs["k"], cs["alpha"])
+        name_map = K.match_keras_layers([l.name for l in model.layers if l.weights], table)
+        convs = [(ours, model.get_layer(kn)) for ours, kn in name_map.items() if ours != "out" and not ours.endswith(("bn", "bna", "bnb"))]
+        probe = tf.keras.Model(model.input, [l.output for _, l in convs])
+        acts = probe.predict(x[:b], batch_size=b, verbose=0)
+        act_out = {f"act_{ours}": np.asarray(a, np.float32) for (ours, _), a in zip(convs, acts)}
         model.compile(optimizer=tfa.optimizers.AdamW(learning_rate=LR, weight_decay=WD), loss=loss)
         losses = []
         for s in range(steps):       # one optimizer step per call, batches in order (fit(shuffle=False) over one batch each)
@@ -86,6 +97,7 @@ def main(argv=None):
                 "tensorflow_addons": tfa.__version__, "policy": "mixed_float16", "numpy": np.__version__}
         out = {f"w0_{i:03d}": v for i, v in enumerate(w0)}
         out.update({f"w1_{i:03d}": v for i, v in enumerate(w1)})
+        out.update(act_out)
         out.update(x=x, y=y, probs=probs, losses=np.asarray(losses, np.float64), meta=np.asarray(json.dumps(meta)))
         path = os.path.join(a.out, f"keras_{name}.npz")
         np.savez_compressed(path, **out)
