@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include "imk_stage.h"
 
+IMK_STAMP_TABLE(bwd1)
+
 namespace {
 
 struct Bwd1Args {
@@ -42,6 +44,7 @@ struct Bwd1Args {
 // tile's 4 k-steps), combined in a fixed order at the end), a quarter of the fragment / accumulator registers.
 template <int LM, bool SMALL>
 __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) {
+    IMK_STAMP_BEGIN(bwd1, 70000 + LM * 10 + (SMALL ? 1 : 0));
     constexpr int NPX = 128, H16 = WG_STRIDE_H;
     constexpr int NF = SMALL ? 2 : 4, NSK = SMALL ? 1 : 2;   // input-channel tiles (= output tiles) and dgrad k-steps at most
     constexpr bool MASK = LM == LM_RAW;
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) 
             }
         }
     }
+    IMK_STAMP_END(1);
 }
 
 bool bwd1_env_on() {

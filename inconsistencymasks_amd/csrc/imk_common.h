@@ -92,10 +92,32 @@ struct ImkProfScope {
             stamp_row_[3] = __builtin_amdgcn_s_memtime();                                                             \
         }                                                                                                             \
     }
+// Per-WORKGROUP entry / exit times (100 MHz counter) of the launches whose kernel id equals the selection (host: imk_debug_wgsel_<tu>):
+// how evenly a persistent launch's workgroups finish.  Later launches of the same id overwrite earlier ones.
+#define IMK_WGSTAMP_ROWS 4096
+#define IMK_WGSTAMP_TABLE(tu)                                                                                        \
+    __device__ unsigned long long g_wgstamps_##tu[IMK_WGSTAMP_ROWS * 2];                                              \
+    __device__ unsigned g_wgsel_##tu;                                                                                 \
+    extern "C" __attribute__((visibility("default"))) int imk_debug_wgsel_##tu(unsigned kid) {                        \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                          \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_wgsel_##tu), &kid, sizeof kid) == hipSuccess ? 0 : -1;                  \
+    }                                                                                                                 \
+    extern "C" __attribute__((visibility("default"))) int imk_debug_wgstamps_##tu(unsigned long long *out) {          \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                          \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgstamps_##tu), sizeof(unsigned long long) * IMK_WGSTAMP_ROWS * 2) == hipSuccess ? 0 : -1; \
+    }
+#define IMK_WGSTAMP_BEGIN(tu, kid)                                                                                    \
+    const bool wgstamp_on_ = (g_wgsel_##tu == (unsigned)(kid)) && blockIdx.x < IMK_WGSTAMP_ROWS && blockIdx.y == 0;   \
+    unsigned long long *const wgstamp_p_ = g_wgstamps_##tu + 2 * blockIdx.x;                                          \
+    if (wgstamp_on_ && threadIdx.x == 0) wgstamp_p_[0] = __builtin_amdgcn_s_memrealtime();
+#define IMK_WGSTAMP_END() do { if (wgstamp_on_ && threadIdx.x == 0) wgstamp_p_[1] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define IMK_STAMP(i) do { if (stamp_row_) stamp_row_[3 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 // last stamp of a kernel: the shader clock and (col 15) the 100 MHz counter again, which calibrates the former per launch
 #define IMK_STAMP_END(i) do { if (stamp_row_) { stamp_row_[3 + (i)] = __builtin_amdgcn_s_memtime(); stamp_row_[15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
+#define IMK_WGSTAMP_TABLE(tu)
+#define IMK_WGSTAMP_BEGIN(tu, kid)
+#define IMK_WGSTAMP_END() do { } while (0)
 #define IMK_STAMP_TABLE(tu)
 #define IMK_STAMP_BEGIN(tu, kid)
 #define IMK_STAMP(i) do { } while (0)

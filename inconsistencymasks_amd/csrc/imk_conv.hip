@@ -25,6 +25,7 @@
 #include "imk_stage.h"
 
 IMK_STAMP_TABLE(conv)
+IMK_WGSTAMP_TABLE(conv)
 
 namespace {
 
@@ -441,9 +442,12 @@ constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
 // bias, ReLU, round to fp16, apply the BatchNorm, zero what lies outside the image and write the 3x3's input tile.  The
 // intermediate tensor is neither written nor read, and every value is bit-identical to the two-launch path (same MFMA, same
 // operand layout per pixel).
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0>
+// DYN: the workgroups take their tiles from per-group counters (a.sched; ImkWalk, dynamic form) -- launches without per-workgroup
+// partial rows only (EP_RELU without statistics, no fused weight gradient: inference)
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0, bool DYN = false>
 __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, ImkWalk wk) {
+    static_assert(!DYN || (EPI == EP_RELU && !DYSTAT && WG == 0), "dynamic walk: results must not depend on the tile -> workgroup map");
     static_assert(PRE == 0 || (WG == 0 && EPI == EP_RELU && !DYSTAT && (LM == LM_U8 || LM == LM_UPADD)), "pre-stage: inference forward only");
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     float *s_red = s_aff + 8 * 16;              // [4 waves][2][16] (the affine table has up to 7 rows of 16: LM_STEM)
     const int t = threadIdx.x;
     IMK_STAMP_BEGIN(conv, 40000 + LM * 1000 + WG * 100 + CHAIN * 10 + (DYSTAT ? 1 : 0));
+    IMK_WGSTAMP_BEGIN(conv, 40000 + LM * 1000 + WG * 100 + CHAIN * 10 + (DYSTAT ? 1 : 0));
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int set = PAIR ? (g >> 1) : 0;        // PAIR: which of the block's two tile rows this lane feeds and owns
     const int H = a.H, W = a.W;
@@ -631,12 +636,24 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 
     // this workgroup's tiles: tile, tile + wk.step, ... inside its group's range (ImkWalk, imk_stage.h); a workgroup without a
     // tile (possible when the ranges are uneven) prefetches the launch's last tile and writes zero statistics rows
-    const int wgrp = blockIdx.x & ((1 << wk.shift) - 1);
+    const int wgrp = imk_walk_range(wk, blockIdx.x);
     int tile = wgrp * wk.chunk + (int)(blockIdx.x >> wk.shift);
     const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
     const int tile0 = min(tile, n_tiles - 1);
     PTile tc = ptile_at(tile0 / per_img, tile0 % per_img, tiles_x, magic_tx);
     issue(tc);
+    // DYN: tickets of this group's counter number the tiles behind the statically assigned first ones; s_tk[2] hands the ticket
+    // wave 0 received to the whole workgroup (written before a barrier, read after it; two slots: one per tile parity)
+    __shared__ int s_tk[2];
+    const bool tk_lane = DYN && t == 0;
+    unsigned *const tk_head = DYN ? a.sched + wgrp * (IMK_SCHED_STRIDE / 4) : nullptr;
+    const int tk_base = wgrp * wk.chunk + wk.step;
+    int it_par = 0, tk_pending = 0;       // tk_pending: the ticket requested one tile ago, handed over one tile later -- a returning
+    if constexpr (DYN) {                  // atomic takes 1-3 us under load, about a tile's time: two tiles of look-ahead hide it
+        const int tk = imk_take_ticket(tk_head, tk_lane);
+        tk_pending = imk_take_ticket(tk_head, tk_lane);
+        if (tk_lane) s_tk[0] = tk;
+    }
     stage_affine_table(a.x, s_aff);       // behind the first tile's loads: one exposed memory latency for both, not two
     if constexpr (WG == 3) {              // BatchNorm of the conv's input (LM_RAW leaves the table free)
         if (t < a.cs_out) { s_aff[t] = a.wg_sc[t]; s_aff[16 + t] = a.wg_sh[t]; }
@@ -714,9 +731,18 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 else zq[p] = *reinterpret_cast<const f16x4 *>(b_zq + o1l[p]);
             }
         }
-        const int next = tile + wk.step;
-        const PTile tn = next < tile_end ? ptile_next(tc, wk.q, wk.r, per_img, tiles_x, magic_tx) : tc;
+        int next;
+        PTile tn;
+        int tk_new = 0;
+        if constexpr (DYN) {
+            next = tk_base + __builtin_amdgcn_readfirstlane(s_tk[it_par]);
+            tn = next < tile_end ? ptile_of_index(next, per_img, tiles_x, magic_tx, wk.magic_pi) : tc;
+        } else {
+            next = tile + wk.step;
+            tn = next < tile_end ? ptile_next(tc, wk.q, wk.r, per_img, tiles_x, magic_tx) : tc;
+        }
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
+        if constexpr (DYN) tk_new = imk_take_ticket(tk_head, tk_lane);     // the tile after next: its latency runs under this tile
         if constexpr (PRE) {
             // rows / columns of the halo tile that lie inside the image (the 3x3 pads its INPUT with zeros, not the 1x1's)
             const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
@@ -856,6 +882,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 }
             }
         }
+        if constexpr (DYN) { it_par ^= 1; if (tk_lane) s_tk[it_par] = tk_pending; tk_pending = tk_new; }
         __syncthreads();   // tile reads done: the LDS tile may be overwritten
         tile = next;
         tc = tn;
@@ -914,6 +941,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             }
         }
     }
+    IMK_WGSTAMP_END();
     IMK_STAMP_END(1);
 }
 
@@ -1046,7 +1074,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
 
     // this workgroup's tiles: tile, tile + wk.step, ... inside its group's range (ImkWalk, imk_stage.h); a workgroup without a
     // tile (possible when the ranges are uneven) prefetches the launch's last tile and writes zero statistics rows
-    const int wgrp = blockIdx.x & ((1 << wk.shift) - 1);
+    const int wgrp = imk_walk_range(wk, blockIdx.x);
     int tile = wgrp * wk.chunk + (int)(blockIdx.x >> wk.shift);
     const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
     const int tile0 = min(tile, n_tiles - 1);
@@ -1325,7 +1353,7 @@ __device__ __forceinline__ void wgrad_mfma_body(const ImkWgradArgs &a, const Imk
     // this split's tiles: an XCD-aware walk over the split index (ImkWalk, imk_stage.h; nbx is a multiple of 8 there, so
     // bx & 7 is the block's XCD group whatever by is)
     const ImkWalk wk = gm.wk;
-    const int wgrp = bx & ((1 << wk.shift) - 1);
+    const int wgrp = imk_walk_range(wk, (unsigned)bx);
     int tile = wgrp * wk.chunk + (bx >> wk.shift);
     const int tile_end = min(n_tiles, (wgrp + 1) * wk.chunk);
     issue(tile < n_tiles ? tile : n_tiles - 1);
@@ -1426,6 +1454,7 @@ __device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx,
 }
 
 __global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
+    IMK_STAMP_BEGIN(conv, 21);
     const int jn = wgf_find_job(jobs, blockIdx.x, true);
     const ImkWgFinalJob &jb = jobs.j[jn];
     const int local = blockIdx.x - jb.work1_begin;
@@ -1443,6 +1472,7 @@ __global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
         for (int i = 0; i < WG_RED_CHUNK; ++i) acc += (sb + i < s1) ? v[i] : 0.f;
     }
     jb.red[((size_t)chunk * jb.n_tiles + tile) * 256 + t] = acc;
+    IMK_STAMP_END(1);
 }
 
 __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, const float *__restrict__ inv_scale_ptr,
@@ -1482,6 +1512,7 @@ __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, c
 
 // all conv layers of a model in one launch: blockIdx.y = job
 __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs) {
+    IMK_STAMP_BEGIN(conv, 23);
     if (jobs.ctl && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) imk_ctl_end_step(jobs.ctl, jobs.stats);
     const ImkPackJob &jb = jobs.j[blockIdx.y];
     if (jb.transposed == 2) {   // chain operand of a 1x1 conv: one k-step, lane (m, g), j < 4 <-> W[ci = 4g + j][co = m]
@@ -1539,6 +1570,7 @@ __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs
         }
         jb.dst[i] = (f16)v;
     }
+    IMK_STAMP_END(1);
 }
 
 }  // namespace
@@ -1829,11 +1861,20 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
 static bool pipe_fits(const ImkConvArgs &a) { return (long long)a.H * a.W < imk_conv_max_pixels() && a.W < (1 << 16); }
 
 
-template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0>
+static bool dyn_walk_on() {
+    static const bool on = []() { const char *e = getenv("IMK_DYN_WALK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0, bool DYN = false>
 static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
+    if constexpr (!DYN && EPI == EP_RELU && !DYSTAT && WG == 0) {      // inference launches with tile counters: the dynamic walk
+        if (a.sched && !a.stats_partial && dyn_walk_on() && a.B * imk_cdiv(a.H, 16) * imk_cdiv(a.W, TW) >= 2048)
+            return launch_conv_pipe_k<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, true>(a, stream);
+    }
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = pipe_lds_base(NC8, PAIR, WG) + (PRE ? (size_t)18 * 18 * (PRE | 1) * 16 + 3 * 16 * sizeof(float) : 0);
-    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE>;
+    auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, DYN>;
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 4;
@@ -1844,11 +1885,12 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     const int n_tiles = a.B * tiles_x * tiles_y;
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
+    const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y, DYN);
+    if (DYN && wk.shift != 5) return IMK_EINVAL;      // (>= 2048 tiles: always the 32-group walk)
     static const std::string vname = []() {     // as rocprofv3 prints the instantiation
         char b[128];
-        snprintf(b, sizeof b, "conv_pipe_kernel<%d, %d, %d, %s, %d, %s, %s, %d, %d>", LM, NC8, CHAIN, PAIR ? "true" : "false", EPI,
-                 DYSTAT ? "true" : "false", FULL ? "true" : "false", WG, PRE);
+        snprintf(b, sizeof b, "conv_pipe_kernel<%d, %d, %d, %s, %d, %s, %s, %d, %d, %s>", LM, NC8, CHAIN, PAIR ? "true" : "false", EPI,
+                 DYSTAT ? "true" : "false", FULL ? "true" : "false", WG, PRE, DYN ? "true" : "false");
         return std::string(b);
     }();
     ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());

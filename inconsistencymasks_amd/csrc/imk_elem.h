@@ -36,6 +36,11 @@ int imk_head_cce_fused_rows(long long n_pix);
 int imk_launch_head_cce_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
                               int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
                               float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream);
+// the same for sigmoid heads (mse) with 1 or 3 maps and <= 16 input channels (imk_headf.hip: head_mse_fused_kernel)
+bool imk_head_mse_fused_ok(int cs, int K, long long n_pix, int rows_cap);
+int imk_launch_head_mse_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                              int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
+                              float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream);
 int imk_launch_loss_finalize(const float *loss_partial, long long n_pix, int K, int kind, float *stats, hipStream_t stream);
 int imk_launch_ctl_init(ImkCtl *ctl, hipStream_t stream);
 int imk_launch_adamw(float *p, float *m, float *v, const float *g, long long n, ImkCtl *ctl, const float *stats,

@@ -22,6 +22,8 @@
 // Fixed reduction orders everywhere (per-wave accumulators -> per-workgroup partial rows): bit-reproducible.
 #include "imk_stage.h"
 
+IMK_STAMP_TABLE(headf)
+
 namespace {
 
 struct HeadCceArgs {
@@ -42,6 +44,7 @@ struct HeadCceArgs {
 
 template <int CS, int KT>
 __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
+    IMK_STAMP_BEGIN(headf, 90001);
     constexpr int NCT = CS / 16;                 // 16-channel tiles
     constexpr int NS = (KT + 1) / 2;             // 32-class k-steps of the dgrad
     constexpr int KT2 = 2 * NS;                  // class tiles incl. the zero tile that completes the last k-step
@@ -289,9 +292,145 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
         }
         wp[i] = v;
     }
+    IMK_STAMP_END(1);
+}
+
+// =====================================================================================================
+// SIGMOID heads (ISIC: 1 map, HeLa: 3; functions.py:303 'mse'), round 4: the same one-pass scheme.  head_loss_kernel wrote the
+// logit gradient as an 8-channel-padded fp16 tensor (16 bytes per pixel for 1-3 numbers) and the head's dgrad launch
+// (conv_pipe_kernel<LM_RAW, ..., WG = 2>) read it back together with the last activation: 5 full-resolution tensor passes
+// and two launches (19.6 + 19.7 us at ISIC) for what is, with K <= 4 outputs, an outer product per pixel.  Here one thread
+// owns a pixel: BatchNorm on load, the fp32 output layer + sigmoid, mse and d(loss * scale)/d(logit) rounded to fp16 (the
+// value the dgrad consumed before), dy = W . dlogit (fp16 weights like the packed dgrad operand, fp32 sums, fp16 result),
+// its BatchNorm-backward statistics, and the output layer's weight / bias gradient -- z read once, dy written once.
+// Per-thread fp32 accumulators, reduced per workgroup in a fixed order into the partial-row layouts the other producers use
+// (bn_bwd_coef_kernel, wgf_stage1_kernel): bit-reproducible.
+template <int CS, int K>
+__global__ __launch_bounds__(256) void head_mse_fused_kernel(HeadCceArgs a) {
+    IMK_STAMP_BEGIN(headf, 90000);
+    constexpr int NA = 2 * CS + CS * K + K + 1;      // sum dy | sum dy z | dW[c][k] | db[k] | loss
+    __shared__ float s_w[K * CS], s_wd[K * CS], s_b[K], s_sc[CS], s_sh[CS];
+    __shared__ float s_red[4][NA];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < K * CS; i += 256) {
+        const int k = i / CS, c = i - k * CS;
+        const float w = (c < a.cin) ? a.w[(size_t)c * K + k] : 0.f;
+        s_w[i] = w;                                  // forward: the fp32 output layer (unet.py:63)
+        s_wd[i] = (float)(f16)w;                     // dgrad: the fp16 operand the packed weights hold
+    }
+    if (t < K) s_b[t] = a.bias[t];
+    if (t < CS) { s_sc[t] = a.sc[t]; s_sh[t] = a.sh[t]; }
+    const float S = a.ctl->loss_scale;
+    if (blockIdx.x == 0 && t == 0) { a.stats[1] = 0.f; a.stats[2] = S; a.stats[3] = (float)a.ctl->step; }   // as head_loss_kernel
+    __syncthreads();
+    const float inv_n = 1.0f / ((float)a.n_pix * (float)K);
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    auto pixel = [&](const f16x8 (&zv)[CS / 8], const uint8_t (&yv)[K], long long p) {
+        float zf[CS], xin[CS];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            zf[c] = (float)zv[c >> 3][c & 7];
+            xin[c] = (float)(f16)(zf[c] * s_sc[c] + s_sh[c]);
+        }
+        float gk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float lg = s_b[k];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) lg += xin[c] * s_w[k * CS + c];
+            const float pk = 1.0f / (1.0f + expf(-lg)), e = pk - (float)yv[k];
+            acc[2 * CS + CS * K + K] += e * e;
+            gk[k] = (float)(f16)(S * 2.0f * e * inv_n * pk * (1.0f - pk));
+            acc[2 * CS + CS * K + k] += gk[k];
+        }
+        f16x8 dv[CS / 8];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                d += gk[k] * s_wd[k * CS + c];
+                acc[2 * CS + c * K + k] += xin[c] * gk[k];
+            }
+            const f16 d16 = (f16)d;
+            dv[c >> 3][c & 7] = d16;
+            acc[c] += (float)d16;
+            acc[CS + c] += (float)d16 * zf[c];
+        }
+#pragma unroll
+        for (int q = 0; q < CS / 8; ++q) *reinterpret_cast<f16x8 *>(a.dy + p * CS + q * 8) = dv[q];
+    };
+    // two pixels per iteration: both pixels' loads are issued before the arithmetic of the first
+    long long p = (long long)blockIdx.x * 256 + t;
+    for (; p + stride < a.n_pix; p += 2 * stride) {
+        f16x8 z0[CS / 8], z1[CS / 8];
+        uint8_t y0[K], y1[K];
+#pragma unroll
+        for (int q = 0; q < CS / 8; ++q) {
+            z0[q] = *reinterpret_cast<const f16x8 *>(a.z + p * CS + q * 8);
+            z1[q] = *reinterpret_cast<const f16x8 *>(a.z + (p + stride) * CS + q * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { y0[k] = a.y[p * K + k]; y1[k] = a.y[(p + stride) * K + k]; }
+        pixel(z0, y0, p);
+        pixel(z1, y1, p + stride);
+    }
+    if (p < a.n_pix) {
+        f16x8 z0[CS / 8];
+        uint8_t y0[K];
+#pragma unroll
+        for (int q = 0; q < CS / 8; ++q) z0[q] = *reinterpret_cast<const f16x8 *>(a.z + p * CS + q * 8);
+#pragma unroll
+        for (int k = 0; k < K; ++k) y0[k] = a.y[p * K + k];
+        pixel(z0, y0, p);
+    }
+    // ---- per-workgroup partial rows, fixed order: lanes (butterfly), then waves 0..3 ----------------------------------------
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const float v = wave_sum<64>(acc[i]);
+        if (lane == 0) s_red[wave][i] = v;
+    }
+    __syncthreads();
+    auto tot = [&](int i) { return (s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i]); };
+    if (t < 2 * CS) a.dystat_partial[(size_t)blockIdx.x * 2 * CS + t] = tot(t);
+    if (t == 0) a.loss_partial[blockIdx.x] = tot(2 * CS + CS * K + K);
+    // weight-gradient partial row [tap 0 | bias][256] in wgf_stage1's layout: element e = r * 64 + l holds (ci = 4 (l >> 4) + r,
+    // co = l & 15); the bias row keeps co in elements 0..15
+    float *wp = a.wg_partial + (size_t)blockIdx.x * 2 * 256;
+    {
+        const int r = t >> 6, l = t & 63, ci = 4 * (l >> 4) + r, co = l & 15;
+        wp[t] = (ci < CS && co < K) ? tot(2 * CS + ci * K + co) : 0.f;
+        wp[256 + t] = (t < K) ? tot(2 * CS + CS * K + t) : 0.f;
+    }
+    IMK_STAMP_END(1);
 }
 
 }  // namespace
+
+// Sigmoid heads with one map on 8 (padded) channels: ISIC at alpha 0.5, the headline shape.  Measured per training step
+// (tests/gpu_probe/ab_env.sh, off / on): ISIC alpha 0.5 1.007 / 0.983 ms; the wider forms hold their 2 CS + CS K + K + 1
+// accumulators in 215-256 registers (two waves per SIMD) and lose -- ISIC alpha 1 (16 channels, 1 map) 1.674 / 1.684, HeLa
+// (16 channels, 3 maps) 1.673 / 1.745 -- so they keep head_loss_kernel + the pipelined dgrad.  rows_cap as below.
+bool imk_head_mse_fused_ok(int cs, int K, long long n_pix, int rows_cap) {
+    static const bool off = []() { const char *e = getenv("IMK_HEAD_MSE_FUSE"); return e && e[0] == '0'; }();
+    if (off || cs != 8 || K != 1) return false;
+    return imk_loss_blocks(n_pix) <= rows_cap;
+}
+
+int imk_launch_head_mse_fused(const f16 *z, const float *sc, const float *sh, const float *w, const float *bias, int cin, int cs,
+                              int K, long long n_pix, const uint8_t *y, const ImkCtl *ctl, float *stats, f16 *dy,
+                              float *loss_partial, float *dystat_partial, float *wg_partial, hipStream_t stream) {
+    HeadCceArgs a{z, sc, sh, w, bias, cin, cs, K, n_pix, y, ctl, stats, dy, loss_partial, dystat_partial, wg_partial, 1};
+    const int grid = imk_loss_blocks(n_pix);
+    ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + K + cs * 2), stream, 6.0 * n_pix * cin * K);
+    if (cs == 8 && K == 1) head_mse_fused_kernel<8, 1><<<grid, 256, 0, stream>>>(a);
+    else return IMK_EUNSUPPORTED;
+    IMK_LAUNCH_CHECK();
+    return IMK_OK;
+}
 
 // Softmax heads with 8 ... 32 (padded) input channels and up to 64 classes.  `rows_cap`: capacity (rows) of dystat_partial.
 bool imk_head_cce_fused_ok(int cs, int K, long long n_pix, int rows_cap) {

@@ -35,6 +35,10 @@ struct ImkInput {
                            // an odd last row / column (Keras 'valid' pooling: EvalNet at sizes that are not multiples of 64)
 };
 
+// tile counters of a launch that walks its tiles dynamically (ImkConvArgs::sched; imk_stage.h: ImkWalk): 32 counters, 256 B apart
+#define IMK_SCHED_HEADS 32
+#define IMK_SCHED_STRIDE 256
+#define IMK_SCHED_BYTES (IMK_SCHED_HEADS * IMK_SCHED_STRIDE)
 struct ImkConvArgs {
     ImkInput x;
     int B, H, W;           // resolution of the conv (= of the output)
@@ -72,6 +76,9 @@ struct ImkConvArgs {
     // second form (the U-Net's output layer: 1x1 conv on a BatchNorm output, dgrad = LM_RAW / EP_PLAIN with the BN-gradient
     // statistics): x = fp16(dystat_z * wg_sc + wg_sh), the BatchNorm being applied to the transposed LDS reads
     const float *wg_sc, *wg_sh;
+    // optional (forward launches without statistics, i.e. inference): IMK_SCHED_BYTES of zeroed tile counters, one per group of the
+    // persistent walk -- the workgroups then TAKE their tiles (imk_stage.h: ImkWalk, dynamic form) instead of striding over them
+    unsigned *sched;
 };
 // multiply-adds x 2 of a conv launch (logical channel counts; + the chained 1x1, + the first-stage 1x1)
 inline double imk_conv_flops(const ImkConvArgs &a) {

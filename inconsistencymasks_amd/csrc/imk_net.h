@@ -95,6 +95,8 @@ struct Ws {
     size_t cat = 0, dcat = 0;      // concatenated pooled tower outputs [B,H/2,W/2,2F] and their gradient
     size_t onehot = 0;             // b_onehot: input B as fp16 one-hot [B,H,W,pad8(cb)]
     size_t head_partial = 0;       // train: per-sample Dense gradients and loss terms
+    size_t sched = 0;              // inference (U-Net): IMK_SCHED_BYTES of tile counters per layer (ImkConvArgs::sched), zeroed per forward
+    bool has_sched = false;
     size_t total = 0;
 };
 
@@ -145,6 +147,9 @@ struct Ctx {
     bool train;
     hipStream_t stream;
     const uint8_t *x_in[2] = {nullptr, nullptr};   // the uint8 network inputs (U-Net: [0] only)
+    unsigned *sched(int conv) const {     // the launch's tile counters (inference with a workspace that carries them), else null
+        return (!train && ws.has_sched) ? reinterpret_cast<unsigned *>(base + ws.sched + IMK_SCHED_BYTES * (size_t)conv) : nullptr;
+    }
     int ovr_conv = -1;    // ensemble inference: this conv's output lives outside the (shared) activation workspace ...
     f16 *ovr_out = nullptr;   // ... here, so that it survives until the fused head + IM kernel has read every model's
     f16 *act(int conv) const { return conv == ovr_conv ? ovr_out : reinterpret_cast<f16 *>(base + ws.L[conv].out); }
@@ -196,6 +201,7 @@ inline int run_conv_fwd(Ctx &c, int conv, float *params_rw, int conv2 = -1, bool
     a.bias = c.params + l.off_b;
     a.out = c.act(conv);
     a.epi = EP_RELU;
+    a.sched = c.sched(conv);
     int stat_conv = conv;
     if (fused) *fused = false;
     if (conv2 >= 0) {
@@ -250,6 +256,7 @@ inline int run_conv_pre_pair(Ctx &c, int pre, int c3, int c1) {
     a.bias = c.params + l.off_b;
     a.out = nullptr;
     a.epi = EP_RELU;
+    a.sched = c.sched(c3);
     a.wpk2 = reinterpret_cast<const f16 *>(c.packed + l2.pk_chain);
     a.bias2 = c.params + l2.off_b;
     a.out2 = c.act(c1);

@@ -291,18 +291,51 @@ __device__ __forceinline__ PTile ptile_next(const PTile &c, int grid_q, int grid
 // [g * chunk, (g + 1) * chunk) and its workgroups (block >> shift = 0 .. step - 1) sweep it together, a band of `step`
 // neighbouring tiles per iteration: the halo re-reads are hits in that XCD's L2.  shift = 0 is the plain walk.  Placement is a
 // matter of speed only; any block -> XCD map gives the same results.
-struct ImkWalk { int chunk, shift, step, q, r; };      // q, r: step = q images + r tiles
-inline ImkWalk imk_walk_make(int &grid, int n_tiles, int per_img) {
+// Dynamic form (round 4; kernels instantiated with DYN, launches that carry ImkConvArgs::sched): the workgroups of one launch
+// have equal work but finish 12 ... 22 us after its start (per-workgroup clock stamps, tests/gpu_probe/wgstamps.py: the e1 / d9
+// forward launch; 93 ... 123 us for the decoder's inference launch) -- the launch ends with its slowest workgroup.  There a
+// workgroup's first tile is the static one and every further tile is TAKEN from its group's counter (one returning atomic per tile,
+// requested two tiles ahead so that its latency never shows): fast workgroups process more tiles, all finish together.  Only for
+// launches whose results do not depend on which workgroup computed which tile (no per-workgroup partial rows): inference.
+struct ImkWalk { int chunk, shift, step, q, r; unsigned magic_pi; };      // q, r: step = q images + r tiles; magic_pi: / per_img (0: divide)
+// group of a block and the index of its tile range: ranges of one XCD are neighbours (shift 5: range = 4 * XCD + quarter)
+__device__ __forceinline__ int imk_walk_range(const ImkWalk &wk, unsigned block) {
+    const int grp = (int)(block & ((1u << wk.shift) - 1u));
+    return wk.shift == 5 ? (((grp & 7) << 2) | (grp >> 3)) : grp;
+}
+inline unsigned imk_div_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+// Tile counters of the dynamic form: IMK_SCHED_HEADS counters per launch, IMK_SCHED_STRIDE bytes apart.  One counter word takes
+// ~90 atomics per microsecond, and counters in one 64-byte line share that (the first version, 8 counters in one line, added
+// 1.6 ms to a 0.9 ms forward); 32 groups = 4 per XCD on separate lines keep the take off the critical path.
+// (IMK_SCHED_HEADS / IMK_SCHED_STRIDE / IMK_SCHED_BYTES: imk_kernels.h)
+inline ImkWalk imk_walk_make(int &grid, int n_tiles, int per_img, bool dyn = false) {
     static const bool off = []() { const char *e = getenv("IMK_XCD_WALK"); return e && e[0] == '0'; }();
     ImkWalk w{};
-    if (!off && grid >= 64 && n_tiles >= 64) {
+    if (dyn && grid >= 64 && n_tiles >= 64) {     // 32 groups: group & 7 = XCD, group >> 3 = quarter of that XCD's range
+        grid &= ~31;
+        w.shift = 5; w.chunk = (n_tiles + 31) / 32; w.step = grid / 32;
+    } else if (!off && grid >= 64 && n_tiles >= 64) {
         grid &= ~7;
         w.shift = 3; w.chunk = (n_tiles + 7) / 8; w.step = grid / 8;
     } else {
         w.shift = 0; w.chunk = n_tiles; w.step = grid;
     }
     w.q = w.step / per_img; w.r = w.step % per_img;
+    w.magic_pi = (per_img > 1 && (long long)n_tiles * per_img < (1ll << 32)) ? imk_div_magic(per_img) : 0u;
     return w;
+}
+
+// tile index of the launch -> (image, tile in image, origin); the index is wave-uniform
+__device__ __forceinline__ PTile ptile_of_index(int tile, int per_img, int tiles_x, unsigned magic_tx, unsigned magic_pi) {
+    const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+    const unsigned b = magic_pi ? (unsigned)(((unsigned long long)tu * magic_pi) >> 32) : (per_img == 1 ? tu : tu / (unsigned)per_img);
+    return ptile_at((int)b, (int)(tu - b * (unsigned)per_img), tiles_x, magic_tx);
+}
+// one tile ticket of counter `head` for the whole WORKGROUP: every lane issues the (bounds-checked) buffer atomic -- no branch, so
+// the compiler keeps counting the loop's memory operations -- but only lane 0 of wave 0 is inside the 4-byte buffer and adds
+__device__ __forceinline__ int imk_take_ticket(unsigned *head, bool chosen) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(head, 0, 4, 0x00020000);
+    return __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs, chosen ? 0 : 0x7ffffff0, 0, 1 /* sc0: return the old value */);
 }
 
 // base of pixel (y, x) of image b in a tensor with pitch_b bytes per pixel: scalar; may point in front of the tensor (y, x = -1)

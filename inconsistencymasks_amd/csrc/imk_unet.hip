@@ -94,6 +94,7 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
     make_ws_layers(p, B, mode, w, take);
+    if (mode == 0) { w.sched = take(IMK_SCHED_BYTES * p->layers.size()); w.has_sched = true; }
 
     if (mode == 1) {
         for (int j = 0; j < 4; ++j) {  // decoder j+6 at res 3-j; u has the channels of ca's input
@@ -117,6 +118,8 @@ Ws make_ws(const imk_unet_plan *p, int B, int mode) {
 
 int run_forward(Ctx &c, const Topo &t, float *probs, float *params_rw) {
     int rc;
+    // inference: the tile counters of this forward's launches (dynamic walk of the persistent conv kernels) start at zero
+    if (!c.train && c.ws.has_sched) IMK_HIP(hipMemsetAsync(c.base + c.ws.sched, 0, IMK_SCHED_BYTES * c.p->layers.size(), c.stream));
 #define RUN(conv) do { rc = run_conv_fwd(c, (conv), params_rw); if (rc) return rc; } while (0)
     // Conv3x3+ReLU -> Conv1x1+ReLU pairs run as one kernel where the channel counts allow it
 #define RUN_PAIR(c3, c1) do { rc = run_conv_pair(c, (c3), (c1), params_rw); if (rc) return rc; } while (0)
@@ -431,7 +434,9 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
     // then the output layer's dgrad (+ fused weight gradient where the pipelined kernel covers the shape)
     const bool head_one_pass = cf.act_out == 1 &&
                                imk_head_cce_fused_ok(imk_pad8(ol.cin), ol.cout, n_pix, c.ws.L[obn].n_bwd_rows);
-    if (!head_one_pass)
+    // sigmoid heads with 1 / 3 maps on <= 16 channels (ISIC, HeLa): the same in one pass (head_mse_fused_kernel, round 4)
+    const bool head_mse_pass = cf.act_out == 0 && imk_head_mse_fused_ok(imk_pad8(ol.cin), ol.cout, n_pix, c.ws.L[obn].n_bwd_rows);
+    if (!head_one_pass && !head_mse_pass)
         OK(imk_launch_head_loss(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b, ol.cin,
                                 imk_pad8(ol.cin), ol.cout, cf.act_out, n_pix, y, sv.ctl, stats, dlogit, loss_partial, stream));
 
@@ -450,7 +455,15 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         loss_done = true;
         return imk_launch_loss_finalize(loss_partial, n_pix, cf.n_out, loss_kind, stats, plan->side[(b.n_fork - 1) % b.n_side]);
     };
-    if (head_one_pass) {
+    if (head_mse_pass) {
+        const int rows = imk_head_cce_fused_rows(n_pix);
+        float *wgp = reinterpret_cast<float *>(c.base + c.ws.L[t.out].wg_partial);
+        OK(imk_launch_head_mse_fused(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b,
+                                     ol.cin, imk_pad8(ol.cin), ol.cout, n_pix, y, sv.ctl, stats, c.dy(obn), loss_partial,
+                                     reinterpret_cast<float *>(c.base + c.ws.L[obn].bwd_partial), wgp, stream));
+        b.dy_rows[obn] = rows;
+        OK(imk_wgf_add_job(b.jobs, wgp, rows, ol.ksize, ol.cin, ol.cout, grads + ol.off_w, grads + ol.off_b));
+    } else if (head_one_pass) {
         const int rows = imk_head_cce_fused_rows(n_pix);
         float *wgp = reinterpret_cast<float *>(c.base + c.ws.L[t.out].wg_partial);
         OK(imk_launch_head_cce_fused(c.act(t.d_c1[3]), c.bn_scale(obn), c.bn_shift(obn), params + ol.off_w, params + ol.off_b,

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include "imk_stage.h"
 
+IMK_STAMP_TABLE(wgemm)
+
 namespace {
 
 bool gemm_env_on() {
@@ -34,6 +36,7 @@ struct WgGemmGeom { int tiles_x, tiles_y, n_tiles, cit_n, cot_n, nci, nco, gi_n,
 // of alpha in (1, 2] and EvalNet's towers: half the accumulators, 3 workgroups per CU instead of 2)
 template <int LM, bool BNB, bool KS3, int NFI, int NFO = 4>
 __global__ __launch_bounds__(256, NFO == 2 ? 3 : 2) void wgrad_gemm_kernel(ImkWgradArgs a, WgGemmGeom gm) {
+    IMK_STAMP_BEGIN(wgemm, 80000 + LM * 10 + (KS3 ? 1 : 0));
     constexpr int KP = 4 / NFI;                      // waves along the k-steps
     constexpr int TR = NFI == 1 ? 8 : 4;             // tile rows (8 rows for the 1x1 forms too: measured slower, 5.77 vs 5.65 ms)
     constexpr int KS = TR / 2;                       // k-steps per tile
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(256, NFO == 2 ? 3 : 2) void wgrad_gemm_kernel(ImkWg
             }
         }
     }
+    IMK_STAMP_END(1);
 }
 
 }  // namespace

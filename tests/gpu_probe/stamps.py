@@ -31,6 +31,7 @@ H, W, C, K, ALPHA, ACT, LOSS = CFG[os.environ.get("CONFIG", "isic")]
 ALPHA = float(os.environ.get("ALPHA", ALPHA))
 lib = _lib.lib
 ROWS, COLS = 4096, 16
+TUS = ("conv", "elem", "gemm", "bwd1", "wgemm", "headf")
 x = torch.randint(0, 256, (32, H, W, C), dtype=torch.uint8, device="cuda")
 y = ((torch.rand((32, H, W, K), device="cuda") > 0.7).to(torch.uint8) if LOSS == 0
      else torch.randint(0, K, (32, H, W), dtype=torch.uint8, device="cuda"))
@@ -39,7 +40,7 @@ for _ in range(5):
     m.train_step(x, y, LOSS, 3e-3, 1e-4)
 torch.cuda.synchronize()
 tabs = {}
-for tu in ("conv", "elem", "gemm"):
+for tu in TUS:
     fn = getattr(lib, "imk_debug_stamps_" + tu)
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     fn(None, 1)
@@ -50,7 +51,7 @@ else:
     m.train_step(x, y, LOSS, 3e-3, 1e-4)
 torch.cuda.synchronize()
 rows = []
-for tu in ("conv", "elem", "gemm"):
+for tu in TUS:
     buf = np.zeros((ROWS, COLS), dtype=np.uint64)
     n = getattr(lib, "imk_debug_stamps_" + tu)(buf.ctypes.data, 0)
     for r in buf[:n]:
@@ -65,7 +66,8 @@ for rt, tu, r in rows:
 mhz = num / den * 100.0
 print(f"shader clock ~{mhz:.0f} MHz; {len(rows)} stamped launches; after the grid size: us from kernel entry at each stamp")
 # kernel ids: 1 bn_finalize, 2 bn_bwd_coef, 10+m bn_bwd_prep<m>, 20 bn_bwd_prep_pool, 1xxxx conv_mfma, 3xxxx wgrad_mfma (side
-# stream except the step's last one), 4xxxx conv_pipe, 5xxxx conv_wide.  "idle" = time between the end of the previous MAIN-chain
+# stream except the step's last one), 4xxxx conv_pipe, 5xxxx conv_wide, 6xxxx conv_gemm, 7xxxx bwd1x1, 8xxxx wgrad_gemm (side), 9000x
+# fused heads, 21 wgf_stage1 (side but the last), 23 pack.  "idle" = time between the end of the previous MAIN-chain
 # kernel's first workgroup and this kernel's entry (head+loss, AdamW, the re-pack and the split reductions carry no stamps).
 prev_end = None
 idle_sum = 0.0
@@ -73,7 +75,7 @@ for rt, tu, r in rows:
     st = [int(v) for v in r[3:15] if int(v)]
     rel = [(v - st[0]) / mhz for v in st]
     kid = int(r[0])
-    side = tu == "conv" and 30000 <= kid < 40000
+    side = (tu == "conv" and (30000 <= kid < 40000 or kid == 21)) or tu == "wgemm"   # (the step's last wgrad / reduction: main)
     t_us = (rt - rows[0][0]) / 100.0
     idle = ""
     if not side:
