@@ -18,6 +18,34 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// The library's ONE definition of "a BatchNorm applied to a stored fp16 activation": fp16(z * sc + sh) with the fp32 fused
+// multiply-add ROUNDED TO fp32 before it is rounded to fp16 (v_pk_fma_f32 + v_cvt_pk_f16_f32) -- two roundings, like the
+// reference's float32 BatchNorm followed by a cast.  Written as a plain expression on a value that was just converted from
+// fp16, the compiler is free to emit v_fma_mixlo_f16 instead, which rounds the exact sum ONCE; it did so in some kernels (and,
+// inside one kernel, for some channels) and not in others: 1e-4 of the values then differ by an fp16 ulp between a fused launch
+// and its two-launch form (round 2-3's "border pixel" discrepancy of the decoder's first-stage launch).
+// The empty asm statements keep the fp32 sums values of their own, so every site computes the same function.
+__device__ __forceinline__ f16x2 imk_affine2(f16x2 z, f32x2 sc, f32x2 sh) {
+    f32x2 t = __builtin_elementwise_fma(__builtin_convertvector(z, f32x2), sc, sh);
+    asm volatile("" : "+v"(t));
+    return __builtin_convertvector(t, f16x2);
+}
+__device__ __forceinline__ f16 imk_affine1(f16 z, float sc, float sh) {
+    float t = __builtin_fmaf((float)z, sc, sh);
+    asm volatile("" : "+v"(t));
+    return (f16)t;
+}
+__device__ __forceinline__ f16x8 imk_affine8(f16x8 z, const float *sc, const float *sh) {
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f16x2 r = imk_affine2(f16x2{z[j], z[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]});
+        o[j] = r[0]; o[j + 1] = r[1];
+    }
+    return o;
+}
+
 // 64-lane butterfly sum inside groups of `width` consecutive lanes (width = 16 or 64)
 template <int WIDTH>
 __device__ __forceinline__ float wave_sum(float v) {

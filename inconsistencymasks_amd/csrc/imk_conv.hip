@@ -7,7 +7,7 @@
 //     upsample+add / u8->float applied on the way in, so those layers never make their own HBM pass;
 //   * the pixel operand (MFMA B) is one ds_read_b128 per lane per k-step straight from that tile: the 8
 //     consecutive k of a lane are the 8 channels of one chunk of one (shifted) pixel, so im2col is free;
-//     pixel stride is an odd number of 16-byte chunks => conflict-free across the 16 pixels of a group;
+//     pixel stride imk_lds_pitch(chunks) (imk_stage.h) => conflict-free across the hardware's 16-lane groups of ds_read_b128;
 //   * the weight operand (MFMA A) is pre-packed in fragment order in HBM (a few KB, L2 resident) and read
 //     with one coalesced 16-byte load per lane per k-step, shared by the wave's P pixel groups;
 //   * output channels sit on the accumulator rows, so a lane owns 4 consecutive channels of one pixel and
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // LDS of conv_pipe_kernel without the PRE stage's extra tile: tile, affine table, statistics, u8 rows, fused-wgrad x tile
 // (+ slack: its transposed reads reach 16 bytes past a pixel); at least the fused 3x3 weight gradient's final reduction
 constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
-    size_t b = (size_t)18 * 18 * (nc8 | 1) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +
+    size_t b = (size_t)18 * 18 * imk_lds_pitch(nc8) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +
                (wg ? (size_t)(wg == 3 ? 18 * 18 : 256) * ((pair ? 1 : 2) | 1) * 16 + 64 : 0);
     if (wg == 3 && b < 4 * 5 * 256 * sizeof(float)) b = 4 * 5 * 256 * sizeof(float);
     return (b + 15) & ~(size_t)15;
@@ -453,9 +453,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
     static_assert(WG != 3 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 3x3 dgrad in front of a BatchNorm");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
-    constexpr int PS = NC8 | 1;                 // pixel stride in 16-byte chunks (odd)
+    constexpr int PS = imk_lds_pitch(NC8);      // pixel stride in 16-byte chunks (imk_stage.h)
     constexpr int NCI = PRE ? PRE : NC8;        // chunks per pixel of the STAGED tensor (PRE: the 1x1's input)
-    constexpr int PSI = NCI | 1;
+    constexpr int PSI = imk_lds_pitch(NCI);
     constexpr int MAX_ITEMS = (18 * 18 * NCI + 255) / 256;
     constexpr int MAX_NS = PAIR ? (9 * NC8 + 1) / 2 : (9 * NC8 + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -759,10 +759,20 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const f16 z = (f16)fmaxf(pa[r] + pb[r], 0.f);              // the 1x1's stored output
-                    w[r] = inside ? (f16)((float)z * psc[r] + psh[r]) : (f16)0.f;
+                    w[r] = inside ? imk_affine1(z, psc[r], psh[r]) : (f16)0.f;      // two roundings, as the staged form (imk_common.h)
                 }
                 if (pre_cb < NC8 * 8)
                     *reinterpret_cast<f16x4 *>(s_tile + (pre_pix[j] * PS + (pre_cb >> 3)) * 16 + (pre_cb & 7) * 2) = w;
+#ifdef IMK_PRE_DEBUG      // probe builds (tests/gpu_probe/pre_dump.py): the first stage's values of the tile's own pixels, for a per-pixel diff
+                if (a.out && pre_cb < NC8 * 8 && py >= 1 && py <= 16 && px >= 1 && px <= 16 && inside) {
+                    const size_t gp = ((size_t)(tc.b * H + tc.ty0 + py - 1) * W + tc.tx0 + px - 1) * (NC8 * 8) + pre_cb;
+                    f16x4 zv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zv[r] = (f16)fmaxf(pa[r] + pb[r], 0.f);
+                    *reinterpret_cast<f16x4 *>(const_cast<f16 *>(a.mask) + gp) = zv;      // pre-BatchNorm (what the 1x1's own launch stores)
+                    *reinterpret_cast<f16x4 *>(a.out + gp) = w;                            // after the BatchNorm (the 3x3's input)
+                }
+#endif
             }
             __syncthreads();      // the 3x3's input tile is complete
         }
@@ -816,7 +826,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 for (int e = 0; e < 4; ++e) { bfw[e] = (f16)b0[e]; bfw[4 + e] = (f16)b1[e]; afw[e] = (f16)a0[e]; afw[4 + e] = (f16)a1[e]; }
                 if constexpr (WG == 2) {      // x = the BatchNorm output: fp16(z * sc + sh), what LM_AFFINE staging computes
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) afw[e] = (f16)((float)afw[e] * x_sc + x_sh);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f16x2 r2 = imk_affine2(f16x2{afw[e], afw[e + 1]}, f32x2{x_sc, x_sc}, f32x2{x_sh, x_sh});
+                        afw[e] = r2[0]; afw[e + 1] = r2[1];
+                    }
                 }
                 wacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afw, bfw, wacc, 0, 0, 0);
                 bacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bfw, bacc, 0, 0, 0);   // column sums -> bias gradient
@@ -964,7 +977,7 @@ template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL, bool CHAIN2 
 __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, ImkWalk wk) {
     constexpr int P = 4;
-    constexpr int PS = NC8 | 1;
+    constexpr int PS = imk_lds_pitch(NC8);
     constexpr int MAX_ITEMS = (18 * 18 * NC8 + 255) / 256;
     constexpr int MAX_NS = (9 * NC8 + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -977,7 +990,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ImkConvArgs a, int tiles
     float *s_aff = reinterpret_cast<float *>(smem + 18 * 18 * PS * 16);        // up to 4 x 32 floats (LM_UPADD)
     float *s_red = s_aff + 4 * 32;                                             // [4 waves][2][16 * MT]
     f16 *s_w = reinterpret_cast<f16 *>(s_red + 4 * 2 * 16 * MT);               // [MT][ns][512]
-    constexpr int MIDP = 40;                                                   // halfs per pixel of the chain's slab
+    constexpr int MIDP = 48;                                                   // halfs per pixel of the chain's slab: 6 chunks (imk_lds_pitch(4))
     const int t = threadIdx.x;
     f16 *s_mid = s_w + (size_t)MT * ns * 512 + (t >> 6) * 64 * MIDP;           // CHAIN2: this wave's [64 pixels][MIDP]
     IMK_STAMP_BEGIN(conv, 50000 + LM * 1000 + MT * 10 + (DYSTAT ? 1 : 0));
@@ -1623,7 +1636,7 @@ int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
 }
 
 // -----------------------------------------------------------------------------------------------------
-static inline int odd_ps(int nc8) { return nc8 | 1; }
+static inline int odd_ps(int nc8) { return imk_lds_pitch(nc8); }   // (name kept: the per-tile kernel's pitch; odd until round 4)
 
 // Tile height: 16 rows unless the LDS tile would exceed 64 KB (wide layers), then 8.
 static inline int conv_tile_h(int cs_in, int ksize) {
@@ -1873,7 +1886,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
             return launch_conv_pipe_k<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, true>(a, stream);
     }
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
-    const size_t lds = pipe_lds_base(NC8, PAIR, WG) + (PRE ? (size_t)18 * 18 * (PRE | 1) * 16 + 3 * 16 * sizeof(float) : 0);
+    const size_t lds = pipe_lds_base(NC8, PAIR, WG) + (PRE ? (size_t)18 * 18 * imk_lds_pitch(PRE) * 16 + 3 * 16 * sizeof(float) : 0);
     auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, DYN>;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -1906,7 +1919,10 @@ template <int NC8, bool PAIR, bool FULL>
 static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
     if (a.pre_wpk) {        // 1x1 first stage + 3x3 + chained 1x1 (inference); instantiated for the pair layout (imk_conv_can_prestage)
         if constexpr (PAIR && NC8 == 1) {
-            if (a.epi != EP_RELU || !a.wpk2 || a.out || a.x.lmode != LM_UPADD || a.x.cs_in != 8) return IMK_EUNSUPPORTED;
+#ifndef IMK_PRE_DEBUG     // (the probe build passes dump tensors in a.out / a.mask)
+            if (a.out) return IMK_EUNSUPPORTED;
+#endif
+            if (a.epi != EP_RELU || !a.wpk2 || a.x.lmode != LM_UPADD || a.x.cs_in != 8) return IMK_EUNSUPPORTED;
             return launch_conv_pipe_k<LM_UPADD, 1, 2, true, EP_RELU, false, FULL, 0, 1>(a, stream);
         } else {
             return IMK_EUNSUPPORTED;
@@ -1978,9 +1994,10 @@ template <int LM, int NC8, int MT, int EPI, bool DYSTAT, bool FULL, bool CHAIN2 
 static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     static int blocks_per_cu = 0;
     const int ns = ((a.ksize == 3 ? 9 : 1) * NC8 + 3) / 4;
-    const size_t lds = (size_t)18 * 18 * (NC8 | 1) * 16 + (4 * 32 + 4 * 2 * 16 * MT) * sizeof(float) + (size_t)MT * ns * 1024 +
-                       (CHAIN2 ? (size_t)4 * 64 * 40 * sizeof(f16) : 0);
+    const size_t lds = (size_t)18 * 18 * imk_lds_pitch(NC8) * 16 + (4 * 32 + 4 * 2 * 16 * MT) * sizeof(float) + (size_t)MT * ns * 1024 +
+                       (CHAIN2 ? (size_t)4 * 64 * 48 * sizeof(f16) : 0);
     auto kern = conv_wide_kernel<LM, NC8, MT, EPI, DYSTAT, FULL, CHAIN2>;
+    { int r = set_lds_limit(kern, lds); if (r) return r; }
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;

@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnPrepArgs a) {
                     const int me = (ys[u] & 1) * 2 + (xs[u] & 1);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const f16 vm = (f16)((float)zz[u][j] * sc[j] + shf[j]);
-                        const f16 o[3] = {(f16)((float)w1[u][j] * sc[j] + shf[j]), (f16)((float)w2[u][j] * sc[j] + shf[j]),
-                                          (f16)((float)w3[u][j] * sc[j] + shf[j])};
+                        const f16 vm = imk_affine1(zz[u][j], sc[j], shf[j]);      // the forward's pooled values (imk_common.h)
+                        const f16 o[3] = {imk_affine1(w1[u][j], sc[j], shf[j]), imk_affine1(w2[u][j], sc[j], shf[j]),
+                                          imk_affine1(w3[u][j], sc[j], shf[j])};
                         bool win = true;
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_pool_kernel(BnPrepArgs a) {
                 // the pooled gradient goes to the FIRST maximum of the window in row-major order
                 f16 v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (f16)((float)z[e][j] * sc[j] + shf[j]);
+                for (int e = 0; e < 4; ++e) v[e] = imk_affine1(z[e][j], sc[j], shf[j]);
                 int win = 0;
 #pragma unroll
                 for (int e = 1; e < 4; ++e) if (v[e] > v[win]) win = e;
@@ -405,7 +405,10 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const f16 *__restrict__ 
         for (int q = 0; q < CS / 8; ++q) {
             const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+            for (int j = 0; j < 8; j += 2) {
+                const f16x2 r2 = imk_affine2(f16x2{v[j], v[j + 1]}, f32x2{s_sc[q * 8 + j], s_sc[q * 8 + j + 1]}, f32x2{s_sh[q * 8 + j], s_sh[q * 8 + j + 1]});
+                xin[q * 8 + j] = (float)r2[0]; xin[q * 8 + j + 1] = (float)r2[1];
+            }
         }
         auto logit = [&](int k) {
             float acc = s_b[k];

@@ -40,7 +40,7 @@ constexpr int G_BM = 16 * G_TH;               // pixels per workgroup tile
 struct GemmGeom {
     int tiles_x, tiles_y, n_sp, gy, mt_total;
     int nc8, nc8p, n_pass, nsp, ns_total;     // packed-weight geometry: chunks, chunks per pass, passes, k-steps per pass / in all
-    int spp, cps, n_stage, ps;                // passes per stage, chunks per stage, stages, LDS pixel pitch in chunks (odd)
+    int spp, cps, n_stage, ps;                // passes per stage, chunks per stage, stages, LDS pixel pitch in chunks (imk_lds_pitch)
     int nc8_2, nc8p_2, ns_2, mt_2;            // CH2: the chained 1x1's k geometry (chunks, chunks per pass, k-steps) and output tiles
 };
 
@@ -420,7 +420,7 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     gm.gy = imk_cdiv_d(mt_total, bn / 16);
     gm.mt_total = mt_total;
     gm.nc8 = nc8; gm.nc8p = nc8p; gm.n_pass = n_pass; gm.nsp = nsp; gm.ns_total = n_pass * nsp;
-    gm.spp = spp; gm.cps = cps; gm.n_stage = imk_cdiv_d(n_pass, spp); gm.ps = odd_up(cps);
+    gm.spp = spp; gm.cps = cps; gm.n_stage = imk_cdiv_d(n_pass, spp); gm.ps = imk_lds_pitch(cps);
     const size_t tile_bytes = (size_t)(G_TH + 2 * halo) * (TW + 2 * halo) * gm.ps * 16;
     lds = 2 * tile_bytes + 4 * (size_t)a.x.cs_in * sizeof(float);
     const size_t out_bytes = (size_t)G_BM * (bn + 8) * sizeof(f16);

@@ -30,7 +30,10 @@ __device__ __forceinline__ void head_input(const f16 *__restrict__ z, long long 
     for (int q = 0; q < CS / 8; ++q) {
         const f16x8 v = *reinterpret_cast<const f16x8 *>(z + p * CS + q * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xin[q * 8 + j] = (float)(f16)((float)v[j] * s_sc[q * 8 + j] + s_sh[q * 8 + j]);
+        for (int j = 0; j < 8; j += 2) {
+            const f16x2 r2 = imk_affine2(f16x2{v[j], v[j + 1]}, f32x2{s_sc[q * 8 + j], s_sc[q * 8 + j + 1]}, f32x2{s_sh[q * 8 + j], s_sh[q * 8 + j + 1]});
+            xin[q * 8 + j] = (float)r2[0]; xin[q * 8 + j + 1] = (float)r2[1];
+        }
     }
 }
 
@@ -105,7 +108,10 @@ struct HeadMfma {
         const int g = (threadIdx.x & 63) >> 4;
         f16x8 x8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = (f16)((float)z8[j] * sc8[j] + sh8[j]);        // as head_input
+        for (int j = 0; j < 8; j += 2) {                                                  // as head_input
+            const f16x2 r2 = imk_affine2(f16x2{z8[j], z8[j + 1]}, f32x2{sc8[j], sc8[j + 1]}, f32x2{sh8[j], sh8[j + 1]});
+            x8[j] = r2[0]; x8[j + 1] = r2[1];
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             pr[kt] = f32x4{bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void head_cce_fused_kernel(HeadCceArgs a) {
             // x = fp16(z * sc + sh): the head's input, as head_kernel / head_loss_kernel form it
             f16x8 x8;                                  // channels 8 g + j of the lane's pixel
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x8[j] = (f16)((float)z8[u][j] * sc8[j] + sh8[j]);
+            for (int j = 0; j < 8; j += 2) {
+                const f16x2 r2 = imk_affine2(f16x2{z8[u][j], z8[u][j + 1]}, f32x2{sc8[j], sc8[j + 1]}, f32x2{sh8[j], sh8[j + 1]});
+                x8[j] = r2[0]; x8[j + 1] = r2[1];
+            }
             // logits of the lane's pixel: classes 16 kt + 4 g + r
             f32x4 lg[KT];
 #pragma unroll
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void head_mse_fused_kernel(HeadCceArgs a) {
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
             zf[c] = (float)zv[c >> 3][c & 7];
-            xin[c] = (float)(f16)(zf[c] * s_sc[c] + s_sh[c]);
+            xin[c] = (float)imk_affine1(zv[c >> 3][c & 7], s_sc[c], s_sh[c]);
         }
         float gk[K];
 #pragma unroll

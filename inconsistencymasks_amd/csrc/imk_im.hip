@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void head_im_sigmoid_kernel(ImkHeadImArgs a, i
 #pragma unroll
             for (int q = 0; q < CS / 8; ++q)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xin[q * 8 + e] = (float)(f16)((float)r[q][e] * s_sc[q * 8 + e] + s_sh[q * 8 + e]);   // = head_input
+                for (int e = 0; e < 8; e += 2) {                                                                                  // = head_input
+                    const f16x2 r2 = imk_affine2(f16x2{r[q][e], r[q][e + 1]}, f32x2{s_sc[q * 8 + e], s_sc[q * 8 + e + 1]}, f32x2{s_sh[q * 8 + e], s_sh[q * 8 + e + 1]});
+                    xin[q * 8 + e] = (float)r2[0]; xin[q * 8 + e + 1] = (float)r2[1];
+                }
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const float v = head_sigmoid(head_logit<CS>(xin, hw_n, K, k));

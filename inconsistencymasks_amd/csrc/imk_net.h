@@ -267,6 +267,10 @@ inline int run_conv_pre_pair(Ctx &c, int pre, int c3, int c1) {
         if (!imk_conv_can_chain(plain, l2.cout)) return IMK_EUNSUPPORTED;
     }
     if (!imk_conv_can_prestage(a, lp.lmode, lp.cin, lp.cout)) return IMK_EUNSUPPORTED;
+#ifdef IMK_PRE_DEBUG
+    a.out = c.act(c3);                              // probe build: first-stage dumps land in the (otherwise unused) d.c3 / d.ca tensors
+    a.mask = c.act(pre);
+#endif
     a.pre_wpk = c.wfwd(pre);
     a.pre_bias = c.params + lp.off_b;
     a.pre_sc = c.bn_scale(lp.bn_after); a.pre_sh = c.bn_shift(lp.bn_after);
