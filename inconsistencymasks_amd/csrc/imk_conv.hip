@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ImkConvArgs a, ImkConvGe
 // (+ slack: its transposed reads reach 16 bytes past a pixel); at least the fused 3x3 weight gradient's final reduction
 constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
     size_t b = (size_t)18 * 18 * imk_lds_pitch(nc8) * 16 + (8 * 16 + 4 * 2 * 16) * sizeof(float) + 1024 +
-               (wg ? (size_t)(wg == 3 ? 18 * 18 : 256) * ((pair ? 1 : 2) | 1) * 16 + 64 : 0);
+               ((wg && wg != 4) ? (size_t)(wg == 3 ? 18 * 18 : 256) * ((pair ? 1 : 2) | 1) * 16 + 64 : 0);
     if (wg == 3 && b < 4 * 5 * 256 * sizeof(float)) b = 4 * 5 * 256 * sizeof(float);
     return (b + 15) & ~(size_t)15;
 }
@@ -452,6 +452,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     static_assert(WG != 1 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_MASK && !DYSTAT && FULL), "fused wgrad: 1x1 dgrad behind a BatchNorm");
     static_assert(WG != 2 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 1x1 dgrad in front of a BatchNorm");
     static_assert(WG != 3 || (LM == LM_RAW && CHAIN == 0 && EPI == EP_PLAIN && DYSTAT && FULL), "fused wgrad: 3x3 dgrad in front of a BatchNorm");
+    // WG = 4 (round 4): no weight gradient -- the 1x1 dgrad that produces the gradient of an upsample + add tensor also emits its 2x2
+    // sums (= the gradient of the lower block's BatchNorm output) with their BatchNorm-backward statistics (ImkConvArgs::sum2_out)
+    static_assert(WG != 4 || (LM == LM_BNBWD && CHAIN == 0 && EPI == EP_PLAIN && !DYSTAT && FULL && PRE == 0), "2x2-sum epilogue: 1x1 dgrad of a decoder's first conv");
     constexpr int P = PAIR ? 2 : 4;             // MFMA column blocks per wave: 4 tile rows, one or two per block
     constexpr int PS = imk_lds_pitch(NC8);      // pixel stride in 16-byte chunks (imk_stage.h)
     constexpr int NCI = PRE ? PRE : NC8;        // chunks per pixel of the STAGED tensor (PRE: the 1x1's input)
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias2[r] = (co0 + r < a.cout2) ? a.bias2[co0 + r] : 0.f;
     }
-    const bool want_stats = DYSTAT || ((EPI == EP_RELU) && a.stats_partial);
+    const bool want_stats = DYSTAT || WG == 4 || ((EPI == EP_RELU) && a.stats_partial);
     // PRE: the 1x1's weight fragment (one k-step: its input has at most 16 channels), its constants in LDS, and the pixels
     // this lane's accumulator rows belong to in each of the wave's NJ MFMAs (pair layout: 2 x 16 pixels per MFMA)
     constexpr int NJ = PAIR ? 3 : 6;            // 4 waves x NJ x (32 | 16) = 384 >= 18 x 18 pixels
@@ -731,6 +734,20 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 else zq[p] = *reinterpret_cast<const f16x4 *>(b_zq + o1l[p]);
             }
         }
+        // WG = 4: the lower block's BatchNorm input at this lane's 2x2 window (tile rows 2 q, 2 q + 1 -> low-res row q of the tile)
+        constexpr int NQ = PAIR ? P : P / 2;          // windows (in y) per lane
+        f16x4 zlo[WG == 4 ? NQ : 1];
+        unsigned olo[WG == 4 ? NQ : 1];
+        const char *b_lo = nullptr;
+        if constexpr (WG == 4) {
+            const char *bz = pix_base(a.sum2_z, tc.b, H >> 1, W >> 1, tc.ty0 >> 1, tc.tx0 >> 1, cso_b);
+            b_lo = pix_base(a.sum2_out, tc.b, H >> 1, W >> 1, tc.ty0 >> 1, tc.tx0 >> 1, cso_b);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                olo[q] = (unsigned)((wave * 2 + q) * (W >> 1) + (n >> 1)) * cso_b + co0 * 2;
+                zlo[q] = *reinterpret_cast<const f16x4 *>(bz + olo[q]);
+            }
+        }
         int next;
         PTile tn;
         int tk_new = 0;
@@ -870,6 +887,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 }
             }
         } else {
+            float hsum[WG == 4 ? P : 1][4];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 f16x4 v;
@@ -888,9 +906,31 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                     if (DYSTAT) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * (float)zq[p][r]; }
-                    } else if (want_stats) {
+                    } else if (WG != 4 && want_stats) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; s1[r] += f; s2[r] += f * f; }
+                    }
+                }
+                if constexpr (WG == 4) {
+                    // 2x2 sums of the rounded outputs, (v00 + v01) + (v10 + v11) in fp32 like bn_bwd_prep_kernel<2>: the left / right
+                    // neighbour is lane ^ 1; the row below is the other tile row of the pair (lane ^ 32) or the next accumulator block
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)v[r]; hsum[p][r] = f + __shfl_xor(f, 1, 64); }
+                }
+            }
+            if constexpr (WG == 4) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f16x4 d;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float tot = PAIR ? hsum[q][r] + __shfl_xor(hsum[q][r], 32, 64) : hsum[2 * q][r] + hsum[2 * q + 1][r];
+                        d[r] = (f16)tot;
+                    }
+                    if ((n & 1) == 0 && (!PAIR || set == 0)) {      // one lane per window stores and counts
+                        *reinterpret_cast<f16x4 *>(const_cast<char *>(b_lo) + olo[q]) = d;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)d[r]; s1[r] += f; s2[r] += f * (float)zlo[q][r]; }
                     }
                 }
             }
@@ -1947,6 +1987,16 @@ static int launch_conv_pipe_v(const ImkConvArgs &a, hipStream_t stream) {
 #undef IMK_PIPE_FWD
     }
     if (a.wpk2) return IMK_EUNSUPPORTED;
+    if (a.sum2_out) {        // 1x1 dgrad + the 2x2 sums of its output with their BatchNorm-backward statistics (imk_conv_can_sum2)
+        if constexpr (FULL) {
+            if (a.wg_partial || a.ksize != 1 || a.x.lmode != LM_BNBWD || a.epi != EP_PLAIN || !a.sum2_z || !a.stats_partial || a.dystat_z ||
+                (a.H & 1) || (a.W & 1))
+                return IMK_EUNSUPPORTED;
+            return launch_conv_pipe_k<LM_BNBWD, NC8, 0, PAIR, EP_PLAIN, false, true, 4>(a, stream);
+        } else {
+            return IMK_EUNSUPPORTED;
+        }
+    }
     if (a.wg_partial) {      // dgrad + weight gradient of a 1x1 conv in one launch (callers check imk_conv_can_fuse_wgrad)
         if constexpr (FULL) {
             const bool dys = a.dystat_z && a.stats_partial;
@@ -2198,6 +2248,18 @@ bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
     return (a.H % 16 == 0) && (a.W % TW == 0) && all_ch && (pair ? a.cs_out == 8 : true);
 }
 int imk_conv_fused_wgrad_rows_max() { return 256 * 8; }
+
+// Can this 1x1 dgrad launch also emit the 2x2 sums of its output (ImkConvArgs::sum2_out)?  The pipelined kernel, full tiles, every
+// lane owning real channels -- what launch_conv_pipe_any would pick for it.
+bool imk_conv_can_sum2(const ImkConvArgs &a) {
+    static const bool off = []() { const char *e = getenv("IMK_FUSE_SUM2"); return e && e[0] == '0'; }();
+    if (off || !pipe_enabled() || !pipe_fits(a) || a.wpk2 || a.wg_partial) return false;
+    if (a.ksize != 1 || a.x.lmode != LM_BNBWD || a.epi != EP_PLAIN || (a.dystat_z && a.stats_partial)) return false;
+    if (a.x.cs_in > 16 || a.cout > 16) return false;
+    const bool pair = pair_enabled() && a.cout <= 8;
+    const bool all_ch = pair ? a.cs_out == 8 : a.cs_out == 16;
+    return (a.H % 16 == 0) && (a.W % TW == 0) && all_ch;
+}
 
 static bool g_use_pipe = true;   // IMK_CONV_PIPE=0 in the environment falls back to the per-tile kernel (A/B runs)
 

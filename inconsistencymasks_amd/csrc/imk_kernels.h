@@ -76,6 +76,13 @@ struct ImkConvArgs {
     // second form (the U-Net's output layer: 1x1 conv on a BatchNorm output, dgrad = LM_RAW / EP_PLAIN with the BN-gradient
     // statistics): x = fp16(dystat_z * wg_sc + wg_sh), the BatchNorm being applied to the transposed LDS reads
     const float *wg_sc, *wg_sh;
+    // optional, dgrad of a decoder block's Conv1x1 on upsample + skip (LM_BNBWD, EP_PLAIN, full tiles): the output is the gradient of
+    // the upsample + add tensor, whose 2x2 sums are the gradient of the lower block's BatchNorm output (UpSampling2D's backward,
+    // unet.py:33).  The launch then also writes those sums to sum2_out [B,H/2,W/2,cs_out] and their BatchNorm-backward statistics
+    // against sum2_z (that BatchNorm's input, same shape) into stats_partial / stats_rows -- the "assemble dy" pass of that
+    // BatchNorm (bn_bwd_prep_kernel<2>) disappears.  See imk_conv_can_sum2.
+    f16 *sum2_out;
+    const f16 *sum2_z;
     // optional (forward launches without statistics, i.e. inference): IMK_SCHED_BYTES of zeroed tile counters, one per group of the
     // persistent walk -- the workgroups then TAKE their tiles (imk_stage.h: ImkWalk, dynamic form) instead of striding over them
     unsigned *sched;
@@ -90,6 +97,7 @@ inline double imk_conv_flops(const ImkConvArgs &a) {
     return f;
 }
 bool imk_conv_can_fuse_wgrad(const ImkConvArgs &dgrad_args);
+bool imk_conv_can_sum2(const ImkConvArgs &dgrad_args);        // this dgrad launch can also emit the 2x2 sums of its output (ImkConvArgs::sum2_out)
 // GEMM-class kernel for the wide layers (imk_gemm.hip): which launches it takes, its launcher, its statistics rows
 bool imk_conv_gemm_ok(const ImkConvArgs &a);
 int imk_launch_conv_gemm(const ImkConvArgs &a, hipStream_t stream);

@@ -129,6 +129,9 @@ inline void make_ws_layers(const imk_unet_plan *p, int B, int mode, Ws &w, Take 
             w.L[i].n_bwd_rows = imk_bn_prep_blocks(B, d.h, d.w, cs);
             const int conv_rows = B * imk_cdiv(d.h, 8) * imk_cdiv(d.w, 16);   // most rows a dgrad epilogue can write
             if (conv_rows > w.L[i].n_bwd_rows) w.L[i].n_bwd_rows = conv_rows;
+            // ... or the persistent 1x1 dgrad one level up, when it assembles this BatchNorm's dy (ImkConvArgs::sum2_out): one row per workgroup
+            const int up_rows = std::min(imk_conv_fused_wgrad_rows_max(), B * imk_cdiv(2 * d.h, 16) * imk_cdiv(2 * d.w, 16));
+            if (up_rows > w.L[i].n_bwd_rows) w.L[i].n_bwd_rows = up_rows;
             w.L[i].bwd_partial = take((size_t)w.L[i].n_bwd_rows * 2 * cs * sizeof(float));
             w.L[i].coef = take(3 * (size_t)cs * sizeof(float));
             w.L[i].dy = take(px * cs * 2);
@@ -306,6 +309,10 @@ struct Bwd {
     bool used_side[imk_unet_plan::MAX_SIDE] = {};
 
     int dy_rows[64] = {};   // per BN: statistics rows written by the kernel that produced dy (0 = none, run the prep pass)
+    // The BatchNorm whose output gradient is the 2x2 sum of the NEXT wgrad_dgrad call's output (a decoder's first conv: its dgrad
+    // yields the gradient of upsample + add): where the pipelined kernel takes that dgrad it assembles the sums and their
+    // statistics itself (ImkConvArgs::sum2_out) and bn_bwd(mode 2) skips its pass.  Consumed (reset) by that call.
+    int sum2_bn = -1;
 
     // Where the pre-activation gradient of `conv` comes from: convs that feed a BatchNorm get it on load from that
     // BN's (dy, z, coefficients); the 3x3 convs get the materialised, ReLU-masked dgrad output of the following 1x1.
@@ -346,12 +353,22 @@ struct Bwd {
         }
         return IMK_OK;
     }
-    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+    int dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1, int s2_bn = -1) {
         ImkConvArgs a{};
         int rows = 0;
         dgrad_args(conv, dst, mask, stat_bn, &rows, a);
+        bool s2 = false;
+        if (s2_bn >= 0 && stat_bn < 0 && !mask) {
+            a.sum2_out = c.dy(s2_bn);
+            a.sum2_z = c.act(c.p->layers[s2_bn].producer);
+            a.stats_partial = reinterpret_cast<float *>(c.base + c.ws.L[s2_bn].bwd_partial);
+            a.stats_rows = &rows;
+            s2 = imk_conv_can_sum2(a);
+            if (!s2) { a.sum2_out = nullptr; a.sum2_z = nullptr; a.stats_partial = nullptr; a.stats_rows = nullptr; }
+        }
         int rc = imk_launch_conv(a, c.stream);
         if (rc) return rc;
+        if (s2) return dgrad_done(s2_bn, rows);
         return dgrad_done(stat_bn, rows);
     }
     void wgrad_args(int conv, const f16 *dA_override, ImkWgradArgs &a) const {
@@ -449,6 +466,8 @@ struct Bwd {
     // (dgrad and wgrad blocks side by side in one grid) was measured for the deep layers: no gain (1.451 vs 1.452 ms per
     // step) -- the common LDS footprint of the fused kernel leaves one workgroup per CU.
     int wgrad_dgrad(int conv, f16 *dst, const f16 *mask, int stat_bn = -1) {
+        const int s2_bn = sum2_bn;
+        sum2_bn = -1;
         // A 1x1 conv whose forward input is the tensor its dgrad masks with (Conv3x3+ReLU -> Conv1x1): the pipelined dgrad
         // kernel has both operands of the weight gradient in LDS and produces it on the side (imk_conv_can_fuse_wgrad) --
         // no weight-gradient launch, no second read of dy, z and x.
@@ -505,13 +524,13 @@ struct Bwd {
         // same at the lower levels changes nothing).  IMK_FORK_LATE = highest level released late (-1: none).
         static const int late_res = []() { const char *e = getenv("IMK_FORK_LATE"); return e ? atoi(e) : 0; }();
         if (l.res <= late_res) {
-            int rc = dgrad(conv, dst, mask, stat_bn);
+            int rc = dgrad(conv, dst, mask, stat_bn, s2_bn);
             if (rc) return rc;
             return wgrad(conv);
         }
         int rc = wgrad(conv);
         if (rc) return rc;
-        return dgrad(conv, dst, mask, stat_bn);
+        return dgrad(conv, dst, mask, stat_bn, s2_bn);
     }
     // all layers' partials -> gradients (2 launches), then join the side stream back into the main one
     int finish_wgrads() {
@@ -543,7 +562,8 @@ struct Bwd {
         const float *save = reinterpret_cast<const float *>(c.base + lw.save);
         const f16 *z = c.act(prod);
         int rows = dy_rows[bn];
-        if (mode != 0 || rows == 0) {
+        // mode 2 with rows: the dgrad that produced the upsampled branch's gradient has assembled dy and its statistics (sum2_bn)
+        if (mode == 1 || rows == 0) {
             int rc = imk_launch_bn_bwd_prep(mode, mode == 0 ? c.dy(bn) : g_direct, g_other, z, c.bn_scale(bn), c.bn_shift(bn),
                                             c.dy(bn), partial, c.B, d.h, d.w, cs, c.stream, g_other_cs);
             if (rc) return rc;

@@ -508,6 +508,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.wgrad_dgrad(t.d_c1[j], c.dA(t.d_c3[j]), c.act(t.d_c3[j])));
         OK(b.wgrad_dgrad(t.d_c3[j], c.dy(t.d_bna[j]), nullptr, t.d_bna[j]));
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
+        b.sum2_bn = j > 0 ? t.d_bnb[j - 1] : t.b_bn;     // dU's 2x2 sums = dy of the block below: assembled by this dgrad where it can
         OK(b.wgrad_dgrad(t.d_ca[j], dU, nullptr));
         OK(b.flush_wgrads());   // the block's weight gradients (and the head's, for the first block) -> side stream
         OK(loss_on_side());
