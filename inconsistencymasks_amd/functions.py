@@ -108,15 +108,21 @@ def _pool():
 # training.  Writers flush before they return (callers list their output directories); everything is flushed at exit.
 _WRITE_POOL = None
 _PENDING = []
+_PENDING_LOCK = __import__("threading").Lock()      # candidates training on threads (im_driver) queue writes concurrently
 
 
 def write_png_async(path, arr):
+    with _PENDING_LOCK:
+        _ensure_write_pool()
+        _PENDING.append(_WRITE_POOL.submit(write_png, path, arr))
+
+
+def _ensure_write_pool():
     global _WRITE_POOL
     if _WRITE_POOL is None:
         import atexit
         _WRITE_POOL = ThreadPoolExecutor(max_workers=_IO_THREADS)
         atexit.register(_flush_at_exit)
-    _PENDING.append(_WRITE_POOL.submit(write_png, path, arr))
 
 
 def _flush_at_exit():
@@ -134,7 +140,8 @@ def _flush_at_exit():
 
 def flush_writes():
     """wait for every queued PNG write (re-raising the first failure)"""
-    pending, _PENDING[:] = list(_PENDING), []
+    with _PENDING_LOCK:      # (candidates training on threads queue writes concurrently)
+        pending, _PENDING[:] = list(_PENDING), []
     for f in pending:
         f.result()
 
@@ -723,6 +730,17 @@ def load_model(path, custom_objects=None, device="cuda"):
 
 
 _VAL_CACHE = {}   # (directories, file list) -> decoded validation set on the device: the monitor runs once per epoch
+# Candidates of a generation may train side by side on threads with a stream each (im_driver.run, IM_PARALLEL_CANDIDATES): the
+# shared caches are filled under a lock, and a filled entry is published only once its uploads have completed on the filling
+# thread's stream (another thread reads it on ITS stream).
+import threading as _threading
+_CACHE_LOCK = _threading.RLock()
+
+
+def _uploaded(*tensors):
+    torch.cuda.current_stream().synchronize()
+    return tensors
+
 
 # Decoded benchmark sets (images + ground truth of the val / test / unlabeled splits) stay on the device across the
 # candidates of a generation: every candidate is evaluated on the same three directories (functions.py:221-226), and
@@ -738,19 +756,21 @@ def _decoded_set(pool, dirs_and_channels, names):
         st = [os.stat(os.path.join(d, n)) for n in names]
         return (d, tuple(names), sum(x.st_size for x in st), max((x.st_mtime_ns for x in st), default=0))
     key = tuple((sig(d), c) for d, c in dirs_and_channels)
-    hit = _DECODE_CACHE.get(key)
-    if hit is not None:
-        return hit
-    out = []
-    for d, c in dirs_and_channels:
-        arrs = list(pool.map(lambda n: read_png(os.path.join(d, n), c), names))
-        out.append(torch.from_numpy(np.stack(arrs, 0)).cuda())
-    nbytes = sum(t.numel() for t in out)
-    if 0 < nbytes <= _DECODE_CACHE_BYTES:
-        while _DECODE_CACHE and sum(sum(t.numel() for t in v) for v in _DECODE_CACHE.values()) + nbytes > _DECODE_CACHE_BYTES:
-            _DECODE_CACHE.pop(next(iter(_DECODE_CACHE)))
-        _DECODE_CACHE[key] = out
-    return out
+    with _CACHE_LOCK:       # (candidates on threads: one decodes, the others wait for it instead of decoding the same files again)
+        hit = _DECODE_CACHE.get(key)
+        if hit is not None:
+            return hit
+        out = []
+        for d, c in dirs_and_channels:
+            arrs = list(pool.map(lambda n: read_png(os.path.join(d, n), c), names))
+            out.append(torch.from_numpy(np.stack(arrs, 0)).cuda())
+        _uploaded()
+        nbytes = sum(t.numel() for t in out)
+        if 0 < nbytes <= _DECODE_CACHE_BYTES:
+            while _DECODE_CACHE and sum(sum(t.numel() for t in v) for v in _DECODE_CACHE.values()) + nbytes > _DECODE_CACHE_BYTES:
+                _DECODE_CACHE.pop(next(iter(_DECODE_CACHE)))
+            _DECODE_CACHE[key] = out
+        return out
 
 
 def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
@@ -758,13 +778,14 @@ def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
     val_binary_io_u monitor of functions.py:216-217); pixel counts from imk_eval_binary."""
     files = sorted(glob.glob(os.path.join(images_dir, "*.png")))
     key = (images_dir, masks_dir, c, tuple(files))
-    if key not in _VAL_CACHE:
-        _VAL_CACHE.clear()
-        with _pool() as pool:
-            items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), files))
-        _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
-                           torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda())
-    xs, ys = _VAL_CACHE[key]
+    with _CACHE_LOCK:
+        if key not in _VAL_CACHE:
+            _VAL_CACHE.clear()
+            with _pool() as pool:
+                items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), files))
+            _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                                        torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda())
+        xs, ys = _VAL_CACHE[key]
     inter = union = 0
     for i in range(0, len(files), batch):
         _, cnt = _ev.eval_binary(model.predict_device(xs[i:i + batch]), ys[i:i + batch], 0.5, True, want_pred=False)
@@ -937,13 +958,14 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
     def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_mean_io_u', mode='max')
         metric = MeanIoU(n_classes)
         key = ("multi", val_images_dir, c, tuple(val_files))
-        if key not in _VAL_CACHE:      # the validation set is decoded once and stays on the device over the epochs
-            _VAL_CACHE.clear()
-            with _pool() as pool:
-                items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files))
-            _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
-                               torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
-        xs, ys = _VAL_CACHE[key]
+        with _CACHE_LOCK:
+            if key not in _VAL_CACHE:      # the validation set is decoded once and stays on the device over the epochs
+                _VAL_CACHE.clear()
+                with _pool() as pool:
+                    items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files))
+                _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                                            torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
+            xs, ys = _VAL_CACHE[key]
         for i in range(0, len(val_files), BATCH_SIZE):      # per-batch IoU, averaged over the batches (functions.py:82-90)
             metric.update_state(ys[i:i + BATCH_SIZE], model.predict_device(xs[i:i + BATCH_SIZE]))
         v = metric.result()
@@ -1238,13 +1260,14 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
 
     def on_epoch_end(ep, loss):      # ModelCheckpoint(monitor='val_loss', mode='min'): Keras' sample-weighted mean of the mse
         key = ("hela", val_images_dir, c, tuple(val_files))
-        if key not in _VAL_CACHE:
-            _VAL_CACHE.clear()
-            with _pool() as pool:
-                items = list(pool.map(lambda p: parse_image_hela(p, c), val_files))
-            _VAL_CACHE[key] = (torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
-                               torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
-        xs, ys = _VAL_CACHE[key]
+        with _CACHE_LOCK:
+            if key not in _VAL_CACHE:
+                _VAL_CACHE.clear()
+                with _pool() as pool:
+                    items = list(pool.map(lambda p: parse_image_hela(p, c), val_files))
+                _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
+                                            torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
+            xs, ys = _VAL_CACHE[key]
         sq, n = 0.0, 0
         for i in range(0, len(val_files), BATCH_SIZE):
             y = ys[i:i + BATCH_SIZE]

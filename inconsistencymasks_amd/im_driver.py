@@ -108,7 +108,7 @@ def _ints(name, default):
     return [int(x) for x in v.split(",")] if v else default
 
 
-def run(dataset, approach="IM"):
+def run(dataset, approach="IM", parallel_candidates=None):
     ds = DATASETS[dataset]
     S = F.config[ds["section"]]
     H, W, C = int(S["IMAGE_HEIGHT"]), int(S["IMAGE_WIDTH"]), int(S["IMAGE_CHANNELS"])
@@ -190,12 +190,13 @@ def run(dataset, approach="IM"):
                 train_dir = os.path.join(unl, "brightfield" if ds["kind"] == "hela" else "images")
                 steps = max(len(os.listdir(train_dir)) // batch // world, 1)
 
-                rows = []
-                for i in _ints("IM_CANDIDATES", [0, 1, 2, 3, 4]):
+                def train_candidate(i, side_by_side=False):
                     name_i = f"{modelname}_{i}"
                     h5 = os.path.join(model_dir, name_i + ".h5")
                     preds = [os.path.join(base, f"{k}_predictions", approach, name_i) for k in ("val", "test", "train_unlabeled")]
                     model = get_unet(H, W, C, K, alpha, actifu, actifu_out, seed=1000 * runid + 100 * gen + i)
+                    if side_by_side:      # the other candidates' streams fill this one's gaps: no side stream of its own (results identical)
+                        model.debug(single_stream=True)
                     if ds["kind"] == "isic":
                         res = F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
@@ -208,9 +209,37 @@ def run(dataset, approach="IM"):
                     else:
                         res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
                                            P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
-                    rows.append((name_i,) + tuple(res))
-                    tick(f"candidate {i}: training + 3 benchmarks")
                     del model
+                    return (name_i,) + tuple(res)
+
+                # The reference trains the generation's candidates one after the other (ISIC_2018/09_ISIC_2018_IM.py:90).  They are
+                # independent (own seed, own files), and one model's training step leaves most of the chip idle in its deep levels:
+                # IM_PARALLEL_CANDIDATES=k (or parallel_candidates=k) trains k of them side by side, one host thread and one stream
+                # each, without their own side streams -- 3 candidates interleaved reach 1.58x the model-steps per second of one
+                # (tests/gpu_probe/concurrent_candidates.py).  Every candidate computes exactly what it computes alone: the CSVs and
+                # checkpoints equal the sequential run's.  One rank only (collectives from several threads would not line up).
+                cands = _ints("IM_CANDIDATES", [0, 1, 2, 3, 4])
+                par = parallel_candidates if parallel_candidates is not None else int(os.environ.get("IM_PARALLEL_CANDIDATES", "1"))
+                if world > 1 or len(cands) < 2:
+                    par = 1
+                if par > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    dev_index = torch.cuda.current_device()
+
+                    def worker(i):
+                        torch.cuda.set_device(dev_index)          # the current device is per thread
+                        with torch.cuda.stream(torch.cuda.Stream()):
+                            row = train_candidate(i, True)
+                            torch.cuda.current_stream().synchronize()
+                        return row
+                    with ThreadPoolExecutor(max_workers=par) as pool:
+                        rows = list(pool.map(worker, cands))
+                    tick(f"{len(cands)} candidates, {par} side by side: training + 3 benchmarks each")
+                else:
+                    rows = []
+                    for i in cands:
+                        rows.append(train_candidate(i))
+                        tick(f"candidate {i}: training + 3 benchmarks")
 
                 if rank == 0:
                     top = sorted(rows, key=lambda r: r[ds["rank"]], reverse=True)[:top_k]
