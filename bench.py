@@ -714,7 +714,8 @@ def run_config(args, config_name, alpha, env, primary):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
-            rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(fam)]
+            fams_t = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook (as frac_rocprof below)
+            rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(fams_t)]
             nl = sum(int(r["launches"]) for r in rows)
             if nl:
                 traffic = round(1e6 * sum(int(r["launches"]) * float(r["hbm_MB_per_launch_corrected(2*fetch+write)"]) for r in rows) / nl)

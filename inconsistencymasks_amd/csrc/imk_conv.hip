@@ -774,9 +774,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 const bool inside = py >= lo_y && py <= hi_y && px >= lo_x && px <= hi_x;
                 f16x4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f16 z = (f16)fmaxf(pa[r] + pb[r], 0.f);              // the 1x1's stored output
-                    w[r] = inside ? imk_affine1(z, psc[r], psh[r]) : (f16)0.f;      // two roundings, as the staged form (imk_common.h)
+                for (int r = 0; r < 4; r += 2) {
+                    const f16x2 z2 = {(f16)fmaxf(pa[r] + pb[r], 0.f), (f16)fmaxf(pa[r + 1] + pb[r + 1], 0.f)};   // the 1x1's stored output
+                    const f16x2 w2 = imk_affine2(z2, f32x2{psc[r], psc[r + 1]}, f32x2{psh[r], psh[r + 1]});      // two roundings, as the staged form (imk_common.h)
+                    w[r] = inside ? w2[0] : (f16)0.f;
+                    w[r + 1] = inside ? w2[1] : (f16)0.f;
                 }
                 if (pre_cb < NC8 * 8)
                     *reinterpret_cast<f16x4 *>(s_tile + (pre_pix[j] * PS + (pre_cb >> 3)) * 16 + (pre_cb & 7) * 2) = w;

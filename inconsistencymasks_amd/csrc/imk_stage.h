@@ -251,9 +251,10 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(s_aff[5 * cs + c8 * 8 + j], xin[3], acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f16 z = (f16)fmaxf(acc[j] + bias[j], 0.f);                                         // the stem's stored output
-            o[j] = imk_affine1(z, sc[j], sh[j]);
+        for (int j = 0; j < 8; j += 2) {
+            const f16x2 z2 = {(f16)fmaxf(acc[j] + bias[j], 0.f), (f16)fmaxf(acc[j + 1] + bias[j + 1], 0.f)};      // the stem's stored output
+            const f16x2 w2 = imk_affine2(z2, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]});
+            o[j] = w2[0]; o[j + 1] = w2[1];
         }
         return o;
     } else {
