@@ -4,7 +4,9 @@ Same function names, positional arguments, return values, output directory layou
 reference (file:line cited per function), so that the per-dataset `*_IM.py` drivers run unchanged from
 the user's point of view.  What differs is underneath: images are processed in batches on the GPU
 (ensemble forward + fused IM kernel, training step kernels), PNG I/O uses Pillow on a host thread pool
-(OpenCV is not available), and model files are safetensors (h5py/Keras are not available).
+(OpenCV is not available), and model files are safetensors under the reference's `.h5` names by default -- `load_model` also takes
+the reference's own Keras HDF5 checkpoints directly (keras_h5.py / h5lite.py: a pure-numpy HDF5 reader), and
+IMK_MODEL_FORMAT=keras_h5 makes `save_model` write Keras `save_weights` HDF5 files instead.
 
 Multi-GPU: if torch.distributed is initialised, every `create_pseudo_labels_im_*` call shards the
 sorted file list in contiguous blocks over the ranks (no data collective; one 3-number all-reduce for the
@@ -708,6 +710,12 @@ def fit(model, loader, steps_per_epoch, epochs, loss_kind, on_epoch_end=None, lr
 
 
 def save_model(model, path):
+    """ModelCheckpoint's model.save(path) (functions.py:217).  Default: safetensors (weights + geometry in the metadata) under the same
+    name; IMK_MODEL_FORMAT=keras_h5: an HDF5 file in Keras' save_weights layout, which `get_unet(...).load_weights(path)` restores in
+    TensorFlow and load_model below reads back."""
+    if os.environ.get("IMK_MODEL_FORMAT", "safetensors") == "keras_h5":
+        from .keras_h5 import save_keras_weights
+        return save_keras_weights(model, path)
     from safetensors.torch import save_file
     sd = {k: v.contiguous() for k, v in model.state_dict().items()}
     meta = {"h": str(model.plan.h), "w": str(model.plan.w), "c_in": str(model.plan.c_in),
@@ -716,7 +724,13 @@ def save_model(model, path):
 
 
 def load_model(path, custom_objects=None, device="cuda"):
-    """Counterpart of tf.keras.models.load_model(path, custom_objects=...) (ISIC_2018/09_ISIC_2018_IM.py:75)."""
+    """Counterpart of tf.keras.models.load_model(path, custom_objects=...) (ISIC_2018/09_ISIC_2018_IM.py:75).  Takes this package's
+    safetensors files and Keras HDF5 checkpoints of the reference's get_unet (full model, or weights-only written by save_model /
+    keras_h5.save_keras_weights); the optimizer state of a Keras file is ignored, like load_model(..., compile=False)."""
+    from . import h5lite
+    if h5lite.is_hdf5(path):
+        from .keras_h5 import load_keras_model
+        return load_keras_model(path, device=device)
     from safetensors import safe_open
     with safe_open(path, framework="pt") as f:
         meta = f.metadata()

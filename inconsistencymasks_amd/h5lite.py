@@ -1,0 +1,774 @@
+"""A small HDF5 reader and writer in pure Python / numpy -- enough of the container format to take the reference's Keras
+checkpoints (`*.h5` written by ModelCheckpoint / model.save: ISIC_2018/09_ISIC_2018_IM.py:74-76, functions.py:217) in
+DIRECTLY, and to hand trained weights back as a Keras `save_weights` file, without h5py or libhdf5 (neither is on the
+main interpreter of the target image).
+
+Follows the published "HDF5 File Format Specification" version 3.0, not any library's source.  Reads what h5py / libhdf5 1.8-1.14
+write with default settings (and what Keras therefore writes): superblock versions 0-3, version-1 and version-2 object
+headers, old-style groups (symbol table: B-tree v1 + local heap) and new-style groups with compact link storage,
+contiguous / compact / chunked (B-tree v1) dataset layouts with the deflate, shuffle and fletcher32 filters, fixed-point,
+floating-point, fixed- and variable-length string types (global heap), attribute messages version 1-3.  Anything else (dense
+link / attribute storage in fractal heaps, version-4 layouts, compound types, external files, references) raises
+H5Unsupported with the name of the feature, never returns wrong data.
+
+Pinned against files written by h5py 3.3.0 / libhdf5 1.10.6 (tests/golden/h5_*.h5, tools/make_h5_fixtures.py), and the
+writer against h5py reading its output (tests/test_cpu_h5lite.py).
+
+    f = h5lite.File(path)            # read-only
+    f["model_weights/conv2d/conv2d/kernel:0"][...]  -> numpy array        f.attrs["keras_version"]  -> str
+    for name in f["model_weights"]: ...                                     f["model_weights"].attrs["layer_names"] -> [bytes]
+
+    h5lite.write(path, tree)         # tree: nested dict  {"group": {"dataset": ndarray, ...}, ...};  attributes under the key
+                                     # h5lite.ATTRS of a group dict, or wrap a dataset as h5lite.Dataset(array, attrs)"""
+import struct
+import zlib
+
+import numpy as np
+
+SIG = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+ATTRS = "\x00attrs"
+
+
+class H5Error(ValueError):
+    pass
+
+
+class H5Unsupported(H5Error):
+    pass
+
+
+def is_hdf5(path):
+    """True if `path` starts with the HDF5 signature (at 0 or at a 512 * 2^k user-block boundary)"""
+    try:
+        with open(path, "rb") as fh:
+            off = 0
+            while True:
+                fh.seek(off)
+                s = fh.read(8)
+                if len(s) < 8:
+                    return False
+                if s == SIG:
+                    return True
+                off = 512 if off == 0 else off * 2
+                if off > (1 << 24):
+                    return False
+    except OSError:
+        return False
+
+
+# ======================================================================================================================= reader
+class _Buf:
+    """the file's bytes + the superblock's offset / length sizes"""
+
+    def __init__(self, data):
+        self.d = data
+        self.O = 8
+        self.L = 8
+        self.base = 0
+
+    def u(self, off, n):
+        if off < 0 or off + n > len(self.d):
+            raise H5Error(f"read of {n} bytes at {off} beyond the end of the file ({len(self.d)} bytes)")
+        return int.from_bytes(self.d[off:off + n], "little")
+
+    def off(self, p):
+        v = self.u(p, self.O)
+        return None if v == (1 << (8 * self.O)) - 1 else v + self.base
+
+    def len(self, p):
+        return self.u(p, self.L)
+
+
+class _Type:
+    """a decoded datatype message: numpy dtype for fixed / float / fixed string, or a variable-length string marker"""
+
+    def __init__(self, kind, size, dtype=None, utf8=False, pad=0):
+        self.kind, self.size, self.dtype, self.utf8, self.pad = kind, size, dtype, utf8, pad
+
+
+def _parse_type(b, p):
+    cv = b.u(p, 1)
+    cls, ver = cv & 15, cv >> 4
+    bits = b.u(p + 1, 3)
+    size = b.u(p + 4, 4)
+    if ver not in (1, 2, 3):
+        raise H5Unsupported(f"datatype message version {ver}")
+    if cls == 0:
+        order = ">" if bits & 1 else "<"
+        signed = bool(bits & 8)
+        if size not in (1, 2, 4, 8):
+            raise H5Unsupported(f"{size}-byte integer type")
+        return _Type("num", size, np.dtype(f"{order}{'i' if signed else 'u'}{size}"))
+    if cls == 1:
+        order = ">" if bits & 1 else "<"
+        if bits & 0x40:
+            raise H5Unsupported("VAX-endian floating point")
+        if size not in (2, 4, 8):
+            raise H5Unsupported(f"{size}-byte floating-point type")
+        return _Type("num", size, np.dtype(f"{order}f{size}"))
+    if cls == 3:
+        return _Type("str", size, np.dtype(f"S{size}"), utf8=((bits >> 4) & 15) == 1, pad=bits & 15)
+    if cls == 9:
+        if bits & 15 != 1:
+            raise H5Unsupported("variable-length sequence type (only variable-length strings are read)")
+        return _Type("vlen", size, None, utf8=((bits >> 8) & 15) == 1)
+    names = {2: "time", 4: "bitfield", 5: "opaque", 6: "compound", 7: "reference", 8: "enumeration", 10: "array"}
+    raise H5Unsupported(f"{names.get(cls, cls)} datatype")
+
+
+def _parse_space(b, p):
+    ver = b.u(p, 1)
+    rank = b.u(p + 1, 1)
+    if ver == 1:
+        q = p + 8
+    elif ver == 2:
+        if b.u(p + 3, 1) == 2:
+            return None                                   # null dataspace
+        q = p + 4
+    else:
+        raise H5Unsupported(f"dataspace message version {ver}")
+    return tuple(b.len(q + i * b.L) for i in range(rank))
+
+
+class _Header:
+    """the messages of one object header: [(type, flags, offset of the data, size)]"""
+
+    def __init__(self, b, addr):
+        self.b, self.addr, self.msgs = b, addr, []
+        if b.d[addr:addr + 4] == b"OHDR":
+            self._v2(addr)
+        else:
+            self._v1(addr)
+
+    def _v1(self, addr):
+        b = self.b
+        if b.u(addr, 1) != 1:
+            raise H5Error(f"object header at {addr}: version {b.u(addr, 1)}, expected 1")
+        n_msgs = b.u(addr + 2, 2)
+        blocks = [(addr + 16, b.u(addr + 8, 4))]
+        while blocks and len(self.msgs) < n_msgs:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and len(self.msgs) < n_msgs:
+                t, s, fl = b.u(p, 2), b.u(p + 2, 2), b.u(p + 4, 1)
+                self.msgs.append((t, fl, p + 8, s))
+                if t == 0x10:
+                    blocks.append((b.off(p + 8), b.len(p + 8 + b.O)))
+                p += 8 + s
+
+    def _v2(self, addr):
+        b = self.b
+        if b.u(addr + 4, 1) != 2:
+            raise H5Error(f"object header at {addr}: version {b.u(addr + 4, 1)}, expected 2")
+        fl = b.u(addr + 5, 1)
+        p = addr + 6
+        if fl & 0x20:
+            p += 16
+        if fl & 0x10:
+            p += 4
+        w = 1 << (fl & 3)
+        size0 = b.u(p, w)
+        p += w
+        track = bool(fl & 4)
+        blocks = [(p, size0)]
+        while blocks:
+            p, size = blocks.pop(0)
+            end = p + size                                 # chunk 0: messages end where the checksum starts
+            hdr = 4 + (2 if track else 0)
+            while p + hdr <= end:
+                t, s, mf = b.u(p, 1), b.u(p + 1, 2), b.u(p + 3, 1)
+                q = p + hdr
+                if t != 0:
+                    self.msgs.append((t, mf, q, s))
+                if t == 0x10:
+                    ca, cl = b.off(q), b.len(q + b.O)
+                    if b.d[ca:ca + 4] != b"OCHK":
+                        raise H5Error(f"object header continuation at {ca}: no OCHK signature")
+                    blocks.append((ca + 4, cl - 8))
+                p = q + s
+
+    def all(self, t):
+        return [(fl, p, s) for (tt, fl, p, s) in self.msgs if tt == t]
+
+    def one(self, t):
+        m = self.all(t)
+        return m[0] if m else None
+
+
+def _global_heap_object(b, addr, index):
+    if b.d[addr:addr + 4] != b"GCOL":
+        raise H5Error(f"no global heap collection at {addr}")
+    size = b.len(addr + 8)
+    p, end = addr + 8 + b.L, addr + size
+    while p + 8 + b.L <= end:
+        idx = b.u(p, 2)
+        n = b.len(p + 8)
+        if idx == 0:
+            break
+        if idx == index:
+            return bytes(b.d[p + 8 + b.L:p + 8 + b.L + n])
+        p += 8 + b.L + ((n + 7) & ~7)
+    raise H5Error(f"global heap object {index} not found in the collection at {addr}")
+
+
+def _decode(b, typ, shape, raw):
+    """raw bytes of `shape` elements of `typ` -> numpy array / python strings"""
+    n = int(np.prod(shape)) if shape else 1
+    if typ.kind == "vlen":
+        es = 4 + b.O + 4
+        out = []
+        for i in range(n):
+            e = raw[i * es:(i + 1) * es]
+            ln = int.from_bytes(e[:4], "little")
+            ha = int.from_bytes(e[4:4 + b.O], "little")
+            ix = int.from_bytes(e[4 + b.O:], "little")
+            s = b"" if (ln == 0 or ha == 0) else _global_heap_object(b, ha + b.base, ix)[:ln]
+            out.append(s.decode("utf-8", "replace") if typ.utf8 else s.decode("ascii", "replace"))
+        if shape == ():
+            return out[0]
+        a = np.empty(n, dtype=object)
+        a[:] = out
+        return a.reshape(shape)
+    a = np.frombuffer(raw, dtype=typ.dtype, count=n).reshape(shape)
+    if typ.kind == "str":
+        if shape == ():
+            v = bytes(a[()])
+            return v.decode("utf-8", "replace") if typ.utf8 else v
+        return a.copy()
+    if typ.dtype.byteorder == ">":
+        a = a.astype(typ.dtype.newbyteorder("<"))
+    return a[()] if shape == () else a.copy()
+
+
+def _parse_attribute(b, p):
+    ver = b.u(p, 1)
+    if ver not in (1, 2, 3):
+        raise H5Unsupported(f"attribute message version {ver}")
+    flags = b.u(p + 1, 1)
+    ns, ts, ss = b.u(p + 2, 2), b.u(p + 4, 2), b.u(p + 6, 2)
+    q = p + 8 + (1 if ver == 3 else 0)
+    pad = (lambda v: (v + 7) & ~7) if ver == 1 else (lambda v: v)
+    name = bytes(b.d[q:q + ns]).split(b"\0")[0].decode("utf-8")
+    q += pad(ns)
+    if ver >= 2 and flags & 3:
+        raise H5Unsupported(f"attribute {name!r}: shared datatype / dataspace")
+    typ = _parse_type(b, q)
+    q += pad(ts)
+    shape = _parse_space(b, q)
+    q += pad(ss)
+    if shape is None:
+        return name, None
+    n = int(np.prod(shape)) if shape else 1
+    es = typ.size if typ.kind != "vlen" else 4 + b.O + 4
+    return name, _decode(b, typ, shape, bytes(b.d[q:q + n * es]))
+
+
+class _Attrs(dict):
+    pass
+
+
+class _Node:
+    def __init__(self, b, addr, name):
+        self._b, self._addr, self.name = b, addr, name
+        self._h = _Header(b, addr)
+        self._attrs = None
+
+    @property
+    def attrs(self):
+        if self._attrs is None:
+            info = self._h.one(0x15)
+            if info is not None:
+                fl, p, _ = info
+                q = p + 2 + (2 if self._b.u(p + 1, 1) & 1 else 0)
+                if self._b.off(q) is not None:
+                    raise H5Unsupported(f"{self.name}: attributes in dense storage (fractal heap); re-save with the default "
+                                        "(earliest) library format")
+            a = _Attrs()
+            for fl, p, s in self._h.all(0x0C):
+                if fl & 2:
+                    raise H5Unsupported(f"{self.name}: shared attribute message")
+                k, v = _parse_attribute(self._b, p)
+                a[k] = v
+            self._attrs = a
+        return self._attrs
+
+
+class Dataset(_Node):
+    """read side: a dataset of an open File.  (For h5lite.write, Dataset(array, attrs) wraps an array with attributes.)"""
+
+    def __init__(self, *args, **kw):
+        if args and isinstance(args[0], _Buf):
+            super().__init__(*args)
+            b, h = self._b, self._h
+            m = h.one(0x03)
+            if m is None or m[0] & 2:
+                raise H5Unsupported(f"{self.name}: shared (committed) datatype")
+            self._type = _parse_type(b, m[1])
+            sp = h.one(0x01)
+            self.shape = _parse_space(b, sp[1]) if sp else ()
+            self.dtype = self._type.dtype if self._type.kind != "vlen" else np.dtype(object)
+        else:                                              # write side
+            self.data = np.asarray(args[0]) if not isinstance(args[0], (bytes, str)) else args[0]
+            self.wattrs = dict(args[1] if len(args) > 1 else kw.get("attrs") or {})
+
+    def _filters(self):
+        m = self._h.one(0x0B)
+        if m is None:
+            return []
+        b, p = self._b, m[1]
+        ver, n = b.u(p, 1), b.u(p + 1, 1)
+        out = []
+        q = p + (8 if ver == 1 else 2)
+        for _ in range(n):
+            fid = b.u(q, 2)
+            if ver == 1 or fid >= 256:
+                nl = b.u(q + 2, 2)
+                q += 2
+            else:
+                nl = 0
+            ncv = b.u(q + 4, 2)
+            q += 6
+            q += ((nl + 7) & ~7) if ver == 1 else nl
+            cd = [b.u(q + 4 * i, 4) for i in range(ncv)]
+            q += 4 * ncv
+            if ver == 1 and ncv & 1:
+                q += 4
+            out.append((fid, cd))
+        return out
+
+    def _unfilter(self, raw, mask, filters, esize):
+        for i in reversed(range(len(filters))):
+            fid, cd = filters[i]
+            if mask & (1 << i):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                es = cd[0] if cd else esize
+                n = len(raw) // es
+                a = np.frombuffer(raw[:n * es], np.uint8).reshape(es, n).T
+                raw = a.tobytes() + raw[n * es:]
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise H5Unsupported(f"{self.name}: filter {fid} (only deflate, shuffle and fletcher32 are read)")
+        return raw
+
+    def _chunks(self, addr, ndim):
+        """leaf entries of the chunk B-tree: (chunk size in bytes, filter mask, offsets, address)"""
+        b = self._b
+        if b.d[addr:addr + 4] != b"TREE" or b.u(addr + 4, 1) != 1:
+            raise H5Error(f"{self.name}: no chunk B-tree node at {addr}")
+        level, used = b.u(addr + 5, 1), b.u(addr + 6, 2)
+        ks = 8 + 8 * (ndim + 1)
+        p = addr + 8 + 2 * b.O
+        for i in range(used):
+            size, mask = b.u(p, 4), b.u(p + 4, 4)
+            offs = tuple(b.u(p + 8 + 8 * k, 8) for k in range(ndim))
+            child = b.off(p + ks)
+            if level == 0:
+                yield size, mask, offs, child
+            else:
+                yield from self._chunks(child, ndim)
+            p += ks + b.O
+
+    def read(self):
+        b, h, typ = self._b, self._h, self._type
+        if self.shape is None:
+            return None
+        n = int(np.prod(self.shape)) if self.shape else 1
+        es = typ.size if typ.kind != "vlen" else 4 + b.O + 4
+        m = h.one(0x08)
+        if m is None:
+            raise H5Error(f"{self.name}: no data layout message")
+        p = m[1]
+        ver = b.u(p, 1)
+        if ver in (1, 2):
+            rank, cls = b.u(p + 1, 1), b.u(p + 2, 1)
+            q = p + 8
+            if cls == 0:
+                q += 4 * rank
+                return _decode(b, typ, self.shape, bytes(b.d[q + 4:q + 4 + b.u(q, 4)]))
+            addr = b.off(q)
+            q += b.O
+            dims = [b.u(q + 4 * i, 4) for i in range(rank)]
+            if cls == 1:
+                raw = bytes(b.d[addr:addr + n * es]) if addr is not None else bytes(n * es)
+                return _decode(b, typ, self.shape, raw)
+            chunk, btree = tuple(dims[:-1]), addr
+        elif ver in (3, 4):                                 # version 4 differs only in how chunks are indexed
+            cls = b.u(p + 1, 1)
+            if cls == 0:
+                size = b.u(p + 2, 2)
+                return _decode(b, typ, self.shape, bytes(b.d[p + 4:p + 4 + size]))
+            if cls == 1:
+                addr = b.off(p + 2)
+                raw = bytes(b.d[addr:addr + n * es]) if (addr is not None and n) else bytes(n * es)
+                return _decode(b, typ, self.shape, raw)
+            if cls != 2 or ver == 4:
+                raise H5Unsupported(f"{self.name}: data layout class {cls} of a version-{ver} layout message (chunk indices other "
+                                    "than the version-1 B-tree, virtual datasets); re-save with the default library format")
+            rank = b.u(p + 2, 1)
+            btree = b.off(p + 3)
+            q = p + 3 + b.O
+            chunk = tuple(b.u(q + 4 * i, 4) for i in range(rank - 1))
+        else:
+            raise H5Unsupported(f"{self.name}: data layout message version {ver}")
+        # chunked
+        if typ.kind == "vlen":
+            raise H5Unsupported(f"{self.name}: chunked variable-length data")
+        out = np.zeros(self.shape, dtype=typ.dtype)
+        filters = self._filters()
+        if btree is not None and n:
+            nd = len(chunk)
+            for size, mask, offs, addr in self._chunks(btree, nd):
+                raw = self._unfilter(bytes(b.d[addr:addr + size]), mask, filters, es)
+                c = np.frombuffer(raw, dtype=typ.dtype, count=int(np.prod(chunk))).reshape(chunk)
+                sl = tuple(slice(o, min(o + cs, s)) for o, cs, s in zip(offs, chunk, self.shape))
+                out[sl] = c[tuple(slice(0, s.stop - s.start) for s in sl)]
+        if typ.dtype.byteorder == ">":
+            out = out.astype(typ.dtype.newbyteorder("<"))
+        return out
+
+    def __getitem__(self, key):
+        a = self.read()
+        return a if key is Ellipsis or key == () else a[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self.read())
+        return a.astype(dtype) if dtype is not None else a
+
+
+class Group(_Node):
+    def __init__(self, b, addr, name):
+        super().__init__(b, addr, name)
+        self._links = None
+
+    def _load(self):
+        if self._links is not None:
+            return self._links
+        b, links = self._b, {}
+        st = self._h.one(0x11)
+        if st is not None:
+            btree, heap = b.off(st[1]), b.off(st[1] + b.O)
+            if b.d[heap:heap + 4] != b"HEAP":
+                raise H5Error(f"{self.name}: no local heap at {heap}")
+            seg = b.off(heap + 8 + 2 * b.L)
+            self._walk(btree, seg, links)
+        else:
+            info = self._h.one(0x02)
+            if info is not None:
+                p = info[1]
+                q = p + 2 + (8 if b.u(p + 1, 1) & 1 else 0)
+                if b.off(q) is not None:
+                    raise H5Unsupported(f"{self.name}: links in dense storage (fractal heap: a group of more than 8 members "
+                                        "written with libver='latest'); re-save with the default library format")
+            for fl, p, s in self._h.all(0x06):
+                if b.u(p, 1) != 1:
+                    raise H5Unsupported(f"link message version {b.u(p, 1)}")
+                f = b.u(p + 1, 1)
+                q = p + 2
+                ltype = 0
+                if f & 8:
+                    ltype = b.u(q, 1)
+                    q += 1
+                if f & 4:
+                    q += 8
+                if f & 0x10:
+                    q += 1
+                w = 1 << (f & 3)
+                nl = b.u(q, w)
+                q += w
+                nm = bytes(b.d[q:q + nl]).decode("utf-8")
+                q += nl
+                if ltype != 0:
+                    continue                               # soft / external links are not followed
+                links[nm] = b.off(q)
+        self._links = links
+        return links
+
+    def _walk(self, addr, seg, links):
+        b = self._b
+        if b.d[addr:addr + 4] == b"SNOD":
+            n = b.u(addr + 6, 2)
+            p = addr + 8
+            es = 2 * b.O + 24
+            for i in range(n):
+                no = b.u(p, b.O)
+                oh = b.off(p + b.O)
+                ct = b.u(p + 2 * b.O, 4)
+                end = b.d.find(b"\0", seg + no)
+                nm = bytes(b.d[seg + no:end]).decode("utf-8")
+                if ct != 2:                                # 2 = symbolic link (no object header)
+                    links[nm] = oh
+                p += es
+            return
+        if b.d[addr:addr + 4] != b"TREE" or b.u(addr + 4, 1) != 0:
+            raise H5Error(f"{self.name}: neither a group B-tree node nor a symbol node at {addr}")
+        used = b.u(addr + 6, 2)
+        p = addr + 8 + 2 * b.O + b.L                       # skip key 0
+        for i in range(used):
+            self._walk(b.off(p), seg, links)
+            p += b.O + b.L
+
+    def keys(self):
+        return sorted(self._load())
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._load())
+
+    def __contains__(self, path):
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path):
+        node = self
+        for part in [s for s in path.split("/") if s]:
+            if not isinstance(node, Group):
+                raise KeyError(f"{node.name} is a dataset, not a group (looking up {path!r} in {self.name})")
+            links = node._load()
+            if part not in links:
+                raise KeyError(f"{part!r} not in {node.name} (members: {', '.join(sorted(links)[:12])}{' ...' if len(links) > 12 else ''})")
+            child = (node.name.rstrip("/") + "/" + part)
+            h = _Header(node._b, links[part])
+            is_group = h.one(0x11) is not None or h.one(0x02) is not None or (h.one(0x08) is None and h.one(0x03) is None)
+            node = Group(node._b, links[part], child) if is_group else Dataset(node._b, links[part], child)
+        return node
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def visit_datasets(self, prefix=""):
+        """every dataset below this group: (path relative to it, Dataset)"""
+        for k, v in self.items():
+            if isinstance(v, Group):
+                yield from v.visit_datasets(prefix + k + "/")
+            else:
+                yield prefix + k, v
+
+
+class File(Group):
+    def __init__(self, path):
+        with open(path, "rb") as fh:
+            data = fh.read()
+        self.path = path
+        off = 0
+        while data[off:off + 8] != SIG:
+            off = 512 if off == 0 else off * 2
+            if off + 8 > len(data):
+                raise H5Error(f"{path}: not an HDF5 file (no signature)")
+        b = _Buf(data)
+        ver = b.u(off + 8, 1)
+        if ver in (0, 1):
+            b.O, b.L = b.u(off + 13, 1), b.u(off + 14, 1)
+            p = off + 24 + (4 if ver == 1 else 0)
+            base = b.u(p, b.O)
+            b.base = base if base else off if off else 0
+            p += 4 * b.O                                   # base, free-space, end-of-file, driver-info addresses
+            root = b.off(p + b.O)                          # symbol table entry: link name offset, object header address
+        elif ver in (2, 3):
+            b.O, b.L = b.u(off + 9, 1), b.u(off + 10, 1)
+            base = b.u(off + 12, b.O)
+            b.base = base if base else off if off else 0
+            root = b.off(off + 12 + 3 * b.O)
+        else:
+            raise H5Unsupported(f"{path}: superblock version {ver}")
+        if b.O not in (4, 8) or b.L not in (4, 8):
+            raise H5Unsupported(f"{path}: {b.O}-byte offsets / {b.L}-byte lengths")
+        self.superblock_version = ver
+        super().__init__(b, root, "/")
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+# ======================================================================================================================= writer
+def _pad8(bs):
+    return bs + bytes(-len(bs) % 8)
+
+
+def _type_msg(a):
+    """datatype message for a numpy array / bytes scalar; returns (message bytes, element size)"""
+    if isinstance(a, (bytes, str)):
+        s = a.encode("utf-8") if isinstance(a, str) else a
+        n = max(len(s), 1)
+        utf8 = isinstance(a, str)
+        return struct.pack("<BBBBI", 0x13, ((1 if utf8 else 0) << 4) | 1, 0, 0, n), n    # class 3 (string), null-padded
+    dt = a.dtype
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, dt.itemsize), dt.itemsize        # null-padded ASCII
+    if dt.kind == "f":
+        props = {2: (0x0F, 10, 5, 0, 10, 15), 4: (31, 23, 8, 0, 23, 127), 8: (63, 52, 11, 0, 52, 1023)}[dt.itemsize]
+        sign, eloc, esize, mloc, msize, bias = props
+        return (struct.pack("<BBBBI", 0x11, 0x20, sign, 0, dt.itemsize)
+                + struct.pack("<HHBBBBI", 0, dt.itemsize * 8, eloc, esize, mloc, msize, bias)), dt.itemsize
+    if dt.kind in "iu":
+        return (struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0, 0, 0, dt.itemsize)
+                + struct.pack("<HH", 0, dt.itemsize * 8)), dt.itemsize
+    raise H5Unsupported(f"writing dtype {dt}")
+
+
+def _space_msg(shape):
+    if shape == ():
+        return struct.pack("<BBBB4x", 1, 0, 0, 0)
+    return struct.pack("<BBBB4x", 1, len(shape), 0, 0) + b"".join(struct.pack("<Q", s) for s in shape)
+
+
+def _norm(v):
+    """value -> (object for _type_msg, shape, raw bytes)"""
+    if isinstance(v, str):
+        s = v.encode("utf-8")
+        return v, (), s if s else b"\0"
+    if isinstance(v, bytes):
+        return v, (), v if v else b"\0"
+    if isinstance(v, (list, tuple)) and v and all(isinstance(x, (bytes, str)) for x in v):
+        v = np.array([x.encode("utf-8") if isinstance(x, str) else x for x in v])
+    a = np.asarray(v)
+    if a.dtype.kind == "U":
+        a = np.char.encode(a, "utf-8")
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8)
+    if a.dtype.kind == "S" and a.dtype.itemsize == 0:
+        a = a.astype("S1")
+    if a.dtype.byteorder == ">":
+        a = a.astype(a.dtype.newbyteorder("<"))
+    shape = a.shape                                        # (ascontiguousarray would turn a 0-d array into 1-d)
+    return a, shape, a.tobytes()
+
+
+def _attr_msg(name, value):
+    obj, shape, raw = _norm(value)
+    t, _ = _type_msg(obj)
+    s = _space_msg(shape)
+    nm = name.encode("utf-8") + b"\0"
+    body = struct.pack("<BBHHH", 1, 0, len(nm), len(t), len(s)) + _pad8(nm) + _pad8(t) + _pad8(s) + raw
+    if len(body) > 64000:
+        raise H5Error(f"attribute {name!r}: {len(body)} bytes do not fit an object-header message (64 KB); split it the way Keras "
+                      "does (name0, name1, ...)")
+    return 0x0C, body
+
+
+def _header(msgs):
+    """version-1 object header from [(type, body)]"""
+    out = b""
+    for t, body in msgs:
+        body = _pad8(body)
+        out += struct.pack("<HHB3x", t, len(body), 0) + body
+    return struct.pack("<BxHII4x", 1, len(msgs), 1, len(out)) + out
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray()
+
+    def alloc(self, n, align=8):
+        self.buf += bytes(-len(self.buf) % align)
+        p = len(self.buf)
+        self.buf += bytes(n)
+        return p
+
+    def put(self, bs, align=8):
+        p = self.alloc(len(bs), align)
+        self.buf[p:p + len(bs)] = bs
+        return p
+
+
+def _count(tree):
+    m = len([k for k in tree if k != ATTRS])
+    for k, v in tree.items():
+        if k != ATTRS and isinstance(v, dict):
+            m = max(m, _count(v))
+    return m
+
+
+def _write_group(w, tree, leaf_k, int_k):
+    """writes the members, then B-tree + heap + symbol node + the group's object header; returns the header's address"""
+    members = {}
+    for k, v in tree.items():
+        if k == ATTRS:
+            continue
+        if "/" in k or not k:
+            raise H5Error(f"member name {k!r}: nested paths go in nested dicts")
+        members[k] = (_write_group(w, v, leaf_k, int_k) if isinstance(v, dict) else _write_dataset(w, v))[0]
+    names = sorted(members, key=lambda s: s.encode("utf-8"))
+    # local heap: offset 0 = the empty string, then the names, each null-terminated and 8-aligned
+    heap, offs = bytearray(8), {}
+    for nm in names:
+        offs[nm] = len(heap)
+        heap += _pad8(nm.encode("utf-8") + b"\0")
+    seg = w.put(bytes(heap))
+    heap_addr = w.put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), 1, seg))      # free-list head 1 = none (H5HL_FREE_NULL)
+    # one symbol node (capacity 2 * leaf_k, chosen >= the largest group of the file)
+    snod = bytearray(b"SNOD" + struct.pack("<BxH", 1, len(names)))
+    for nm in names:
+        snod += struct.pack("<QQII16x", offs[nm], members[nm], 0, 0)
+    snod += bytes(8 + 2 * leaf_k * 40 - len(snod))
+    snod_addr = w.put(bytes(snod))
+    # B-tree: one level-0 node with one child; key 0 = "" (heap offset 0), key 1 = the largest name in the child
+    node = bytearray(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1 if names else 0, UNDEF, UNDEF))
+    node += struct.pack("<QQQ", 0, snod_addr, offs[names[-1]] if names else 0)
+    node += bytes(24 + (2 * int_k + 1) * 8 + 2 * int_k * 8 - len(node))
+    btree = w.put(bytes(node))
+    msgs = [(0x11, struct.pack("<QQ", btree, heap_addr))]
+    msgs += [_attr_msg(k, v) for k, v in (tree.get(ATTRS) or {}).items()]
+    return w.put(_header(msgs)), (btree, heap_addr)
+
+
+def _write_dataset(w, v):
+    attrs = {}
+    if isinstance(v, Dataset):
+        attrs, v = v.wattrs, v.data
+    obj, shape, raw = _norm(v)
+    t, es = _type_msg(obj)
+    n = int(np.prod(shape)) if shape else 1
+    addr = w.put(raw) if n else UNDEF
+    msgs = [(0x01, _space_msg(shape)), (0x03, t),
+            (0x05, struct.pack("<BBBB", 2, 2, 2, 0)),                    # fill value v2: late allocation, write if set, undefined
+            (0x08, struct.pack("<BBQQ", 3, 1, addr, n * es))]           # layout v3, contiguous
+    msgs += [_attr_msg(k, a) for k, a in attrs.items()]
+    return w.put(_header(msgs)), None
+
+
+def write(path, tree):
+    """Write `tree` (nested dicts of arrays / h5lite.Dataset; attributes under h5lite.ATTRS) as an HDF5 file: superblock
+    version 0, old-style groups, contiguous little-endian datasets, fixed-length string attributes -- the subset every
+    HDF5 library since 1.6 reads."""
+    leaf_k = max(4, (_count(tree) + 1) // 2)
+    int_k = 16
+    w = _Writer()
+    w.alloc(96)                                            # superblock v0 (56 bytes + the 40-byte root symbol table entry)
+    root, (btree, heap) = _write_group(w, tree, leaf_k, int_k)
+    eof = len(w.buf)
+    sb = SIG + struct.pack("<BBBxBBBxHHI", 0, 0, 0, 0, 8, 8, leaf_k, int_k, 0)
+    sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", btree, heap)      # root entry: cached symbol-table info
+    w.buf[0:len(sb)] = sb
+    with open(path, "wb") as fh:
+        fh.write(bytes(w.buf))
+
+
+# ============================================================================================================== Keras conventions
+def load_attr_list(group, name):
+    """Keras' load_attributes_from_hdf5_group: the attribute, or its chunks name0, name1, ... (attributes above 64 KB are split)"""
+    a = group.attrs
+    if name in a:
+        vals = list(np.asarray(a[name]).reshape(-1))
+    else:
+        vals, i = [], 0
+        while f"{name}{i}" in a:
+            vals += list(np.asarray(a[f"{name}{i}"]).reshape(-1))
+            i += 1
+    return [v.decode("utf-8") if isinstance(v, bytes) else str(v) for v in vals]

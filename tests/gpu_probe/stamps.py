@@ -32,9 +32,10 @@ ALPHA = float(os.environ.get("ALPHA", ALPHA))
 lib = _lib.lib
 ROWS, COLS = 4096, 16
 TUS = ("conv", "elem", "gemm", "bwd1", "wgemm", "headf")
-x = torch.randint(0, 256, (32, H, W, C), dtype=torch.uint8, device="cuda")
-y = ((torch.rand((32, H, W, K), device="cuda") > 0.7).to(torch.uint8) if LOSS == 0
-     else torch.randint(0, K, (32, H, W), dtype=torch.uint8, device="cuda"))
+BT = int(os.environ.get("B", 32))
+x = torch.randint(0, 256, (BT, H, W, C), dtype=torch.uint8, device="cuda")
+y = ((torch.rand((BT, H, W, K), device="cuda") > 0.7).to(torch.uint8) if LOSS == 0
+     else torch.randint(0, K, (BT, H, W), dtype=torch.uint8, device="cuda"))
 m = UNet(H, W, C, K, ALPHA, ACT, seed=3)
 for _ in range(5):
     m.train_step(x, y, LOSS, 3e-3, 1e-4)

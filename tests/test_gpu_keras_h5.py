@@ -1,0 +1,55 @@
+"""functions.load_model / save_model on Keras HDF5 checkpoints (ISIC_2018/09_ISIC_2018_IM.py:74-76): the file the
+HDF5 library wrote in Keras' full-model layout (tests/golden/h5_keras_full_model.h5) goes straight into the HIP path, and a
+trained model goes out as a Keras save_weights file and comes back bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def test_load_model_takes_a_keras_full_model_checkpoint():
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd import keras_h5 as K
+    from oracle import unet_oracle as U
+    path = os.path.join(GOLD, "h5_keras_full_model.h5")
+    m = F.load_model(path, custom_objects={"dice_loss": None})
+    assert (m.plan.h, m.plan.w, m.plan.c_in, m.plan.n_out, m.plan.alpha, m.plan.act_out) == (32, 32, 3, 2, 0.25, "softmax")
+    sd, _ = K.state_dict_from_keras_h5(path)
+    mine = m.state_dict()
+    assert set(mine) == set(sd) and all(np.array_equal(mine[k].numpy(), sd[k]) for k in sd)
+    x = np.random.default_rng(0).integers(0, 256, (4, 32, 32, 3), dtype=np.uint8)
+    got = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = U.forward({k: torch.from_numpy(v) for k, v in sd.items()}, x, 3, 2, 0.25, "softmax", emulate_fp16=True).numpy()
+    assert got.shape == ref.shape == (4, 32, 32, 2)
+    assert np.abs(got - ref).max() <= 3e-2                            # the tolerance of tests/test_gpu_unet.py
+
+
+def test_save_model_as_keras_weights_and_back(tmp_path, monkeypatch):
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd import h5lite as H
+    from inconsistencymasks_amd.unet import UNet
+    m = UNet(64, 96, 3, 1, 0.5, "sigmoid", seed=11)
+    x = torch.randint(0, 256, (8, 64, 96, 3), dtype=torch.uint8, device="cuda")
+    y = (torch.rand((8, 64, 96, 1), device="cuda") > 0.6).to(torch.uint8)
+    m.init_train_state()
+    for _ in range(3):                                                # moving statistics and weights away from their initial values
+        m.train_step(x, y, 0, 3e-3, 1e-4)
+    p_st, p_h5 = str(tmp_path / "a.h5"), str(tmp_path / "b.h5")
+    F.save_model(m, p_st)
+    monkeypatch.setenv("IMK_MODEL_FORMAT", "keras_h5")
+    F.save_model(m, p_h5)
+    assert not H.is_hdf5(p_st) and H.is_hdf5(p_h5)
+    f = H.File(p_h5)
+    assert H.load_attr_list(f, "layer_names")[:3] == ["conv2d", "batch_normalization", "conv2d_1"] and f.attrs["backend"] == b"tensorflow"
+    a, b = F.load_model(p_st), F.load_model(p_h5)
+    assert (b.plan.h, b.plan.w, b.plan.act_out) == (64, 96, "sigmoid")
+    assert torch.equal(a.params, b.params) and torch.equal(a.params, m.params)
+    assert torch.equal(a.predict_device(x), b.predict_device(x))
