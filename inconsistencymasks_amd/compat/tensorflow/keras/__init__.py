@@ -4,14 +4,18 @@ import types
 
 def _load_model(filepath, custom_objects=None, compile=True):
     """tf.keras.models.load_model(path, custom_objects=...) (ISIC_2018/09_ISIC_2018_IM.py:75; EvalNet files at
-    ISIC_2018/12_ISIC_2018_IM++.py): the safetensors metadata says which network the file holds."""
+    ISIC_2018/12_ISIC_2018_IM++.py): a Keras HDF5 checkpoint of get_unet goes to the HDF5 reader; otherwise the safetensors
+    metadata says which network the file holds."""
+    from inconsistencymasks_amd import h5lite
+    from inconsistencymasks_amd.functions import load_model
+    if h5lite.is_hdf5(filepath):
+        return load_model(filepath, custom_objects=custom_objects)
     from safetensors import safe_open
     with safe_open(filepath, framework="pt") as f:
         meta = f.metadata() or {}
     if meta.get("net") == "evalnet":
         from inconsistencymasks_amd.evalnet_functions import load_evalnet
         return load_evalnet(filepath)
-    from inconsistencymasks_amd.functions import load_model
     return load_model(filepath, custom_objects=custom_objects)
 
 

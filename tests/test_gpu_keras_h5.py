@@ -53,3 +53,33 @@ def test_save_model_as_keras_weights_and_back(tmp_path, monkeypatch):
     assert (b.plan.h, b.plan.w, b.plan.act_out) == (64, 96, "sigmoid")
     assert torch.equal(a.params, b.params) and torch.equal(a.params, m.params)
     assert torch.equal(a.predict_device(x), b.predict_device(x))
+
+
+def test_isic_generation_with_hdf5_model_files(tmp_path):
+    """IMK_MODEL_FORMAT=keras_h5: the subset baseline and one IM generation write, rename and reload their models as real HDF5
+    files (ModelCheckpoint -> load_model -> top-K rename, ISIC_2018/09_ISIC_2018_IM.py:74-76, 131-135); the results agree with the
+    default format's to the last digit (same seeds, and the weights survive either container bit for bit)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_driver import CONFIG, SETUP
+    from inconsistencymasks_amd import h5lite as H
+    rows = {}
+    for fmt in ("safetensors", "keras_h5"):
+        work = tmp_path / fmt
+        work.mkdir()
+        base = work / "data"
+        cfg = work / "config.ini"
+        cfg.write_text(CONFIG.format(base=base))
+        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": "0,1",
+               "IMK_MODEL_FORMAT": fmt}
+        setup = SETUP.format(root=ROOT).split("import torch\nx = torch.from_numpy")[0]      # the data only
+        subprocess.run([sys.executable, "-c", setup], env=env, check=True, cwd=work)
+        for script in ("03_ISIC_2018_subset.py", "09_ISIC_2018_IM.py"):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", script)], env=env, cwd=work, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        models = sorted(os.listdir(base / "models"))
+        assert "ISIC_2018_subset_1_topK_1.h5" in models and any("_IM_1_n2_gen0_" in m and "topK_1" in m for m in models)
+        assert all(H.is_hdf5(str(base / "models" / m)) == (fmt == "keras_h5") for m in models)
+        stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+        rows[fmt] = (base / "csv" / f"results_{stem}.csv").read_text()
+    assert rows["safetensors"] == rows["keras_h5"]
