@@ -19,22 +19,48 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-// The library's ONE definition of "a BatchNorm applied to a stored fp16 activation": fp16(z * sc + sh) with the fp32 fused
-// multiply-add ROUNDED TO fp32 before it is rounded to fp16 (v_pk_fma_f32 + v_cvt_pk_f16_f32) -- two roundings, like the
-// reference's float32 BatchNorm followed by a cast.  Written as a plain expression on a value that was just converted from
-// fp16, the compiler is free to emit v_fma_mixlo_f16 instead, which rounds the exact sum ONCE; it did so in some kernels (and,
-// inside one kernel, for some channels) and not in others: 1e-4 of the values then differ by an fp16 ulp between a fused launch
-// and its two-launch form (round 2-3's "border pixel" discrepancy of the decoder's first-stage launch).
-// The empty asm statements keep the fp32 sums values of their own, so every site computes the same function.
+// The library's ONE definition of "a BatchNorm applied to a stored fp16 activation": fp16(z * sc + sh), the fp32 fused multiply-add
+// rounded to fp16 ONCE -- v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp16 source, fp32 scale and shift, fp16 result), one instruction per
+// value.  Written as a plain expression the compiler picks between that and v_cvt_f32_f16 + v_pk_fma_f32 + v_cvt_pk_f16_f32 (the sum
+// rounded to fp32 first, then to fp16) site by site -- and, inside one kernel, channel by channel: 1e-4 of the values then differ by
+// an fp16 ulp between a fused launch and its two-launch form (round 2-3's "border pixel" discrepancy of the decoder's first-stage
+// launch).  Round 4 first pinned every site to the two-rounding form (4 instructions per pair, a third of the
+// VALU work of the inference kernels, which are VALU-bound); this is the same pin on the cheaper and more accurate instruction.
 __device__ __forceinline__ f16x2 imk_affine2(f16x2 z, f32x2 sc, f32x2 sh) {
-    f32x2 t = __builtin_elementwise_fma(__builtin_convertvector(z, f32x2), sc, sh);
-    asm volatile("" : "+v"(t));
-    return __builtin_convertvector(t, f16x2);
+    f16x2 d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(z), "v"(sc[0]), "v"(sh[0]), "v"(sc[1]), "v"(sh[1]));
+    return d;
 }
 __device__ __forceinline__ f16 imk_affine1(f16 z, float sc, float sh) {
-    float t = __builtin_fmaf((float)z, sc, sh);
-    asm volatile("" : "+v"(t));
-    return (f16)t;
+    f16x2 d, zz = {z, z};
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(zz), "v"(sc), "v"(sh));
+    return d[0];
+}
+// relu(acc + bias) rounded to fp16, four channels at a time: v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_max_f16 -- 1.5 instructions per
+// value instead of 3 (add, max, convert).  Rounding is monotonic and keeps the sign, so max-after-rounding gives the value
+// max-before-rounding gives (a sum that rounds to -0 yields +0 either way: v_pk_max_f16 orders -0 below +0).
+// MaxPooling2D of a BatchNorm output, applied on load: the window's four values by the definition above, then their maximum
+__device__ __forceinline__ f16x8 imk_affine_pool8(f16x8 z0, f16x8 z1, f16x8 z2, f16x8 z3, const float *sc, const float *sh) {
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 s2 = {sc[j], sc[j + 1]}, h2 = {sh[j], sh[j + 1]};
+        const f16x2 a = imk_affine2(f16x2{z0[j], z0[j + 1]}, s2, h2), b = imk_affine2(f16x2{z1[j], z1[j + 1]}, s2, h2);
+        const f16x2 c = imk_affine2(f16x2{z2[j], z2[j + 1]}, s2, h2), d = imk_affine2(f16x2{z3[j], z3[j + 1]}, s2, h2);
+        const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+        o[j] = m[0]; o[j + 1] = m[1];
+    }
+    return o;
+}
+__device__ __forceinline__ f16x2 imk_bias_relu2(f32x2 acc, f32x2 bias) {
+    return __builtin_elementwise_max(__builtin_convertvector(acc + bias, f16x2), f16x2{0, 0});
+}
+__device__ __forceinline__ f16x4 imk_bias_relu4(f32x4 acc, const float *bias) {
+    const f16x2 l = imk_bias_relu2(f32x2{acc[0], acc[1]}, f32x2{bias[0], bias[1]});
+    const f16x2 h = imk_bias_relu2(f32x2{acc[2], acc[3]}, f32x2{bias[2], bias[3]});
+    return f16x4{l[0], l[1], h[0], h[1]};
 }
 __device__ __forceinline__ f16x8 imk_affine8(f16x8 z, const float *sc, const float *sh) {
     f16x8 o;

@@ -24,6 +24,9 @@
 
 #include "imk_stage.h"
 
+#ifndef IMK_ABL
+#define IMK_ABL 0
+#endif
 IMK_STAMP_TABLE(conv)
 IMK_WGSTAMP_TABLE(conv)
 
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
     const int lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4;
     const int set = PAIR ? (g >> 1) : 0;        // PAIR: which of the block's two tile rows this lane feeds and owns
     const int H = a.H, W = a.W;
-    const int cs_in = a.x.cs_in;
+    constexpr int cs_in = NCI * 8;              // == a.x.cs_in (checked at launch): the affine table's rows sit at compile-time offsets
     const int per_img = tiles_x * tiles_y;
     auto tile_row = [&](int p) { return wave * 4 + (PAIR ? 2 * p + set : p); };
     constexpr unsigned CSB = NCI * 16;          // bytes per pixel of the (fp16) input tensor: cs_in = NCI * 8
@@ -606,7 +609,11 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         valid = 0;
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
+#if IMK_ABL & 1
+            const bool in_img = psrc_load<LM, CSB>(src, 1, 1, 0, W, raw[k]) || true;      // every lane the same (cached) address
+#else
             const bool in_img = psrc_load<LM, CSB>(src, it_py[k], it_px[k], it_c8[k], W, raw[k]);
+#endif
             valid |= ((it_lds[k] >= 0 && in_img) ? 1u : 0u) << k;
         }
         if constexpr (WG == 1 || WG == 2) {      // thread t <-> pixel t of the (full) tile
@@ -677,7 +684,13 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
             for (int k = 0; k < MAX_ITEMS; ++k) {
                 if (it_lds[k] >= 0) {
+#if IMK_ABL & 4
+                    f16x8 v;
+                    if constexpr (LM == LM_U8 || LM == LM_STEM) v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div, a.x.u8_c);
+                    else v = raw[k].v[0];
+#else
                     f16x8 v = raw_transform<LM>(raw[k], s_aff, cs_in, it_c8[k], a.x.cin, a.x.u8_div, a.x.u8_c);
+#endif
                     if (!(valid & (1u << k))) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<f16x8 *>(s_stage + it_lds[k]) = v;
                 }
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
         }
         issue(tn);                                // in flight during the MFMAs, the epilogue and its stores
         if constexpr (DYN) tk_new = imk_take_ticket(tk_head, tk_lane);     // the tile after next: its latency runs under this tile
-        if constexpr (PRE) {
+        if constexpr (PRE && !(IMK_ABL & 8)) {
             // rows / columns of the halo tile that lie inside the image (the 3x3 pads its INPUT with zeros, not the 1x1's)
             const int oy = tc.ty0 - halo, ox = tc.tx0 - halo;
             const int lo_y = oy < 0 ? -oy : 0, hi_y = min(HT - 1, H - 1 - oy), lo_x = ox < 0 ? -ox : 0, hi_x = min(WT - 1, W - 1 - ox);
@@ -772,14 +785,16 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
                 const f32x4 pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_pre, bfp, f32x4{0, 0, 0, 0}, 0, 0, 0);
                 const int py = pre_yx[j] >> 8, px = pre_yx[j] & 255;
                 const bool inside = py >= lo_y && py <= hi_y && px >= lo_x && px <= hi_x;
-                f16x4 w;
+                const float pbv[4] = {pb[0], pb[1], pb[2], pb[3]};
+                const f16x4 z4 = imk_bias_relu4(pa, pbv);                                                          // the 1x1's stored output
+                unsigned wd[2];
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const f16x2 z2 = {(f16)fmaxf(pa[r] + pb[r], 0.f), (f16)fmaxf(pa[r + 1] + pb[r + 1], 0.f)};   // the 1x1's stored output
-                    const f16x2 w2 = imk_affine2(z2, f32x2{psc[r], psc[r + 1]}, f32x2{psh[r], psh[r + 1]});      // two roundings, as the staged form (imk_common.h)
-                    w[r] = inside ? w2[0] : (f16)0.f;
-                    w[r + 1] = inside ? w2[1] : (f16)0.f;
+                    const f16x2 z2 = {z4[r], z4[r + 1]};
+                    const f16x2 w2 = imk_affine2(z2, f32x2{psc[r], psc[r + 1]}, f32x2{psh[r], psh[r + 1]});      // as the staged form (imk_common.h)
+                    wd[r >> 1] = inside ? __builtin_bit_cast(unsigned, w2) : 0u;                                   // (one select per pair)
                 }
+                const f16x4 w = __builtin_bit_cast(f16x4, uint2{wd[0], wd[1]});
                 if (pre_cb < NC8 * 8)
                     *reinterpret_cast<f16x4 *>(s_tile + (pre_pix[j] * PS + (pre_cb >> 3)) * 16 + (pre_cb & 7) * 2) = w;
 #ifdef IMK_PRE_DEBUG      // probe builds (tests/gpu_probe/pre_dump.py): the first stage's values of the tile's own pixels, for a per-pixel diff
@@ -858,7 +873,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < MAX_NS; ++s) {
+        for (int s = 0; s < ((IMK_ABL & 16) ? 1 : MAX_NS); ++s) {
             if (s < ns) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
@@ -872,16 +887,12 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             // the lane's 4 channels of pixel n are exactly k-slots (g, 0..3) of the next MFMA's B operand.
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                f16x4 hv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
+                const f16x4 hv = imk_bias_relu4(acc[p], bias);
                 if (CHAIN == 1 && (FULL || inb[p]) && lane_mid) *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o1) + o1[p]) = hv;
                 const f16x8 bf2 = {hv[0], hv[1], hv[2], hv[3], 0, 0, 0, 0};
                 const f32x4 a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2, bf2, f32x4{0, 0, 0, 0}, 0, 0, 0);
-                f16x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(a2[r] + bias2[r], 0.f);
-                if ((FULL || inb[p]) && lane_out) {
+                const f16x4 v = imk_bias_relu4(a2, bias2);
+                if ((FULL || inb[p]) && lane_out && (!(IMK_ABL & 2) || a.H < 0)) {
                     *reinterpret_cast<f16x4 *>(const_cast<char *>(b_o2) + o2[p]) = v;
                     if (want_stats)
 #pragma unroll
@@ -894,8 +905,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles
             for (int p = 0; p < P; ++p) {
                 f16x4 v;
                 if (EPI == EP_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (f16)fmaxf(acc[p][r] + bias[r], 0.f);
+                    v = imk_bias_relu4(acc[p], bias);
                 } else if (EPI == EP_MASK) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = ((float)mk[p][r] > 0.f) ? (f16)acc[p][r] : (f16)0.f;
@@ -1927,6 +1937,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
         if (a.sched && !a.stats_partial && dyn_walk_on() && a.B * imk_cdiv(a.H, 16) * imk_cdiv(a.W, TW) >= 2048)
             return launch_conv_pipe_k<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, true>(a, stream);
     }
+    if (a.x.cs_in != (PRE ? PRE : NC8) * 8) return IMK_EINVAL;      // the kernel takes the input's channel stride from its template arguments
     static int blocks_per_cu = 0;   // occupancy of this instantiation, queried once
     const size_t lds = pipe_lds_base(NC8, PAIR, WG) + (PRE ? (size_t)18 * 18 * imk_lds_pitch(PRE) * 16 + 3 * 16 * sizeof(float) : 0);
     auto kern = conv_pipe_kernel<LM, NC8, CHAIN, PAIR, EPI, DYSTAT, FULL, WG, PRE, DYN>;

@@ -543,13 +543,7 @@ __global__ __launch_bounds__(256) void concat_pool_kernel(const f16 *__restrict_
     const f16 *p = z + ((size_t)(b * 2 * Hh + 2 * y) * W + 2 * x) * cs + c0;
     const f16x8 v0 = *reinterpret_cast<const f16x8 *>(p), v1 = *reinterpret_cast<const f16x8 *>(p + cs);
     const f16x8 v2 = *reinterpret_cast<const f16x8 *>(p + (size_t)W * cs), v3 = *reinterpret_cast<const f16x8 *>(p + (size_t)W * cs + cs);
-    f16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {   // same rounding as the LM_POOL load of the conv kernels
-        const float a = (float)v0[j] * sc[j] + sh[j], bq = (float)v1[j] * sc[j] + sh[j];
-        const float c = (float)v2[j] * sc[j] + sh[j], d = (float)v3[j] * sc[j] + sh[j];
-        o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-    }
+    const f16x8 o = imk_affine_pool8(v0, v1, v2, v3, sc, sh);   // the LM_POOL load of the conv kernels
     *reinterpret_cast<f16x8 *>(cat + (size_t)pix * (csa + csb) + c8 * 8) = o;
 }
 
@@ -598,9 +592,9 @@ __global__ __launch_bounds__(256) void evalnet_head_kernel(EvalHeadArgs a) {
             for (int y = 0; y < Hh; ++y)
                 for (int x = 0; x < Wh; ++x) {
                     const f16 *p = a.z + ((size_t)(b * a.H + 2 * y) * a.W + 2 * x) * a.cs + c;
-                    const float v0 = (float)p[0] * sc + sh, v1 = (float)p[a.cs] * sc + sh;
-                    const float v2 = (float)p[(size_t)a.W * a.cs] * sc + sh, v3 = (float)p[(size_t)a.W * a.cs + a.cs] * sc + sh;
-                    acc += (float)(f16)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                    const float v0 = (float)imk_affine1(p[0], sc, sh), v1 = (float)imk_affine1(p[a.cs], sc, sh);
+                    const float v2 = (float)imk_affine1(p[(size_t)a.W * a.cs], sc, sh), v3 = (float)imk_affine1(p[(size_t)a.W * a.cs + a.cs], sc, sh);
+                    acc += fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
                 }
             acc /= (float)(Hh * Wh);
         }

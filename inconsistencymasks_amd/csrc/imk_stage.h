@@ -97,15 +97,7 @@ __device__ __forceinline__ f16x8 load_chunk(const ImkInput &in, int b, int y, in
             const f16 *p = (const f16 *)in.in + ((size_t)(b * H2 + 2 * y) * W2 + 2 * x) * cs + c8 * 8;
             const f16x8 z00 = *(const f16x8 *)p, z01 = *(const f16x8 *)(p + cs);
             const f16x8 z10 = *(const f16x8 *)(p + (size_t)W2 * cs), z11 = *(const f16x8 *)(p + (size_t)W2 * cs + cs);
-            const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = (float)z00[j] * sc[j] + sh[j], bq = (float)z01[j] * sc[j] + sh[j];
-                const float c = (float)z10[j] * sc[j] + sh[j], d = (float)z11[j] * sc[j] + sh[j];
-                o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-            }
-            return o;
+            return imk_affine_pool8(z00, z01, z10, z11, s_aff + c8 * 8, s_aff + cs + c8 * 8);
         }
         case LM_UPADD: {
             const int Hl = H / 2, Wl = W / 2;
@@ -205,15 +197,7 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
     } else if constexpr (LM == LM_AFFINE) {
         return affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
     } else if constexpr (LM == LM_POOL) {
-        const float *sc = s_aff + c8 * 8, *sh = s_aff + cs + c8 * 8;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = (float)r.v[0][j] * sc[j] + sh[j], bq = (float)r.v[1][j] * sc[j] + sh[j];
-            const float c = (float)r.v[2][j] * sc[j] + sh[j], d = (float)r.v[3][j] * sc[j] + sh[j];
-            o[j] = (f16)fmaxf(fmaxf(a, bq), fmaxf(c, d));
-        }
-        return o;
+        return imk_affine_pool8(r.v[0], r.v[1], r.v[2], r.v[3], s_aff + c8 * 8, s_aff + cs + c8 * 8);
     } else if constexpr (LM == LM_UPADD) {
         const f16x8 lo = affine8(r.v[0], s_aff + c8 * 8, s_aff + cs + c8 * 8);
         const f16x8 sk = affine8(r.v[1], s_aff + 2 * cs + c8 * 8, s_aff + 3 * cs + c8 * 8);
@@ -252,7 +236,7 @@ __device__ __forceinline__ f16x8 raw_transform(const RawChunk<LM> &r, const floa
         }
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-            const f16x2 z2 = {(f16)fmaxf(acc[j] + bias[j], 0.f), (f16)fmaxf(acc[j + 1] + bias[j + 1], 0.f)};      // the stem's stored output
+            const f16x2 z2 = imk_bias_relu2(f32x2{acc[j], acc[j + 1]}, f32x2{bias[j], bias[j + 1]});               // the stem's stored output
             const f16x2 w2 = imk_affine2(z2, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]});
             o[j] = w2[0]; o[j + 1] = w2[1];
         }
