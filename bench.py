@@ -723,6 +723,19 @@ def run_config(args, config_name, alpha, env, primary):
                 break
     except Exception:
         pass
+    # `traffic` averages the launches of the PMC pass (the whole process: ensemble pre-training + timed region + exclusive pass), the
+    # sampled algorithmic figure below the timed region only -- their quotient means nothing.  Over ONE population
+    # (profiles/r04_traffic_ratio.py: per variant, launches of the PMC pass x the library's algorithmic bytes of that variant):
+    traffic_ratio, traffic_alg = None, None
+    try:
+        import csv
+        path = os.path.join(ROOT, "profiles", "r04_traffic_vs_algorithmic.csv")
+        if primary and traffic_src and "r04_pmc_traffic.csv" in traffic_src and os.path.exists(path):
+            fam_row = [r for r in csv.reader(open(path)) if r and r[0].startswith("FAMILY")]
+            if fam_row:
+                traffic_alg, traffic_ratio = round(1e6 * float(fam_row[0][2])), float(fam_row[0][4])
+    except Exception:
+        pass
     # The same fraction from rocprofv3's own durations: the family's launches INSIDE the timed region of the committed kernel trace
     # of this command (profiles/summarize.py cuts the trace at the marker dispatches) against this run's algorithmic bytes / flops
     frac_rocprof, rocprof_src, rocprof_us = None, None, None
@@ -765,6 +778,7 @@ def run_config(args, config_name, alpha, env, primary):
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": FAMILIES[v], "achieved": round(achieved, 1), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_over_algorithmic": traffic_ratio, "traffic_population_algorithmic_bytes_per_launch": traffic_alg,
                 "frac_rocprof": frac_rocprof, "rocprof_avg_us_per_launch": round(rocprof_us, 2) if rocprof_us else None,
                 "frac_rocprof_source": rocprof_src,
                 "avg_us_per_launch_whole_process": round(1000 * whole_ms / max(whole_n, 1), 2),
