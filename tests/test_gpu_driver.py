@@ -798,6 +798,32 @@ def test_bench_one_rank_process_group_rccl():
     assert out["roofline"]["step"]["train_step"]["host_enqueue_ms_per_step"] > 0
 
 
+def test_bench_two_ranks_driver_command_form():
+    """The driver's N > 1 command, literally (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...`), with both ranks time-slicing this box's one GPU over gloo (IMK_BENCH_ONE_GPU /
+    IMK_BENCH_BACKEND): the unlabeled set sharded in contiguous blocks, the per-step gradient all-reduce, the barrier-bracketed timing
+    with its MAX over ranks and the single JSON line from rank 0 all execute.  (RCCL with two ranks needs two GPUs.)"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {**os.environ, "IMK_BENCH_ONE_GPU": "1", "IMK_BENCH_BACKEND": "gloo"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "96", "--labeled", "32", "--steps", "1",
+           "--warmup", "1", "--pretrain-steps", "10", "--bn-settle-steps", "10", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["value"] > 0
+    c = out["config"]
+    assert c["unlabeled_images"] == 96 and c["unlabeled_images_per_gpu"] == 48 and c["parallelism"] == "dp2"
+    assert c["global_batch"] == 2 * c["train_batch_per_gpu"] and c["process_group"].startswith("gloo")
+    assert out["scaling"] in ("strong", "weak") and "other_configs" not in out     # (the extra shapes ride on the default N = 1 line only)
+
+
 def test_isic_driver_candidates_side_by_side(tmp_path):
     """IM_PARALLEL_CANDIDATES=3: the generation's candidates train on three host threads with a stream each (VERDICT round 3, item
     7; the reference trains them one after the other, ISIC_2018/09_ISIC_2018_IM.py:90).  Every candidate must compute exactly
