@@ -448,7 +448,9 @@ constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
 // DYN: the workgroups take their tiles from per-group counters (a.sched; ImkWalk, dynamic form) -- launches without per-workgroup
 // partial rows only (EP_RELU without statistics, no fused weight gradient: inference)
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0, bool DYN = false>
-__global__ __launch_bounds__(256) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
+// (inference launches of the 8-channel layers: four workgroups per CU, i.e. <= 128 registers -- the decoder's launch sat at 134 and ran
+//  three waves per SIMD: 0.891 -> 0.873 ms per 256-image forward; the 16-channel and the training variants gain nothing from a cap)
+__global__ __launch_bounds__(256, (DYN && NC8 == 1) ? 4 : 1) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, ImkWalk wk) {
     static_assert(!DYN || (EPI == EP_RELU && !DYSTAT && WG == 0), "dynamic walk: results must not depend on the tile -> workgroup map");
     static_assert(PRE == 0 || (WG == 0 && EPI == EP_RELU && !DYSTAT && (LM == LM_U8 || LM == LM_UPADD)), "pre-stage: inference forward only");
