@@ -656,7 +656,7 @@ def test_decoder_first_stage_matches_its_own_launch(tmp_path):
     fp16 ulp on some seeds (12-16): the first stage's BatchNorm `fp16(z * sc + sh)` had been compiled to v_fma_mixlo_f16 -- ONE
     rounding of the exact sum -- in the fused launch, while the staged form of the two launches rounds to fp32 and then to fp16;
     1e-4 of the values land on an fp16 tie of the fp32 result and differ (tests/gpu_probe/pre_dump.py dumps both and names the
-    pixels).  Every BatchNorm-on-load site now goes through one helper with the two roundings made explicit (imk_common.h)."""
+    pixels).  Every BatchNorm-on-load site now goes through one helper (imk_common.h: the one-rounding instruction written out)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "pre_child.py"
