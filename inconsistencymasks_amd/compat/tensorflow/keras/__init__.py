@@ -9,6 +9,10 @@ def _load_model(filepath, custom_objects=None, compile=True):
     from inconsistencymasks_amd import h5lite
     from inconsistencymasks_amd.functions import load_model
     if h5lite.is_hdf5(filepath):
+        from inconsistencymasks_amd.keras_h5 import keras_h5_kind
+        if keras_h5_kind(filepath) == "evalnet":
+            from inconsistencymasks_amd.evalnet_functions import load_evalnet
+            return load_evalnet(filepath)
         return load_model(filepath, custom_objects=custom_objects)
     from safetensors import safe_open
     with safe_open(filepath, framework="pt") as f:

@@ -333,6 +333,10 @@ def _evaluate_evalnet(model, xa, xb, y, batch_size, steps, k):
 
 
 def save_evalnet(model, path):
+    """ModelCheckpoint's model.save(path) for the EvalNet; IMK_MODEL_FORMAT=keras_h5: a Keras save_weights HDF5 file (keras_h5.py)"""
+    if os.environ.get("IMK_MODEL_FORMAT", "safetensors") == "keras_h5":
+        from .keras_h5 import save_keras_evalnet_weights
+        return save_keras_evalnet_weights(model, path)
     from safetensors.torch import save_file
     p = model.plan
     meta = {"net": "evalnet", "h": str(p.h), "w": str(p.w), "ca": str(p.ca), "cb": str(p.cb), "n_out": str(p.n_out),
@@ -342,6 +346,11 @@ def save_evalnet(model, path):
 
 
 def load_evalnet(path, device="cuda"):
+    """load_model for an EvalNet file: this package's safetensors, or a Keras HDF5 checkpoint of evalnet.get_evalnet / get_evalnet_miou"""
+    from . import h5lite
+    if h5lite.is_hdf5(path):
+        from .keras_h5 import load_keras_evalnet
+        return load_keras_evalnet(path, device=device)
     from safetensors import safe_open
     with safe_open(path, framework="pt") as f:
         meta = f.metadata()

@@ -115,24 +115,16 @@ def infer_config(first_kernel_shape, out_kernel_shape):
     return c_in, int(out_kernel_shape[3]), alpha
 
 
-def read_keras_h5(path):
-    """-> (Keras layer name -> {weight name: array}, output activation or None, [H, W, C] of the InputLayer or None)"""
+def _read_keras(path):
+    """-> (Keras layer name -> {weight name: array}, parsed model_config or None, this package's imk_config attribute or None)"""
     f = h5lite.File(path)
     g = f["model_weights"] if "model_weights" in f else f
-    act = shape = None
     cfg = f.attrs.get("model_config")
     if cfg is not None:
         cfg = json.loads(cfg.decode("utf-8") if isinstance(cfg, bytes) else cfg)
-        for l in cfg.get("config", {}).get("layers", []):
-            c = l.get("config", {})
-            if c.get("name") == "out":
-                act = c.get("activation")
-            if l.get("class_name") == "InputLayer" and c.get("batch_input_shape"):
-                shape = [int(v) for v in c["batch_input_shape"][1:]]
     own = f.attrs.get("imk_config")                        # written by save_keras_weights: Keras ignores it
     if own is not None:
         own = json.loads(own.decode("utf-8") if isinstance(own, bytes) else own)
-        act, shape = own.get("act_out"), [int(own["h"]), int(own["w"]), int(own["c_in"])]
     names = h5lite.load_attr_list(g, "layer_names") or g.keys()
     weights_of = {}
     for lname in names:
@@ -147,7 +139,38 @@ def read_keras_h5(path):
                 found[wn.split("/")[-1].split(":")[0]] = np.asarray(ds[...])
         if found:
             weights_of[lname] = found
+    return weights_of, cfg, own
+
+
+def _config_layers(cfg):
+    return cfg.get("config", {}).get("layers", []) if cfg else []
+
+
+def read_keras_h5(path):
+    """-> (Keras layer name -> {weight name: array}, output activation or None, [H, W, C] of the InputLayer or None)"""
+    weights_of, cfg, own = _read_keras(path)
+    act = shape = None
+    for l in _config_layers(cfg):
+        c = l.get("config", {})
+        if c.get("name") == "out":
+            act = c.get("activation")
+        if l.get("class_name") == "InputLayer" and c.get("batch_input_shape"):
+            shape = [int(v) for v in c["batch_input_shape"][1:]]
+    if own is not None and own.get("net", "unet") == "unet":
+        act, shape = own.get("act_out"), [int(own["h"]), int(own["w"]), int(own["c_in"])]
     return weights_of, act, shape
+
+
+def keras_h5_kind(path):
+    """'unet' / 'evalnet' / None: which of the reference's two networks a Keras HDF5 file holds (by its layer names)"""
+    f = h5lite.File(path)
+    g = f["model_weights"] if "model_weights" in f else f
+    names = set(h5lite.load_attr_list(g, "layer_names") or g.keys())
+    if "out" in names:
+        return "unet"
+    if {"iou", "detection"} <= names or any(re.fullmatch(r"dense(_\d+)?", n) for n in names):
+        return "evalnet"
+    return None
 
 
 def state_dict_from_keras_h5(path):
@@ -198,7 +221,7 @@ def save_keras_weights(model_or_sd, path, c_in=None, n_out=None, alpha=None, own
         m = model_or_sd
         sd = {k: v.numpy() for k, v in m.state_dict().items()}
         c_in, n_out, alpha = m.plan.c_in, m.plan.n_out, m.plan.alpha
-        own = {"h": m.plan.h, "w": m.plan.w, "c_in": c_in, "n_out": n_out, "alpha": alpha, "act_out": m.plan.act_out}
+        own = {"net": "unet", "h": m.plan.h, "w": m.plan.w, "c_in": c_in, "n_out": n_out, "alpha": alpha, "act_out": m.plan.act_out}
     else:
         sd = {k: np.asarray(v) for k, v in model_or_sd.items()}
         if c_in is None:
@@ -216,4 +239,134 @@ def save_keras_weights(model_or_sd, path, c_in=None, n_out=None, alpha=None, own
     tree[h5lite.ATTRS] = {"layer_names": order, "backend": b"tensorflow", "keras_version": b"2.10.0"}
     if own:
         tree[h5lite.ATTRS]["imk_config"] = json.dumps(own)
+    h5lite.write(path, tree)
+
+
+# ---------------------------------------------------------------------------------------------------------------- EvalNet (evalnet.py:24-73)
+def evalnet_layer_table(ca, cb, n_out, alpha, two_heads):
+    """(name, kind, k, cin, cout) in evalnet.py's creation order -- the order of the plan's flat parameter vector: tower A (input block,
+    conv block), tower B, five merged blocks, the Dense head(s) as 1x1 'convs' on the pooled features"""
+    f = lambda v: int(v * alpha)
+    f0 = f(16)
+    t = []
+    for tw, cin in (("a", ca), ("b", cb)):
+        t += [(f"{tw}.in.c", "conv", 1, cin, f0), (f"{tw}.in.bn", "bn", 0, f0, f0),
+              (f"{tw}.c3", "conv", 3, f0, f0), (f"{tw}.c1", "conv", 1, f0, f0), (f"{tw}.bn", "bn", 0, f0, f0)]
+    prev = 2 * f0
+    for i, v in enumerate((16, 32, 64, 128, 256), start=1):
+        t += [(f"m{i}.c3", "conv", 3, prev, f(v)), (f"m{i}.c1", "conv", 1, f(v), f(v)), (f"m{i}.bn", "bn", 0, f(v), f(v))]
+        prev = f(v)
+    return t + ([("iou", "conv", 1, prev, n_out), ("detection", "conv", 1, prev, n_out)] if two_heads else [("dense", "conv", 1, prev, n_out)])
+
+
+_HEADS = ("dense", "iou", "detection")
+
+
+def evalnet_keras_layer_names(table):
+    out, ci, bi = {}, 0, 0
+    for name, kind, *_ in table:
+        if name in _HEADS:
+            out[name] = name
+        elif kind == "conv":
+            out[name] = "conv2d" if ci == 0 else f"conv2d_{ci}"
+            ci += 1
+        else:
+            out[name] = "batch_normalization" if bi == 0 else f"batch_normalization_{bi}"
+            bi += 1
+    return out
+
+
+def evalnet_state_dict_from_keras_h5(path):
+    """-> (state dict, dict(h, w, ca, cb, n_out, alpha, two_heads, normalize_a, normalize_b)); entries the file does not record are None"""
+    weights_of, cfg, own = _read_keras(path)
+    convs = sorted([n for n in weights_of if re.fullmatch(r"conv2d(_\d+)?", n)], key=_suffix)
+    bns = sorted([n for n in weights_of if re.fullmatch(r"batch_normalization(_\d+)?", n)], key=_suffix)
+    two = "iou" in weights_of and "detection" in weights_of
+    dense = [n for n in weights_of if re.fullmatch(r"dense(_\d+)?", n)]
+    if len(convs) != 16 or len(bns) != 9 or not (two or len(dense) == 1):
+        raise ValueError(f"{path}: not an evalnet.get_evalnet / get_evalnet_miou checkpoint ({len(convs)} Conv2D, {len(bns)} BatchNormalization, "
+                         f"heads {sorted(set(weights_of) - set(convs) - set(bns))})")
+    k_a, k_b = weights_of[convs[0]]["kernel"], weights_of[convs[3]]["kernel"]
+    head = weights_of["iou" if two else dense[0]]["kernel"]
+    ca, cb, n_out = int(k_a.shape[2]), int(k_b.shape[2]), int(head.shape[-1])
+    _, _, alpha = infer_config(k_a.shape, (1, 1, 1, 1))
+    table = evalnet_layer_table(ca, cb, n_out, alpha, two)
+    it_c, it_b = iter(convs), iter(bns)
+    sd = {}
+    for name, kind, k, ci, co in table:
+        if name in _HEADS:
+            w = weights_of[name if two else dense[0]]
+            kern = np.asarray(w["kernel"], np.float32).reshape(1, 1, ci, co)          # Dense kernel [features, units]
+            sd[name + ".w"], sd[name + ".b"] = kern, np.asarray(w["bias"], np.float32)
+        elif kind == "conv":
+            w = weights_of[next(it_c)]
+            kern = np.asarray(w["kernel"], np.float32)
+            if kern.shape != (k, k, ci, co):
+                raise ValueError(f"{path}: {name}: kernel {kern.shape}, expected {(k, k, ci, co)}")
+            sd[name + ".w"], sd[name + ".b"] = kern, np.asarray(w["bias"], np.float32)
+        else:
+            w = weights_of[next(it_b)]
+            for ours, theirs in (("gamma", "gamma"), ("beta", "beta"), ("mean", "moving_mean"), ("var", "moving_variance")):
+                sd[f"{name}.{ours}"] = np.asarray(w[theirs], np.float32)
+    meta = {"h": None, "w": None, "ca": ca, "cb": cb, "n_out": n_out, "alpha": alpha, "two_heads": two, "normalize_a": None, "normalize_b": None}
+    layers = _config_layers(cfg)
+    if layers:
+        # the two Inputs in model_config["config"]["input_layers"] order (A first, evalnet.py:45); a Lambda fed by an input = its x / 255
+        order = [e[0] for e in cfg["config"].get("input_layers", [])] or [l["config"]["name"] for l in layers if l.get("class_name") == "InputLayer"]
+        shapes = {l["config"]["name"]: l["config"].get("batch_input_shape") for l in layers if l.get("class_name") == "InputLayer"}
+        if len(order) == 2 and all(shapes.get(n) for n in order):
+            meta["h"], meta["w"] = int(shapes[order[0]][1]), int(shapes[order[0]][2])
+            fed = set()
+            for l in layers:
+                if l.get("class_name") == "Lambda":
+                    for node in l.get("inbound_nodes", []):
+                        for e in node:
+                            fed.add(e[0])
+            meta["normalize_a"], meta["normalize_b"] = order[0] in fed, order[1] in fed
+    if own is not None and own.get("net") == "evalnet":
+        meta.update({k: own[k] for k in ("h", "w", "normalize_a", "normalize_b") if k in own})
+        meta["b_onehot"] = bool(own.get("b_onehot", False))
+    return sd, meta
+
+
+def load_keras_evalnet(path, height=None, width=None, normalize_a=None, normalize_b=None, device="cuda"):
+    """tf.keras.models.load_model(path) for an EvalNet checkpoint of the reference (ISIC_2018/12_ISIC_2018_IM++.py): -> EvalNet"""
+    import torch
+    from .evalnet import EvalNet
+    sd, m = evalnet_state_dict_from_keras_h5(path)
+    pick = lambda a, b: a if a is not None else b
+    h, w, na, nb = pick(height, m["h"]), pick(width, m["w"]), pick(normalize_a, m["normalize_a"]), pick(normalize_b, m["normalize_b"])
+    if None in (h, w, na, nb):
+        raise ValueError(f"{path}: a weights-only HDF5 file does not record the input size / which inputs are divided by 255 -- pass "
+                         "height=, width=, normalize_a=, normalize_b=")
+    net = EvalNet(int(h), int(w), m["ca"], m["cb"], m["n_out"], m["alpha"], m["two_heads"], bool(na), bool(nb), seed=0, device=device,
+                  b_onehot=bool(m.get("b_onehot", False)))
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    return net
+
+
+def save_keras_evalnet_weights(model, path):
+    """The EvalNet's weights in the layout of Keras' save_weights (HDF5); Dense kernels as [features, units]."""
+    p = model.plan
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    table = evalnet_layer_table(p.ca, p.cb, p.n_out, p.alpha, p.two_heads)
+    kn = evalnet_keras_layer_names(table)
+    tree = {}
+    # `layer_names` in the order of Keras' model.layers for this graph (layers by depth, creation order inside a depth): the two towers
+    # interleave -- the order load_weights(by_name=False) zips with; by_name=True does not depend on it
+    towers = [f"{t}.{l}" for l in ("in.c", "in.bn", "c3", "c1", "bn") for t in ("a", "b")]
+    order = [kn[n].encode() for n in towers + [n for n, *_ in table if n not in towers]]
+    for name, kind, k, ci, co in table:
+        kname = kn[name]
+        if kind == "conv":
+            kern = np.asarray(sd[name + ".w"], np.float32)
+            ws = {"kernel:0": kern.reshape(ci, co) if name in _HEADS else kern, "bias:0": np.asarray(sd[name + ".b"], np.float32)}
+        else:
+            ws = {"gamma:0": sd[name + ".gamma"], "beta:0": sd[name + ".beta"], "moving_mean:0": sd[name + ".mean"],
+                  "moving_variance:0": sd[name + ".var"]}
+        tree[kname] = {h5lite.ATTRS: {"weight_names": [f"{kname}/{w}".encode() for w in ws]},
+                       kname: {w: np.asarray(a, np.float32) for w, a in ws.items()}}
+    own = {"net": "evalnet", "h": p.h, "w": p.w, "ca": p.ca, "cb": p.cb, "n_out": p.n_out, "alpha": p.alpha, "two_heads": bool(p.two_heads),
+           "normalize_a": bool(p.cfg.normalize_a), "normalize_b": bool(p.cfg.normalize_b), "b_onehot": bool(p.b_onehot)}
+    tree[h5lite.ATTRS] = {"layer_names": order, "backend": b"tensorflow", "keras_version": b"2.10.0", "imk_config": json.dumps(own)}
     h5lite.write(path, tree)

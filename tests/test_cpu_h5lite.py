@@ -208,3 +208,35 @@ def test_keras_weights_file_round_trip_and_get_weights_order(tmp_path):
     K.save_keras_weights(sd, p)
     _, cfg = K.state_dict_from_keras_h5(p)
     assert cfg["h"] is None and cfg["act_out"] is None and cfg["alpha"] == 1.25
+
+
+def test_keras_evalnet_fixture_to_state_dict(tmp_path):
+    """evalnet.get_evalnet_miou's checkpoint layout (two towers: `layer_names` in model.layers order, i.e. interleaved): the mapping goes
+    by creation order all the same, Dense kernels become 1x1 'conv' weights, the normalisation flags come from the Lambda layers' inputs"""
+    from inconsistencymasks_amd import keras_h5 as K
+    path = os.path.join(GOLD, "h5_keras_evalnet.h5")
+    exp = np.load(os.path.join(GOLD, "h5_keras_evalnet.npz"))
+    assert K.keras_h5_kind(path) == "evalnet" and K.keras_h5_kind(os.path.join(GOLD, "h5_keras_full_model.h5")) == "unet"
+    sd, m = K.evalnet_state_dict_from_keras_h5(path)
+    assert m == {"h": 64, "w": 64, "ca": 3, "cb": 2, "n_out": 2, "alpha": 0.5, "two_heads": True, "normalize_a": True, "normalize_b": False}
+    table = K.evalnet_layer_table(3, 2, 2, 0.5, True)
+    kn = K.evalnet_keras_layer_names(table)
+    assert kn["a.in.c"] == "conv2d" and kn["b.in.c"] == "conv2d_3" and kn["m1.c3"] == "conv2d_6" and kn["m5.bn"] == "batch_normalization_8"
+    n = 0
+    for name, kind, k, ci, co in table:
+        if name in ("iou", "detection"):
+            assert sd[name + ".w"].shape == (1, 1, ci, co) and np.array_equal(sd[name + ".w"].reshape(ci, co), exp[name + "/kernel:0"])
+            assert np.array_equal(sd[name + ".b"], exp[name + "/bias:0"])
+            n += 2
+        elif kind == "conv":
+            assert np.array_equal(sd[name + ".w"], exp[kn[name] + "/kernel:0"]) and np.array_equal(sd[name + ".b"], exp[kn[name] + "/bias:0"])
+            n += 2
+        else:
+            for ours, theirs in (("gamma", "gamma"), ("beta", "beta"), ("mean", "moving_mean"), ("var", "moving_variance")):
+                assert np.array_equal(sd[f"{name}.{ours}"], exp[f"{kn[name]}/{theirs}:0"])
+            n += 4
+    assert n == len(exp.files) == len(sd)
+    with pytest.raises(ValueError, match="not a unet.get_unet"):
+        K.state_dict_from_keras_h5(path)
+    with pytest.raises(ValueError, match="not an evalnet"):
+        K.evalnet_state_dict_from_keras_h5(os.path.join(GOLD, "h5_keras_full_model.h5"))

@@ -83,3 +83,38 @@ def test_isic_generation_with_hdf5_model_files(tmp_path):
         stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
         rows[fmt] = (base / "csv" / f"results_{stem}.csv").read_text()
     assert rows["safetensors"] == rows["keras_h5"]
+
+
+def test_load_evalnet_takes_a_keras_checkpoint_and_round_trips(tmp_path, monkeypatch):
+    """evalnet.get_evalnet_miou's Keras checkpoint (tests/golden/h5_keras_evalnet.h5: h5py's bytes, two towers) through load_evalnet and
+    the compat tf.keras.models.load_model; save_evalnet under IMK_MODEL_FORMAT=keras_h5 and back, bit for bit"""
+    from inconsistencymasks_amd import evalnet_functions as EF
+    from inconsistencymasks_amd import h5lite as H
+    from inconsistencymasks_amd import keras_h5 as K
+    from oracle import evalnet_oracle as E
+    path = os.path.join(GOLD, "h5_keras_evalnet.h5")
+    m = EF.load_evalnet(path)
+    p = m.plan
+    assert (p.h, p.w, p.ca, p.cb, p.n_out, p.alpha, p.two_heads, p.cfg.normalize_a, p.cfg.normalize_b) == (64, 64, 3, 2, 2, 0.5, True, 1, 0)
+    sd, _ = K.evalnet_state_dict_from_keras_h5(path)
+    rng = np.random.default_rng(3)
+    xa = rng.integers(0, 256, (4, 64, 64, 3), dtype=np.uint8)
+    xb = (rng.random((4, 64, 64, 2)) > 0.5).astype(np.uint8)
+    got = np.concatenate(m.predict([xa, xb]), 1)
+    ref, _ = E.forward({k: torch.from_numpy(v) for k, v in sd.items()}, xa, xb, True, True, False, emulate_fp16=True)
+    assert got.shape == (4, 4) and np.abs(got - ref.numpy()).max() <= 2e-2          # tests/test_gpu_evalnet.py's tolerance
+    sys.path.insert(0, os.path.join(ROOT, "inconsistencymasks_amd", "compat"))
+    import tensorflow as tf                                                          # the compat namespace
+    m2 = tf.keras.models.load_model(path)
+    assert type(m2).__name__ == "EvalNet" and torch.equal(m2.params, m.params)
+    u = tf.keras.models.load_model(os.path.join(GOLD, "h5_keras_full_model.h5"))
+    assert type(u).__name__ == "UNet"
+    monkeypatch.setenv("IMK_MODEL_FORMAT", "keras_h5")
+    q = str(tmp_path / "evalnet.h5")
+    EF.save_evalnet(m, q)
+    assert H.is_hdf5(q)
+    names = H.load_attr_list(H.File(q), "layer_names")
+    assert names[:4] == ["conv2d", "conv2d_3", "batch_normalization", "batch_normalization_2"] and names[-2:] == ["iou", "detection"]
+    back = EF.load_evalnet(q)
+    assert torch.equal(back.params, m.params) and (back.plan.cfg.normalize_a, back.plan.cfg.normalize_b) == (1, 0)
+    assert np.array_equal(np.concatenate(back.predict([xa, xb]), 1), got)

@@ -18,6 +18,8 @@ libhdf5 1.10.6).  Run THIS script with that interpreter; it writes
                                        variable-length-string / fixed-string-array attributes, groups with 300 members
                                        (several symbol-table nodes under a B-tree)
   tests/golden/h5_cases.npz             the expected values
+  tests/golden/h5_keras_evalnet.h5/.npz the same for evalnet.get_evalnet_miou (two towers: `layer_names` in model.layers order, i.e. interleaved;
+                                       Lambda / Input layers with their inbound nodes in model_config)
   tests/golden/h5_latest.h5             the same library told to use its LATEST format (superblock 3, version-2 object headers,
                                        link messages, version-4 layouts; a 20-member group in dense storage): what the reader
                                        takes of it and what it must refuse by name
@@ -108,6 +110,55 @@ def write_keras_full_model(path, npz_path):
     np.savez(npz_path, **expect)
 
 
+def write_keras_evalnet(path, npz_path):
+    """evalnet.get_evalnet_miou (evalnet.py:48-73) at alpha 0.5, 64x64 (the smallest the six poolings allow), inputs of 3 and 2 channels, normalize_A only: the full-model layout
+    with `layer_names` in the order of Keras' model.layers (by depth: the two towers interleave), Lambda / Input layers in model_config"""
+    rs = np.random.RandomState(20241005)
+    f16, chans = 8, [8, 16, 32, 64, 128]
+    layers = [("input_1", "InputLayer", [], {"name": "input_1", "batch_input_shape": [None, 64, 64, 3]}, []),
+              ("input_2", "InputLayer", [], {"name": "input_2", "batch_input_shape": [None, 64, 64, 2]}, []),
+              ("lambda", "Lambda", [], {"name": "lambda"}, [[["input_1", 0, 0, {}]]])]
+    conv = lambda nm, k, ci, co, inb: (nm, "Conv2D", [("kernel:0", (k, k, ci, co)), ("bias:0", (co,))], {"name": nm, "filters": co}, [[[inb, 0, 0, {}]]])
+    bn = lambda nm, c, inb: (nm, "BatchNormalization", [("gamma:0", (c,)), ("beta:0", (c,)), ("moving_mean:0", (c,)), ("moving_variance:0", (c,))],
+                            {"name": nm}, [[[inb, 0, 0, {}]]])
+    # model.layers order: depth first, creation order inside a depth
+    layers += [conv("conv2d", 1, 3, f16, "lambda"), conv("conv2d_3", 1, 2, f16, "input_2"), bn("batch_normalization", f16, "conv2d"),
+               bn("batch_normalization_2", f16, "conv2d_3"), conv("conv2d_1", 3, f16, f16, "batch_normalization"),
+               conv("conv2d_4", 3, f16, f16, "batch_normalization_2"), conv("conv2d_2", 1, f16, f16, "conv2d_1"), conv("conv2d_5", 1, f16, f16, "conv2d_4"),
+               bn("batch_normalization_1", f16, "conv2d_2"), bn("batch_normalization_3", f16, "conv2d_5"),
+               ("max_pooling2d", "MaxPooling2D", [], {"name": "max_pooling2d"}, [[["batch_normalization_1", 0, 0, {}]]]),
+               ("max_pooling2d_1", "MaxPooling2D", [], {"name": "max_pooling2d_1"}, [[["batch_normalization_3", 0, 0, {}]]]),
+               ("concatenate", "Concatenate", [], {"name": "concatenate"}, [[["max_pooling2d", 0, 0, {}], ["max_pooling2d_1", 0, 0, {}]]])]
+    prev, ci, nc, nb = "concatenate", 2 * f16, 6, 4
+    for i, co in enumerate(chans):
+        layers += [conv(f"conv2d_{nc}", 3, ci, co, prev), conv(f"conv2d_{nc + 1}", 1, co, co, f"conv2d_{nc}"), bn(f"batch_normalization_{nb}", co, f"conv2d_{nc + 1}"),
+                   (f"max_pooling2d_{i + 2}", "MaxPooling2D", [], {"name": f"max_pooling2d_{i + 2}"}, [[[f"batch_normalization_{nb}", 0, 0, {}]]])]
+        prev, ci, nc, nb = f"max_pooling2d_{i + 2}", co, nc + 2, nb + 1
+    layers += [("global_average_pooling2d", "GlobalAveragePooling2D", [], {"name": "global_average_pooling2d"}, [[[prev, 0, 0, {}]]])]
+    for nm in ("iou", "detection"):
+        layers.append((nm, "Dense", [("kernel:0", (chans[-1], 2)), ("bias:0", (2,))], {"name": nm, "units": 2, "activation": "sigmoid"},
+                       [[["global_average_pooling2d", 0, 0, {}]]]))
+    expect = {}
+    with h5py.File(path, "w") as f:
+        f.attrs["keras_version"] = "2.10.0"
+        f.attrs["backend"] = "tensorflow"
+        f.attrs["model_config"] = json.dumps({"class_name": "Functional", "config": {
+            "name": "model_2", "layers": [{"class_name": cls, "config": c, "name": nm, "inbound_nodes": inb} for nm, cls, _, c, inb in layers],
+            "input_layers": [["input_1", 0, 0], ["input_2", 0, 0]], "output_layers": [["iou", 0, 0], ["detection", 0, 0]]}})
+        g = f.create_group("model_weights")
+        g.attrs["layer_names"] = np.array([nm.encode() for nm, *_ in layers])
+        g.attrs["backend"] = b"tensorflow"
+        g.attrs["keras_version"] = b"2.10.0"
+        for nm, cls, ws, _, _ in layers:
+            lg = g.create_group(nm)
+            lg.attrs["weight_names"] = np.array([f"{nm}/{wn}".encode() for wn, _ in ws]) if ws else np.zeros((0,), "S1")
+            for wn, shape in ws:
+                a = (rs.uniform(0.5, 1.5, shape) if wn.startswith("moving_variance") else rs.standard_normal(shape) * 0.3).astype(np.float32)
+                lg.create_dataset(f"{nm}/{wn}", data=a)
+                expect[f"{nm}/{wn}"] = a
+    np.savez(npz_path, **expect)
+
+
 def write_cases(path, npz_path):
     rs = np.random.RandomState(7)
     exp = {}
@@ -171,7 +222,8 @@ def write_latest(path):
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     write_latest(os.path.join(GOLD, "h5_latest.h5"))
+    write_keras_evalnet(os.path.join(GOLD, "h5_keras_evalnet.h5"), os.path.join(GOLD, "h5_keras_evalnet.npz"))
     write_keras_full_model(os.path.join(GOLD, "h5_keras_full_model.h5"), os.path.join(GOLD, "h5_keras_full_model.npz"))
     write_cases(os.path.join(GOLD, "h5_cases.h5"), os.path.join(GOLD, "h5_cases.npz"))
-    for n in ("h5_keras_full_model.h5", "h5_keras_full_model.npz", "h5_cases.h5", "h5_cases.npz", "h5_latest.h5"):
+    for n in ("h5_keras_full_model.h5", "h5_keras_full_model.npz", "h5_cases.h5", "h5_cases.npz", "h5_latest.h5", "h5_keras_evalnet.h5", "h5_keras_evalnet.npz"):
         print(n, os.path.getsize(os.path.join(GOLD, n)), "bytes; h5py", h5py.__version__, "libhdf5", h5py.version.hdf5_version)
