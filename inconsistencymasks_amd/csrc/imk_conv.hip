@@ -465,13 +465,16 @@ __global__ __launch_bounds__(256, (DYN && NC8 == 1) ? 4 : 1) void conv_pipe_kern
     constexpr int NCI = PRE ? PRE : NC8;        // chunks per pixel of the STAGED tensor (PRE: the 1x1's input)
     constexpr int PSI = imk_lds_pitch(NCI);
     constexpr int MAX_ITEMS = (18 * 18 * NCI + 255) / 256;
-    constexpr int MAX_NS = PAIR ? (9 * NC8 + 1) / 2 : (9 * NC8 + 3) / 4;
+    constexpr int MAX_NS = PAIR ? 3 * NC8 : (9 * NC8 + 3) / 4;       // (PAIR 1x1: (NC8 + 1) / 2 <= 3 NC8)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ks3 = (a.ksize == 3);
     const int halo = ks3 ? 1 : 0;
     const int HT = 16 + 2 * halo, WT = TW + 2 * halo;
     const int n_items = HT * WT * NCI;
-    const int nq = (ks3 ? 9 : 1) * NC8, ns = PAIR ? (nq + 1) / 2 : (nq + 3) / 4;
+    // PAIR, 3x3: the block's two tile rows are vertically adjacent, so they share 2 of their 3 input rows -- the k-slots are the UNION of
+    // their taps, 4 input rows x 3 columns = 12 (tap, chunk) slots per chunk: 3 NC8 k-steps instead of ceil(9 NC8 / 2) (NC8 = 1: 3, not 5)
+    const bool shared_taps = PAIR && ks3;
+    const int nq = (shared_taps ? 12 : (ks3 ? 9 : 1)) * NC8, ns = shared_taps ? 3 * NC8 : (PAIR ? (nq + 1) / 2 : (nq + 3) / 4);
     uint8_t *s_tile = smem;
     uint8_t *s_t0 = smem + pipe_lds_base(NC8, PAIR, WG);                          // PRE: the staged input of the 1x1, [pixel][PSI]
     float *s_pre = reinterpret_cast<float *>(s_t0 + 18 * 18 * PSI * 16);          // PRE: [bias | scale | shift][16]
@@ -496,16 +499,16 @@ __global__ __launch_bounds__(256, (DYN && NC8 == 1) ? 4 : 1) void conv_pipe_kern
     // those lanes simply read offset 0 (no per-read select).
 #pragma unroll
     for (int s = 0; s < MAX_NS; ++s) {
-        const int q = PAIR ? 2 * s + (g & 1) : 4 * s + g;
+        const int q = (PAIR && !shared_taps) ? 2 * s + (g & 1) : 4 * s + g;
         const bool vq = (s < ns) && (q < nq);
-        const int tap = q / NC8, c8 = q - tap * NC8;
+        const int tap = q / NC8, c8 = q - tap * NC8;          // shared taps: tap = (input row 0..3 of the pair's window) * 3 + column
         const int ty = ks3 ? tap / 3 : 0, tx = ks3 ? tap - 3 * (tap / 3) : 0;
         off[s] = vq ? ((ty * WT + tx) * PS + c8) * 16 : 0;
         af[s] = (s < ns) ? *reinterpret_cast<const f16x8 *>(a.wpk + ((size_t)s * 64 + lane) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     int base[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) base[p] = (tile_row(p) * WT + n) * PS * 16;
+    for (int p = 0; p < P; ++p) base[p] = ((shared_taps ? wave * 4 + 2 * p : tile_row(p)) * WT + n) * PS * 16;   // shared taps: from the pair's upper row
     // this thread's staging items (constant over tiles): LDS offset and position inside the halo tile.  Idle slots
     // (beyond the tile's item count) repeat slot 0's pixel, so that their (unconditional) load is a cache hit.
     int it_lds[MAX_ITEMS], it_py[MAX_ITEMS], it_px[MAX_ITEMS], it_c8[MAX_ITEMS];
@@ -1600,7 +1603,29 @@ __global__ __launch_bounds__(256) void pack_conv_batched_kernel(ImkPackJobs jobs
     }
     const int T = jb.ksize == 3 ? 9 : 1;
     const int m_dim = jb.transposed ? jb.cin : jb.cout, k_dim = jb.transposed ? jb.cout : jb.cin;
-    if (jb.pair) {              // one 16-row block, k-step s: group g carries (tap, chunk) pair q = 2s + (g & 1) of row g >> 1
+    if (jb.pair && T == 9) {    // 3x3, pair layout with shared taps (conv_pipe_kernel): k-step s, group g carry slot q = 4s + g =
+        // (window row r = 0..3, column c, chunk) of the 4 x 3 window the pair's two pixel rows read; accumulator rows 0-7 are the
+        // upper pixel row's channels (kernel row r), rows 8-15 the lower one's (kernel row r - 1): zero where that is outside 0..2
+        const int nc8 = ((k_dim + 7) & ~7) / 8;
+        const int ns = 3 * nc8;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * 512; i += gridDim.x * 256) {
+            const int j = i & 7, lane = (i >> 3) & 63, st = i >> 9;
+            const int m = lane & 15, g = lane >> 4;
+            const int q = 4 * st + g;
+            const int ut = q / nc8, c8 = q - ut * nc8;
+            const int r = ut / 3, c = ut - 3 * r, ky = r - (m >> 3);
+            const int mi = m & 7, ki = c8 * 8 + j;
+            float v = 0.f;
+            if (ky >= 0 && ky <= 2 && mi < m_dim && ki < k_dim) {
+                const int tap = ky * 3 + c;
+                if (!jb.transposed) v = jb.w[((size_t)tap * jb.cin + ki) * jb.cout + mi];
+                else v = jb.w[((size_t)(T - 1 - tap) * jb.cin + mi) * jb.cout + ki];
+            }
+            jb.dst[i] = (f16)v;
+        }
+        return;
+    }
+    if (jb.pair) {              // 1x1: one 16-row block, k-step s: group g carries chunk q = 2s + (g & 1) of row g >> 1
         const int nc8 = ((k_dim + 7) & ~7) / 8;
         const int nq = T * nc8, ns = (nq + 1) / 2;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * 512; i += gridDim.x * 256) {
@@ -2405,7 +2430,7 @@ size_t imk_packed_conv_halfs(int ksize, int cin, int cout, int transposed, bool 
     const int T = ksize == 3 ? 9 : 1;
     const int m_dim = transposed ? cin : cout, k_dim = transposed ? cout : cin;
     const int nc8 = imk_pad8(k_dim) / 8;
-    if (pair) return (size_t)((T * nc8 + 1) / 2) * 512;
+    if (pair) return (size_t)(T == 9 ? 3 * nc8 : (nc8 + 1) / 2) * 512;
     const int nc8p = imk_pass_chunks(nc8);
     const int ns = imk_cdiv_d(nc8, nc8p) * ((T * nc8p + 3) / 4);
     return (size_t)((m_dim + 15) / 16) * ns * 512;
