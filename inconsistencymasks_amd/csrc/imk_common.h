@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // rounded to fp32 first, then to fp16) site by site -- and, inside one kernel, channel by channel: 1e-4 of the values then differ by
 // an fp16 ulp between a fused launch and its two-launch form (round 2-3's "border pixel" discrepancy of the decoder's first-stage
 // launch).  Round 4 first pinned every site to the two-rounding form (4 instructions per pair, a third of the
-// VALU work of the inference kernels, which are VALU-bound); this is the same pin on the cheaper and more accurate instruction.
+// vector instructions of the inference kernels); this is the same pin on the cheaper and more accurate instruction.
 __device__ __forceinline__ f16x2 imk_affine2(f16x2 z, f32x2 sc, f32x2 sh) {
     f16x2 d;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
@@ -38,9 +38,6 @@ __device__ __forceinline__ f16 imk_affine1(f16 z, float sc, float sh) {
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(zz), "v"(sc), "v"(sh));
     return d[0];
 }
-// relu(acc + bias) rounded to fp16, four channels at a time: v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_max_f16 -- 1.5 instructions per
-// value instead of 3 (add, max, convert).  Rounding is monotonic and keeps the sign, so max-after-rounding gives the value
-// max-before-rounding gives (a sum that rounds to -0 yields +0 either way: v_pk_max_f16 orders -0 below +0).
 // v_pk_max_f16 as written: through __builtin_elementwise_max the compiler first "canonicalises" operands it cannot see through
 // (the asm results above) with a v_pk_max_f16 x, x each -- 7 instructions per pair for a 4-way maximum instead of 3
 __device__ __forceinline__ f16x2 imk_pk_max(f16x2 a, f16x2 b) {
@@ -61,6 +58,9 @@ __device__ __forceinline__ f16x8 imk_affine_pool8(f16x8 z0, f16x8 z1, f16x8 z2, 
     }
     return o;
 }
+// relu(acc + bias) rounded to fp16, four channels at a time: v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_max_f16 -- 1.5 instructions per
+// value instead of 3 (add, max, convert).  Rounding is monotonic and keeps the sign, so max-after-rounding gives the value
+// max-before-rounding gives (a sum that rounds to -0 yields +0 either way: v_pk_max_f16 orders -0 below +0).
 __device__ __forceinline__ f16x2 imk_bias_relu2(f32x2 acc, f32x2 bias) {
     return __builtin_elementwise_max(__builtin_convertvector(acc + bias, f16x2), f16x2{0, 0});
 }
