@@ -86,12 +86,12 @@ def main():
 | `r04_configs_step_times.txt`, `r04_step_vs_batch.txt` | wall time of a training step (batch 32) and a 128-image inference call, all shapes and the IM+ width schedule; the ISIC step against the batch size: T(B) = 0.55 ms + B x 14.9 us |
 | `r04_step_timeline_*.txt`, `r04_step_timeline_single_stream_*.txt` | kernel-by-kernel timeline of one step and one inference call (two streams / every kernel alone) for ISIC, SUIM, Cityscapes alpha 1 and 2 |
 | `r04_sq_counters_{isic,city_a2}.csv` | SQ counters per kernel (after the LDS-pitch change) |
-| `r04_full_driver_run.txt`, `r04_full_driver_run_parallel3.txt` | `ISIC_2018/09_ISIC_2018_IM.py` through PNG directories at the dataset's real size, sequential candidates and `IM_PARALLEL_CANDIDATES=3` on the same box: 37.0 -> 30.6 s per generation (candidates 31.4 -> 25.0 s), identical CSVs |
+| `r04_full_driver_run.txt`, `r04_full_driver_run_parallel3.txt` | `ISIC_2018/09_ISIC_2018_IM.py` through PNG directories at the dataset's real size, sequential candidates and `IM_PARALLEL_CANDIDATES=3` on the same box: 35.3 -> 28.9 s per generation on the final build (37.0 -> 30.6 mid-round), identical CSVs; `r04_full_driver_run_keras_h5.txt`: the same with HDF5 model files (35.1 s) |
 """)
     rb = load("r04_bench_under_rocprof.json") or b
     out.append(f"""Headline (`r04_bench.json`): **{b['value']:.0f} images/s per IM generation on 1 GPU** -- {b['ms_per_step']} ms per generation =
 {b['stage_ms']['ensemble_infer_plus_im']} ms (ensemble forward + fused head/IM) + {b['stage_ms']['train_epoch']} ms ({b['config']['epoch_steps']} training steps of {r['step']['train_step']['ms']} ms; this round's
-ensemble keeps {b['config'].get('kept')} of the 2 335 pseudo-labelled pairs, round 3's kept 2 317: 77 instead of 80 steps) -- next to
+ensemble keeps {b['config'].get('kept')} of the 2 335 pseudo-labelled pairs -- 2 225 to 2 326 over the round's builds, i.e. 77 or 80 steps: compare per step) -- next to
 {cb['value']} images/s for the CPU restatement ({cb['cpu_model']}, {cb['threads_forward']} / {cb['threads_train_step']} threads, {cb['gflops_forward_batch1']} / {cb['gflops_train_step']} GFLOP/s:
 not a tuned CPU library).  Round 3 ended at 23 942 (97.53 ms, 1.0177 ms per step).  `cpu_baseline.parity_sample`: max |dp| {ps['max_abs_dp']} on the
 trained ensemble, {ps['fixed_weights'].get('max_abs_dp')} on fixed weights (the round-to-round figure), {ps['decision_flip_rate']:.1e} of the decisions flip,
@@ -102,7 +102,7 @@ events ({r['avg_us_per_launch']} us per launch incl. the launch boundary), **{r[
 {r['avg_algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic in the sampled launches (`r04_traffic_vs_algorithmic.csv`: 0.99x over the family); host time to
 enqueue one training step {r['step']['train_step']['host_enqueue_ms_per_step']} ms (GPU: {r['step']['train_step']['ms']}).  The family average hides two regimes (timed-region table
 below): the training variants run at 0.41-0.59 of 8 TB/s (the 1x1 dgrad + fused weight gradient 4.7 TB/s, the e1 / d9 forward 4.5),
-the three VALU-bound inference variants at 0.16-0.24.
+the three big inference variants at 0.20-0.29 (0.16-0.24 before the instruction-count, occupancy and shared-tap changes of `r04_notes.md`).
 """)
     tr = list(csv.DictReader(open(os.path.join(HERE, "r04_timed_region_kernel_stats.csv"))))
     out.append("Inside the timed region, rocprofv3's own durations (`r04_timed_region_kernel_stats.csv`, top 14 by time):\n")
