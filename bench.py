@@ -523,7 +523,7 @@ def run_config(args, config_name, alpha, env, primary):
         models.append(m)
     ens = F.EnsembleIM(models)
     student = UNet(H, W, C, K, ALPHA, ACT, seed=7, device=dev)
-    bn_rule, bn_mom = F.dp_bn_momentum_rule(world)      # > 1 rank: 0.99^N unless IMK_DP_BN_MOMENTUM=reference (functions.py)
+    bn_rule, bn_mom = F.dp_bn_momentum_rule(world)      # Keras' 0.99 at any world size; IMK_DP_BN_MOMENTUM=scaled: 0.99^N (functions.py)
     student.set_bn_momentum(bn_mom)
     init_params = student.params.clone()
     gen_perm = torch.Generator(device=dev).manual_seed(42 + rank)

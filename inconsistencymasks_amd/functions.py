@@ -109,14 +109,14 @@ def _pool():
 # writer, and -- for the prediction dumps of benchmark_*, which nothing in the pipeline reads back -- the next candidate's
 # training.  Writers flush before they return (callers list their output directories); everything is flushed at exit.
 _WRITE_POOL = None
-_PENDING = []
+_PENDING = {}                                       # thread id -> futures that thread queued
 _PENDING_LOCK = __import__("threading").Lock()      # candidates training on threads (im_driver) queue writes concurrently
 
 
 def write_png_async(path, arr):
     with _PENDING_LOCK:
         _ensure_write_pool()
-        _PENDING.append(_WRITE_POOL.submit(write_png, path, arr))
+        _PENDING.setdefault(__import__("threading").get_ident(), []).append(_WRITE_POOL.submit(write_png, path, arr))
 
 
 def _ensure_write_pool():
@@ -131,7 +131,7 @@ def _flush_at_exit():
     """the interpreter ignores exceptions of atexit handlers (the process would still exit 0 with files missing): a failed write
     that only surfaces here ends the process with status 1"""
     try:
-        flush_writes()
+        flush_writes(all_threads=True)
     except BaseException:      # noqa: BLE001 -- report and fail, whatever it was
         import sys
         import traceback
@@ -140,10 +140,14 @@ def _flush_at_exit():
         os._exit(1)
 
 
-def flush_writes():
-    """wait for every queued PNG write (re-raising the first failure)"""
-    with _PENDING_LOCK:      # (candidates training on threads queue writes concurrently)
-        pending, _PENDING[:] = list(_PENDING), []
+def flush_writes(all_threads=False):
+    """wait for the PNG writes THIS thread queued (re-raising the first failure): a candidate training on a thread of its own
+    (IM_PARALLEL_CANDIDATES) waits for and reports its own files, not another candidate's.  all_threads=True (the driver after it
+    has joined its candidate threads; interpreter exit) waits for everything."""
+    me = __import__("threading").get_ident()
+    with _PENDING_LOCK:
+        keys = list(_PENDING) if all_threads else [me]
+        pending = [f for k in keys for f in _PENDING.pop(k, [])]
     for f in pending:
         f.result()
 
@@ -666,25 +670,35 @@ def _grad_allreduce(model):
 def dp_bn_momentum_rule(world=None):
     """(rule name, momentum) of the BatchNorm moving statistics for a run of `world` ranks.
 
-    Data-parallel runs keep the reference's per-GPU batch of 32, so an epoch has N times fewer optimizer steps -- and Keras'
-    BatchNorm moving statistics (momentum 0.99 PER STEP) need ~500 steps to forget their initial values: at 8 ranks that is the
-    whole 50-epoch schedule, and the validation metric that picks the checkpoint lags (profiles/r03_dp_convergence.txt: val IoU
-    0.989 instead of 0.9998 after 50 epochs, ~0 until epoch 20).  With more than one rank the default is therefore "scaled":
-    momentum 0.99^N, the same memory in SAMPLES as the single-GPU recipe (0.9994 at 8 ranks).  IMK_DP_BN_MOMENTUM=reference
-    keeps Keras' 0.99 per step at any world size (unet.py:7 leaves the layer's default); "scaled" can be forced the same way.
-    One rank is always the reference's recipe."""
+    Default at ANY world size: the reference's recipe, Keras' momentum 0.99 per optimizer step (unet.py:7 leaves the layer's
+    default) -- a data-parallel run trains the same model definition as one rank, and 1-rank and N-rank results are comparable
+    under one rule.  What that costs at 8 ranks is measured (profiles/r03_dp_convergence.txt): the per-GPU batch stays 32, an epoch
+    has N times fewer steps, the moving statistics need ~500 steps to forget their initial values, and the validation metric that
+    picks the checkpoint lags (val IoU 0.989 instead of 0.9998 after 50 epochs).  IMK_DP_BN_MOMENTUM=scaled opts into momentum
+    0.99^N -- the same memory in SAMPLES as the single-GPU recipe (0.9994 at 8 ranks) -- a stated deviation from the reference;
+    fit() prints one line per process group naming the rule in force.  One rank is always 0.99."""
     if world is None:
         _, world = _rank_world()
     mode = os.environ.get("IMK_DP_BN_MOMENTUM", "").lower()
     if mode not in ("", "scaled", "reference"):
         raise ValueError(f"IMK_DP_BN_MOMENTUM={mode!r}: expected 'scaled' or 'reference'")
-    if world > 1 and mode != "reference":
+    if world > 1 and mode == "scaled":
         return "scaled", 0.99 ** world
     return "reference", 0.99
 
 
+_DP_RULE_SAID = [False]
+
+
 def _dp_bn_momentum(model):
-    model.set_bn_momentum(dp_bn_momentum_rule()[1])
+    rule, mom = dp_bn_momentum_rule()
+    model.set_bn_momentum(mom)
+    rank, world = _rank_world()
+    if world > 1 and rank == 0 and not _DP_RULE_SAID[0]:
+        _DP_RULE_SAID[0] = True
+        print(f"[imk] data parallel, {world} ranks: BatchNorm momentum rule '{rule}' = {mom:.6f} per step"
+              + ("" if rule == "scaled" else " (the reference's; IMK_DP_BN_MOMENTUM=scaled keeps the moving statistics' memory in samples)"),
+              flush=True)
 
 
 def fit(model, loader, steps_per_epoch, epochs, loss_kind, on_epoch_end=None, lr=None, wd=None):
@@ -756,6 +770,16 @@ def _uploaded(*tensors):
     return tensors
 
 
+def _used_here(tensors):
+    """Cached device tensors are allocated on the filling thread's stream and read on every candidate thread's stream
+    (IM_PARALLEL_CANDIDATES): tell the caching allocator, so that an evicted block is not handed out again on its original
+    stream while kernels queued on another one still read it."""
+    cur = torch.cuda.current_stream()
+    for t in tensors:
+        t.record_stream(cur)
+    return tensors
+
+
 # Decoded benchmark sets (images + ground truth of the val / test / unlabeled splits) stay on the device across the
 # candidates of a generation: every candidate is evaluated on the same three directories (functions.py:221-226), and
 # decoding them again costs more than evaluating them.  Keyed by the files' names, sizes and modification times; bounded
@@ -773,7 +797,7 @@ def _decoded_set(pool, dirs_and_channels, names):
     with _CACHE_LOCK:       # (candidates on threads: one decodes, the others wait for it instead of decoding the same files again)
         hit = _DECODE_CACHE.get(key)
         if hit is not None:
-            return hit
+            return _used_here(hit)
         out = []
         for d, c in dirs_and_channels:
             arrs = list(pool.map(lambda n: read_png(os.path.join(d, n), c), names))
@@ -799,7 +823,7 @@ def _binary_iou_dataset(model, images_dir, masks_dir, c, batch=64):
                 items = list(pool.map(lambda p: parse_image_ISIC_2018(p, c), files))
             _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
                                         torch.from_numpy(np.stack([it[1] for it in items], 0)[..., 0]).cuda())
-        xs, ys = _VAL_CACHE[key]
+        xs, ys = _used_here(_VAL_CACHE[key])
     inter = union = 0
     for i in range(0, len(files), batch):
         _, cnt = _ev.eval_binary(model.predict_device(xs[i:i + batch]), ys[i:i + batch], 0.5, True, want_pred=False)
@@ -979,7 +1003,7 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
                     items = list(pool.map(lambda p: parse_image_multiclass(p, n_classes, c), val_files))
                 _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
                                             torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
-            xs, ys = _VAL_CACHE[key]
+            xs, ys = _used_here(_VAL_CACHE[key])
         for i in range(0, len(val_files), BATCH_SIZE):      # per-batch IoU, averaged over the batches (functions.py:82-90)
             metric.update_state(ys[i:i + BATCH_SIZE], model.predict_device(xs[i:i + BATCH_SIZE]))
         v = metric.result()
@@ -1281,7 +1305,7 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
                     items = list(pool.map(lambda p: parse_image_hela(p, c), val_files))
                 _VAL_CACHE[key] = _uploaded(torch.from_numpy(np.stack([it[0] for it in items], 0)).cuda(),
                                             torch.from_numpy(np.stack([it[1] for it in items], 0)).cuda())
-            xs, ys = _VAL_CACHE[key]
+            xs, ys = _used_here(_VAL_CACHE[key])
         sq, n = 0.0, 0
         for i in range(0, len(val_files), BATCH_SIZE):
             y = ys[i:i + BATCH_SIZE]

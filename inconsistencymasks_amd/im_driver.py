@@ -108,6 +108,19 @@ def _ints(name, default):
     return [int(x) for x in v.split(",")] if v else default
 
 
+_CAND_STREAMS = {}
+
+
+def _candidate_streams(n):
+    """n streams per device for IM_PARALLEL_CANDIDATES, created once: a fresh Stream per candidate would leave its freed blocks in a
+    dead stream's pool of the caching allocator until an out-of-memory flush."""
+    dev = torch.cuda.current_device()
+    pool = _CAND_STREAMS.setdefault(dev, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream())
+    return pool[:n]
+
+
 def run(dataset, approach="IM", parallel_candidates=None):
     ds = DATASETS[dataset]
     S = F.config[ds["section"]]
@@ -226,14 +239,24 @@ def run(dataset, approach="IM", parallel_candidates=None):
                     from concurrent.futures import ThreadPoolExecutor
                     dev_index = torch.cuda.current_device()
 
+                    import queue
+                    free = queue.SimpleQueue()                    # a fixed set of streams, reused over candidates and generations;
+                    for st in _candidate_streams(par):            # a worker holds one for the whole candidate
+                        free.put(st)
+
                     def worker(i):
                         torch.cuda.set_device(dev_index)          # the current device is per thread
-                        with torch.cuda.stream(torch.cuda.Stream()):
-                            row = train_candidate(i, True)
-                            torch.cuda.current_stream().synchronize()
+                        st = free.get()
+                        try:
+                            with torch.cuda.stream(st):
+                                row = train_candidate(i, True)
+                                st.synchronize()
+                        finally:
+                            free.put(st)
                         return row
                     with ThreadPoolExecutor(max_workers=par) as pool:
                         rows = list(pool.map(worker, cands))
+                    F.flush_writes(all_threads=True)              # every candidate's prediction PNGs are on disk
                     tick(f"{len(cands)} candidates, {par} side by side: training + 3 benchmarks each")
                 else:
                     rows = []
@@ -248,13 +271,15 @@ def run(dataset, approach="IM", parallel_candidates=None):
                         os.rename(os.path.join(model_dir, f"{row[0]}.h5"), os.path.join(model_dir, f"{row[0][:-2]}_topK_{i}.h5"))
                     os.makedirs(csv_dir, exist_ok=True)
                     with open(os.path.join(csv_dir, f"results_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
-                        if world > 1:       # one rank writes exactly the reference's file; a data-parallel run says what differed
-                            rule, mom = F.dp_bn_momentum_rule(world)
-                            f.write(f"# data parallel: {world} ranks x batch {batch} per rank, BatchNorm momentum rule '{rule}' = {mom:.6f} "
-                                    "(IMK_DP_BN_MOMENTUM; functions.dp_bn_momentum_rule)\n")
                         wr = csv.writer(f, delimiter=";")
                         wr.writerow(ds["header"])
                         wr.writerows(rows)
+                    if world > 1:       # the CSV stays byte-compatible with the reference's; what a data-parallel run did differently
+                        import json     # goes into a sidecar file
+                        rule, mom = F.dp_bn_momentum_rule(world)
+                        with open(os.path.join(csv_dir, f"results_{modelname}.meta.json"), "w", encoding="utf-8") as f:
+                            json.dump({"data_parallel_ranks": world, "batch_per_rank": batch, "bn_momentum_rule": rule,
+                                       "bn_momentum": round(mom, 6), "env": "IMK_DP_BN_MOMENTUM"}, f)
                     with open(os.path.join(csv_dir, f"mean_im_size_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
                         wr = csv.writer(f, delimiter=";")
                         wr.writerow(["val_mean_im_size", "test_mean_im_size", "unlabeled_mean_im_size"])

@@ -488,16 +488,17 @@ def test_package_import_raises_the_hardware_queue_limit():
 
 
 def test_dp_bn_momentum_rule(monkeypatch):
-    """One rank: Keras' 0.99 per step.  More ranks: 0.99^N by default (the moving statistics keep their memory in samples;
-    profiles/r03_dp_convergence.txt), 0.99 again under IMK_DP_BN_MOMENTUM=reference."""
+    """Keras' 0.99 per step at any world size unless IMK_DP_BN_MOMENTUM=scaled opts into 0.99^N (the moving statistics keep
+    their memory in samples; profiles/r03_dp_convergence.txt); one rank is always the reference's recipe."""
     from inconsistencymasks_amd import functions as F
     monkeypatch.delenv("IMK_DP_BN_MOMENTUM", raising=False)
     assert F.dp_bn_momentum_rule(1) == ("reference", 0.99)
-    name, m = F.dp_bn_momentum_rule(8)
-    assert name == "scaled" and abs(m - 0.99 ** 8) < 1e-12
+    assert F.dp_bn_momentum_rule(8) == ("reference", 0.99)
     monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "reference")
     assert F.dp_bn_momentum_rule(8) == ("reference", 0.99)
     monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "scaled")
+    name, m = F.dp_bn_momentum_rule(8)
+    assert name == "scaled" and abs(m - 0.99 ** 8) < 1e-12
     assert F.dp_bn_momentum_rule(1) == ("reference", 0.99) and F.dp_bn_momentum_rule(2)[0] == "scaled"
     monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "bogus")
     with pytest.raises(ValueError):

@@ -1,5 +1,6 @@
 """End-to-end run of the ISIC IM driver on a toy dataset (1 run id, n = 2, generations 0 and 1, 2 candidates):
 the file/model/CSV naming and the top-K hand-off of ISIC_2018/09_ISIC_2018_IM.py:59-153."""
+import json
 import os
 import subprocess
 import sys
@@ -653,11 +654,13 @@ def test_isic_driver_two_ranks_on_one_gpu(tmp_path):
     models = sorted(os.listdir(outs[2] / "models"))
     assert stem + "_topK_1.h5" in models and stem + "_topK_2.h5" in models
     rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
-    # a data-parallel run names its BatchNorm momentum rule in a leading comment (default with > 1 rank: 0.99^N); one rank writes the
-    # reference's file as it is
-    assert rows[0].startswith("# data parallel: 2 ranks") and "'scaled' = 0.980100" in rows[0]
-    assert not (outs[1] / "csv" / f"results_{stem}.csv").read_text().startswith("#")
-    rows = rows[1:]
+    # the CSV is the reference's format at any world size (header on line 1); a data-parallel run names its BatchNorm momentum rule
+    # (default: the reference's 0.99 per step) in a sidecar file
+    assert not rows[0].startswith("#")
+    assert rows[0] == (outs[1] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()[0]
+    meta = json.loads((outs[2] / "csv" / f"results_{stem}.meta.json").read_text())
+    assert meta["data_parallel_ranks"] == 2 and meta["bn_momentum_rule"] == "reference" and meta["bn_momentum"] == 0.99
+    assert not (outs[1] / "csv" / f"results_{stem}.meta.json").exists()
     assert len(rows) == 3 and all(0.0 <= float(v) <= 1.0 for v in rows[1].split(";")[1:])
     # every validation / test prediction was written exactly once although the benchmarks were sharded
     assert len(os.listdir(outs[2] / "val_predictions" / "IM" / (stem + "_0"))) == 8
@@ -673,13 +676,13 @@ def test_suim_and_hela_drivers_two_ranks_on_one_gpu(tmp_path):
     a, b = (outs[w] / "train_unlabeled_predictions" / "IM" / stem for w in (1, 2))
     _same_png_tree(a, b, ("im", "images", "masks"), {"images": 3})
     assert (outs[1] / "csv" / f"mean_im_size_{stem}.csv").read_text() == (outs[2] / "csv" / f"mean_im_size_{stem}.csv").read_text()
-    rows = [r for r in (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines() if not r.startswith("#")]
+    rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(rows) == 3 and all(0.0 <= float(v) <= 1.0 for v in rows[1].split(";")[1:])
     outs = _run_one_and_two_ranks(tmp_path / "hela", HELA_CONFIG, HELA_SETUP, os.path.join(ROOT, "HeLa", "09_HeLa_IM.py"))
     stem = "HELA_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
     a, b = (outs[w] / "train_unlabeled_predictions" / "IM" / stem for w in (1, 2))
     _same_png_tree(a, b, ("im", "brightfield", "alive", "dead", "mod_position"), {"mod_position": 3})
-    rows = [r for r in (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines() if not r.startswith("#")]
+    rows = (outs[2] / "csv" / f"results_{stem}.csv").read_text().strip().splitlines()
     assert len(rows) == 3 and len(rows[1].split(";")) == 10
 
 
