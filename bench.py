@@ -567,12 +567,20 @@ def run_config(args, config_name, alpha, env, primary):
     host_enqueue = []
     step_events = []
     last_batch = []
+    stage_marks = [False]       # timed region under rocprofv3: marker dispatches at the stage boundaries (profiles/summarize.py)
+    stage_snap = [None]         # one generation outside the timed region: the library's per-kernel totals after the inference stage
 
     def generation(record=None):
         e0, e1, e2 = ev(), ev(), ev()
+        if stage_marks[0]:
+            Profiler.mark(4)
         e0.record()
         ps, ims, keep = im_stage(x_unl)
         e1.record()
+        if stage_marks[0]:
+            Profiler.mark(3)
+        if stage_snap[0] is not None:
+            stage_snap[0]["inference"] = prof.totals_dump()
         # training set = kept pseudo-labelled pairs + labelled pairs (the directory the reference builds)
         if use_dist and world > 1:   # every rank must run the same number of gradient all-reduces: the smallest shard decides.
             # Issued BEFORE the keep rule's host sync below, so that the agreed count is there when the host wakes up: one
@@ -632,6 +640,7 @@ def run_config(args, config_name, alpha, env, primary):
         prof.totals(True)
         Profiler.mark(1)
         torch.cuda.synchronize()
+        stage_marks[0] = True      # two 64-thread marker dispatches per generation (~2 us each in a ~94 ms generation)
     t0 = time.perf_counter()
     # Sampling: an event record is a barrier packet on the stream (~5 us before the next kernel starts), so bracketing
     # every launch costs ~10 % of a training step; every 61st hooked launch (prime, coprime to the ~135 launches of a
@@ -641,12 +650,29 @@ def run_config(args, config_name, alpha, env, primary):
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_totals = None
+    stage_totals = None
     if primary and not args.no_prof:
+        stage_marks[0] = False
         Profiler.mark(2)
         kernel_totals = prof.totals_dump()
         prof.totals(False)
     pc, pms, pby, pfl = prof_collect()
     prof.set_period(0)
+    if primary and not args.no_prof:
+        # which kernel variants make up which stage (launches and algorithmic bytes per generation): one more generation, outside
+        # the clock, with the library's totals read at the stage boundary (host-side sums: no synchronisation involved)
+        prof.totals(True)
+        stage_snap[0] = {}
+        generation()
+        whole = prof.totals_dump()
+        prof.totals(False)
+        inf = stage_snap[0].get("inference", {})
+        stage_snap[0] = None
+        def _fmt(d):
+            return {k: {"launches": t["launches"], "MB_per_launch": round(t["bytes"] / max(t["launches"], 1) / 1e6, 3),
+                        "GFLOP_per_launch": round(t["flops"] / max(t["launches"], 1) / 1e9, 4)} for k, t in sorted(d.items()) if t["launches"]}
+        trn = {k: {f: t[f] - inf.get(k, {}).get(f, 0) for f in ("launches", "bytes", "flops")} for k, t in whole.items()}
+        stage_totals = {"inference": _fmt(inf), "training": _fmt(trn)}
     # host cost of enqueueing a step (fwd_bwd + all-reduce + adamw), outside the timed region: from an idle device, 8 steps at
     # a time (~1000 launches: inside an epoch the host runs ahead until the launch queue back-pressures it, which would
     # time the GPU, not the host)
@@ -710,7 +736,7 @@ def run_config(args, config_name, alpha, env, primary):
         import csv
         fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
         tag = "" if config_name == "isic" and alpha is None else f"_{config_name}" + (f"_a{alpha:g}" if alpha is not None else "")
-        for name in (f"r04_pmc_traffic{tag}.csv", f"r03_pmc_traffic{tag}.csv") + (("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if not tag else ()):
+        for name in (f"r05_pmc_traffic{tag}.csv", f"r04_pmc_traffic{tag}.csv", f"r03_pmc_traffic{tag}.csv") + (("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if not tag else ()):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -729,8 +755,9 @@ def run_config(args, config_name, alpha, env, primary):
     traffic_ratio, traffic_alg = None, None
     try:
         import csv
-        path = os.path.join(ROOT, "profiles", "r04_traffic_vs_algorithmic.csv")
-        if primary and traffic_src and "r04_pmc_traffic.csv" in traffic_src and os.path.exists(path):
+        rnd = traffic_src.split("profiles/")[1][:3] if traffic_src else "r05"
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_vs_algorithmic.csv")
+        if primary and traffic_src and f"{rnd}_pmc_traffic.csv" in traffic_src and os.path.exists(path):
             fam_row = [r for r in csv.reader(open(path)) if r and r[0].startswith("FAMILY")]
             if fam_row:
                 traffic_alg, traffic_ratio = round(1e6 * float(fam_row[0][2])), float(fam_row[0][4])
@@ -739,19 +766,26 @@ def run_config(args, config_name, alpha, env, primary):
     # The same fraction from rocprofv3's own durations: the family's launches INSIDE the timed region of the committed kernel trace
     # of this command (profiles/summarize.py cuts the trace at the marker dispatches) against this run's algorithmic bytes / flops
     frac_rocprof, rocprof_src, rocprof_us = None, None, None
+    timed_rows = []
     try:
         import csv
-        path = os.path.join(ROOT, "profiles", "r04_timed_region_kernel_stats.csv")
-        if primary and os.path.exists(path) and pc[v]:
+        for name in ("r05_timed_region_kernel_stats.csv", "r04_timed_region_kernel_stats.csv"):
+            path = os.path.join(ROOT, "profiles", name)
+            if primary and os.path.exists(path):
+                timed_rows = list(csv.DictReader(open(path)))
+                rocprof_src = (f"profiles/{name} (rocprofv3 --kernel-trace of this command, dispatches between the timed region's markers: "
+                               "sum over the family's variants of calls x algorithmic bytes / sum of their durations)")
+                break
+        if timed_rows and pc[v]:
             fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
             fams = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook
-            rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(fams)]
-            calls = sum(int(r["calls"]) for r in rows)
-            if calls:
-                rocprof_us = sum(int(r["calls"]) * float(r["avg_us"]) for r in rows) / calls
-                per_launch = (pfl[v] if mfma_bound else pby[v]) / pc[v]
-                frac_rocprof = round(per_launch / rocprof_us / (1e6 if mfma_bound else 1e3) / peak, 4)
-                rocprof_src = "profiles/r04_timed_region_kernel_stats.csv (rocprofv3 --kernel-trace of this command, dispatches between the timed region's markers)"
+            col = "GFLOP_per_launch" if mfma_bound else "algorithmic_MB_per_launch"
+            rows = [r for r in timed_rows if r["kernel"].startswith(fams) and r.get(col)]
+            work = sum(int(r["calls"]) * float(r[col]) for r in rows)                        # MB or GFLOP, exact (the library's own sums)
+            ms = sum(float(r["total_ms"]) for r in rows)
+            if ms:
+                rocprof_us = 1e3 * ms / sum(int(r["calls"]) for r in rows)
+                frac_rocprof = round(work / ms / peak, 4)     # MB / ms = GB/s; GFLOP / ms = TFLOP/s
     except Exception:
         pass
     whole_n = setup_prof[0][v] + pc[v]
@@ -792,6 +826,69 @@ def run_config(args, config_name, alpha, env, primary):
                         "the main-stream kernels, event-bracketed durations include that sharing; 'exclusive' = the same "
                         "workload with every kernel alone on one stream (the plans' single_stream switch).  bound = mfma for the "
                         "GEMM-class conv families (>= 33 channels: far above the fp16 ridge), hbm otherwise"}
+    # ---- per stage: the generation has two regimes, and one family name must not hide the weaker one ---------------------
+    # (a) T(B) = chain + B x per-image, fitted live on training steps of 8 / 16 / 32 images (lr = 0: the weights stay): the fixed part
+    #     is the dependent launch chain, the slope the kernels' per-image work
+    chain_ms = per_image_us = None
+    tb = {}
+    try:
+        for bsz in (8, 16, BATCH):
+            xb, yb = last_batch[0][:bsz], last_batch[1][:bsz]
+            for _ in range(3):
+                student.fwd_bwd(xb, yb, LOSS); student.adamw_step(0.0, 0.0)
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(20):
+                student.fwd_bwd(xb, yb, LOSS); student.adamw_step(0.0, 0.0)
+            b.record()
+            torch.cuda.synchronize()
+            tb[bsz] = a.elapsed_time(b) / 20
+        xs, ys = np.array(sorted(tb), dtype=np.float64), np.array([tb[k] for k in sorted(tb)])
+        slope, icpt = np.polyfit(xs, ys, 1)
+        chain_ms, per_image_us = round(float(icpt), 4), round(1000 * float(slope), 2)
+    except Exception:
+        pass
+    # (b) the dominant kernel variant of each stage from rocprofv3's durations inside the timed region (the committed trace of this
+    #     command, cut at the stage markers by profiles/summarize.py) and the library's exact algorithmic bytes
+    def stage_top(stage):
+        rows = [r for r in timed_rows if r.get("stage", "") == stage]
+        if not rows and stage_totals:        # a trace without stage markers (round 4's): a variant belongs to the stage that launches it
+            other = "training" if stage == "inference" else "inference"
+            mine = {k for k, t in stage_totals[stage].items()
+                    if t["launches"] * max(t["MB_per_launch"], 1e-9) >= stage_totals[other].get(k, {"launches": 0, "MB_per_launch": 0})["launches"]
+                    * max(stage_totals[other].get(k, {"MB_per_launch": 0})["MB_per_launch"], 1e-9)}
+            rows = [r for r in timed_rows if r["kernel"] in mine]
+        rows = [r for r in rows if r.get("algorithmic_MB_per_launch")]
+        if not rows:
+            return None
+        r = max(rows, key=lambda q: float(q["total_ms"]))
+        mf = r["kernel"].startswith(("conv_gemm", "wgrad_gemm"))
+        return {"kernel": r["kernel"], "calls": int(r["calls"]), "avg_us": float(r["avg_us"]),
+                "share_of_stage_kernel_time": round(float(r["total_ms"]) / max(sum(float(q["total_ms"]) for q in rows), 1e-9), 3),
+                "frac": float(r["frac_of_2.5PFLOPs"]) if mf else float(r["frac_of_8TBps"]),
+                "achieved": float(r["TFLOPs"]) if mf else float(r["GBps"]), "unit": "TFLOP/s" if mf else "GB/s",
+                "family_frac": round(sum(int(q["calls"]) * float(q["algorithmic_MB_per_launch"]) for q in rows)
+                                     / max(sum(float(q["total_ms"]) for q in rows), 1e-9) / HBM_PEAK_GBS, 4)}
+    by_stage = None
+    if primary and timed_rows:
+        ti, tt = stage_top("inference"), stage_top("training")
+        if ti:
+            narrow = ti["kernel"].startswith(("conv_pipe", "conv_wide"))
+            ti.update(bound="valu-issue" if narrow else ("mfma" if ti["unit"] == "TFLOP/s" else "hbm"),
+                      bound_evidence="profiles/r05_sq_counters_isic.csv, profiles/r04_notes.md ablations: waves issue ~40 % and wait ~47 % of "
+                                     "their cycles, HBM traffic = the algorithmic bytes" if narrow else None,
+                      stage_ms=round(t_inf, 3), stage_frac_of_min_bytes_floor=step_view["ensemble_infer_plus_im"]["frac"])
+        if tt:
+            tt.update(bound="launch-chain" if chain_ms and chain_ms > 0.4 * step_ms else ("mfma" if tt["unit"] == "TFLOP/s" else "hbm"),
+                      chain_ms=chain_ms, per_image_us=per_image_us, step_ms=round(step_ms, 4),
+                      step_ms_by_batch={str(k): round(v, 4) for k, v in sorted(tb.items())},
+                      stage_ms=round(t_ep, 3), stage_frac_of_min_bytes_floor=step_view["train_step"]["frac"])
+        by_stage = {"inference": ti, "training": tt,
+                    "note": "kernel = the variant with the largest summed duration among the stage's hooked kernels in the committed "
+                            "rocprofv3 trace of this command; frac = its algorithmic bytes (flops) over that duration over the peak; "
+                            "family_frac = the same over every hooked variant of the stage; chain_ms / per_image_us = intercept / slope "
+                            "of the training step time over batches of 8, 16, 32 measured in THIS run"}
+    roofline["by_stage"] = by_stage
     # the same generation once more with every kernel alone on the stream: the kernels' own rates
     for m in models + [student]:
         m.debug(single_stream=True)
@@ -856,6 +953,8 @@ def run_config(args, config_name, alpha, env, primary):
             out["timed_region_kernel_totals"] = {k: {"launches": t["launches"], "MB_per_launch": round(t["bytes"] / max(t["launches"], 1) / 1e6, 3),
                                                      "GFLOP_per_launch": round(t["flops"] / max(t["launches"], 1) / 1e9, 4)}
                                                  for k, t in sorted(kernel_totals.items())}
+        if stage_totals:
+            out["stage_kernel_totals_per_generation"] = stage_totals
         if sharding_check:
             out["sharding_check"] = sharding_check
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is a 1-GPU-run item (rank 0 only)

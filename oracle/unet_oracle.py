@@ -116,6 +116,26 @@ def _r(x, on):
     return _RoundF16.apply(x) if on else x
 
 
+class _AffineF16(torch.autograd.Function):
+    """y = fp16(x * scale + shift) with ONE rounding: the exact sum (formed in float64: an fp16 x times an fp32 scale has 35
+    significant bits) goes to fp16 directly, numpy's float64 -> float16 conversion being correctly rounded.  This is what the HIP
+    kernels' BatchNorm-on-load computes since round 4 (`v_fma_mixlo_f16`, csrc/imk_common.h imk_affine*); rounding the fp32
+    product and the fp32 sum first differs from it by an fp16 ulp in ~1e-4 of the values.  Backward: the straight-through
+    gradients of the affine map, the incoming gradient rounded to fp16 like every stored activation gradient."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        ctx.save_for_backward(x, scale)
+        y = x.double() * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+        return torch.from_numpy(y.numpy().astype(np.float16).astype(np.float32))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scale = ctx.saved_tensors
+        g = g.half().float()
+        return g * scale[None, :, None, None], (g * x).sum(dim=(0, 2, 3)), g.sum(dim=(0, 2, 3))
+
+
 def _conv(x, w, b, relu, f16):
     k = w.shape[0]
     wt = w.permute(3, 2, 0, 1)
@@ -141,8 +161,9 @@ def _bn(x, p, name, training, f16, stats_out):
         mean, var = p[name + ".mean"], p[name + ".var"]
     scale = g * torch.rsqrt(var + BN_EPS)
     shift = bta - mean * scale
-    y = x * scale[None, :, None, None] + shift[None, :, None, None]
-    return _r(y, f16)
+    if f16:
+        return _AffineF16.apply(x, scale, shift)
+    return x * scale[None, :, None, None] + shift[None, :, None, None]
 
 
 def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_fp16=False,
@@ -227,8 +248,10 @@ def new_opt_state(p):
 
 def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
                lr=3e-3, wd=1e-4, b1=0.9, b2=0.999, eps=1e-7, emulate_fp16=False, loss_scale=1.0,
-               return_grads=False, override=None, grad_taps=None):
+               return_grads=False, override=None, grad_taps=None, apply=True):
     """One step of forward(train) -> loss -> backward -> tfa-AdamW, in place on p / opt.
+    apply=False: a step the dynamic loss scale skips (non-finite gradients) -- Keras' LossScaleOptimizer leaves the variables and
+    the optimizer's slots alone, the BatchNorm moving statistics of the forward pass have moved all the same.
     Returns (loss, grads?)"""
     names = trainable_names(p)
     leaves = {k: p[k].clone().requires_grad_(True) for k in names}
@@ -241,11 +264,12 @@ def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
     loss = loss_fn(probs, t, loss_kind, logits if act_out == "softmax" else None)
     (loss * loss_scale).backward()
     grads = {k: leaves[k].grad / loss_scale for k in names}
-    opt["step"] += 1
-    s = opt["step"]
+    if apply:
+        opt["step"] += 1
+    s = max(opt["step"], 1)
     lr_t = lr * math.sqrt(1 - b2 ** s) / (1 - b1 ** s)
     with torch.no_grad():
-        for k in names:
+        for k in (names if apply else []):
             g = grads[k]
             p[k].mul_(1 - wd)                                   # decoupled decay, not scaled by lr
             opt["m"][k].mul_(b1).add_(g, alpha=1 - b1)

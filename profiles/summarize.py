@@ -91,40 +91,61 @@ def timed_region(out):
         if any("imk_mark_kernel" in r["Kernel_Name"] for r in rr):
             rows = rr
             break
-    marks = {int(r["Grid_Size_X"]) // 64: r for r in rows if "imk_mark_kernel" in r["Kernel_Name"]}
+    marks = {}
+    stage_marks = []     # (start timestamp, stage that begins there): bench.py's marker 4 opens a generation's inference stage, 3 its epoch
+    for r in rows:
+        if "imk_mark_kernel" in r["Kernel_Name"]:
+            ident = int(r["Grid_Size_X"]) // 64
+            if ident in (1, 2):
+                marks[ident] = r
+            elif ident in (3, 4):
+                stage_marks.append((int(r["Start_Timestamp"]), "training" if ident == 3 else "inference"))
     if 1 not in marks or 2 not in marks:
         return
     t0, t1 = int(marks[1]["End_Timestamp"]), int(marks[2]["Start_Timestamp"])
+    stage_marks = sorted(m for m in stage_marks if t0 <= m[0] <= t1)
+    import bisect
+    starts = [m[0] for m in stage_marks]
+
+    def stage_of(ts):
+        i = bisect.bisect_right(starts, ts) - 1
+        return stage_marks[i][1] if i >= 0 else ("inference" if stage_marks else "")
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
-        if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1:
-            k = short(r["Kernel_Name"])
+        if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1 and "imk_mark_kernel" not in r["Kernel_Name"]:
+            k = (stage_of(int(r["Start_Timestamp"])), short(r["Kernel_Name"]))
             agg[k][0] += 1
             agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    totals = {}
+    totals, stage_totals = {}, {}
     try:
         line = [l for l in open(os.path.join(out, "bench_traced.json")).read().splitlines() if l.startswith("{")][-1]
         totals = json.loads(line).get("timed_region_kernel_totals", {})
+        stage_totals = json.loads(line).get("stage_kernel_totals_per_generation", {})
     except Exception:
         pass
     # the library sums some families under one name (wgf_stage1 + wgf_stage2, the step tail, the conv_mfma variants by tile): those
-    # rows carry no bytes here; conv_pipe / conv_wide (the dominant family) match by their full template names
+    # rows carry no bytes here; conv_pipe / conv_wide (the dominant family) match by their full template names.  A variant that runs
+    # in both stages (the deep levels' kernels) has other bytes per launch in each (256 images per inference call, 32 per step): the
+    # bench line's per-stage totals (one generation outside the clock) price it per stage.
     tot_ns = sum(v[1] for v in agg.values())
+    stage_ns = collections.defaultdict(float)
+    for (st, _), v in agg.items():
+        stage_ns[st] += v[1]
     with open(os.path.join(out, "timed_region_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent_of_kernel_time", "algorithmic_MB_per_launch", "GFLOP_per_launch",
-                    "GBps", "frac_of_8TBps", "TFLOPs", "frac_of_2.5PFLOPs", "region_ms"])
-        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow(["stage", "kernel", "calls", "total_ms", "avg_us", "percent_of_kernel_time", "percent_of_stage_kernel_time",
+                    "algorithmic_MB_per_launch", "GFLOP_per_launch", "GBps", "frac_of_8TBps", "TFLOPs", "frac_of_2.5PFLOPs", "region_ms"])
+        for (st, k), v in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1][1])):
             avg_us = v[1] / v[0] / 1e3
-            t = totals.get(k)      # exact kernel name only: a family-wide average would misprice its variants
+            t = stage_totals.get(st, {}).get(k) or totals.get(k)      # exact kernel name only: a family-wide average would misprice its variants
             if t and t.get("launches"):
                 mb, gf = t["MB_per_launch"], t["GFLOP_per_launch"]
                 gbps, tf = mb / avg_us * 1e3, gf / avg_us * 1e3
                 extra = [mb, gf, round(gbps, 1), round(gbps / HBM_PEAK_GBS, 4), round(tf, 1), round(tf / MFMA_PEAK_TFLOPS, 4)]
             else:
                 extra = ["", "", "", "", "", ""]
-            w.writerow([k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), round(100 * v[1] / max(tot_ns, 1), 2)] + extra +
-                       [round((t1 - t0) / 1e6, 3)])
+            w.writerow([st, k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), round(100 * v[1] / max(tot_ns, 1), 2),
+                        round(100 * v[1] / max(stage_ns[st], 1), 2)] + extra + [round((t1 - t0) / 1e6, 3)])
 
 
 if __name__ == "__main__":

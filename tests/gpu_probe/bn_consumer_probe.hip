@@ -255,15 +255,16 @@ int main(int argc, char **argv) {
     static float h_rows[4096 * 256], h_rows8[8 * 256]; static long long h_acc[32 * 256 * 2];
     for (int cs2 : {16, 32, 128, 256})
         for (int grid : {256, 512, 1024, 1536})
-            for (int mode = first_mode; mode < 7; ++mode) {
+            for (int mode = first_mode; mode < 8; ++mode) {
                 if (mode == 2 && cur_cs2 != (unsigned)cs2) { hipMemset(flag, 0, 256); launches = 0; cur_cs2 = cs2; hipDeviceSynchronize(); }
                 const int R = mode == 4 ? 8 : (mode == 5 ? 32 : 1);        // modes 4 / 5 / 6: chain E with 8 / 32 / 1 replica rows
                 unsigned it_no = 0;
-                if (mode >= 4) { hipMemset(acc, 0, 2 * acc_words * 8); hipDeviceSynchronize(); }
+                if (mode >= 4 && mode < 7) { hipMemset(acc, 0, 2 * acc_words * 8); hipDeviceSynchronize(); }
                 auto chain = [&]() {
                     if (mode == 0) { producer<<<grid, 256>>>(a, b, n, rows, cs2); finalize<<<cs2, 256>>>(rows, grid, cs2, scale); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }
                     else if (mode == 1) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer<true><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }
                     else if (mode == 2) { producer<<<grid, 256>>>(a, b, n, rows, cs2); ++launches; consumer_lead<<<grid + cs2, 256>>>(b, c, n, rows, grid, cs2, scale, flag, launches * cs2, flag + 32); }
+                    else if (mode == 7) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }    // floor: no reduction at all (stale scale)
                     else if (mode == 3) { producer_xcd<<<grid, 256>>>(a, b, n, rows, cs2, counters, rows8, xcc_of, split); consumer_rows<<<grid, 256>>>(b, c, n, rows8, 8, cs2); }
                     else {
                         long long *cur = acc + (it_no & 1) * acc_words, *nxt = acc + ((it_no + 1) & 1) * acc_words; ++it_no;
@@ -276,7 +277,7 @@ int main(int argc, char **argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 static const char *names[] = {"finalize launch (today)", "consumer re-reduces    ", "leading finalize blocks", "XCD-local ticket, 8 rows", "int64 atomics,  8 rows  ",
-                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   "};
+                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   ", "FLOOR: two launches, no reduction"};
                 printf("%zu MiB, 2cs %3d, %4d rows (%3d KB per consumer workgroup): %s %.2f us per producer + consumer\n", mb, cs2, grid, grid * cs2 * 4 / 1024,
                        names[mode], ms * 1000 / 100);
                 if (mode == 2) { unsigned e = 0; hipMemcpy(&e, flag + 32, 4, hipMemcpyDeviceToHost); if (e) printf("   !! %u poll time-outs\n", e); }
@@ -293,7 +294,7 @@ int main(int argc, char **argv) {
                     }
                     printf("   chain D: worst relative difference of a total %.2e, workgroups not on their group's XCD %u (of %d x 105 launches)\n", worst, sp, grid);
                 }
-                if (mode >= 4) {    // the integer total must be the exact sum of chain A's rows
+                if (mode >= 4 && mode < 7) {    // the integer total must be the exact sum of chain A's rows
                     const long long *cur = acc + ((it_no - 1) & 1) * acc_words;
                     hipMemcpy(h_acc, cur, (size_t)R * cs2 * 16, hipMemcpyDeviceToHost);
                     int bad = 0;

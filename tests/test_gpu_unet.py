@@ -192,13 +192,11 @@ def test_train_step_parity(UNet, name):
             cc = l["cout"]
             errs[n + ".gamma"] = rel_l2(g[l["off_w"]:l["off_w"] + cc].numpy(), grads_ref[n + ".gamma"].numpy())
             errs[n + ".beta"] = rel_l2(g[l["off_b"]:l["off_b"] + cc].numpy(), grads_ref[n + ".beta"].numpy())
-    # The stem's bias gradient is the one cancellation-dominated tensor: a sum over every pixel of the batch of ReLU-masked terms
-    # whose unmasked sum is exactly zero behind the BatchNorm (what survives is ~1e-3 of the terms' magnitude), so single-ulp
-    # differences in the BatchNorm-on-load values (one rounding on the GPU since round 4, two in the oracle's emulation) show up
-    # ten times larger there than anywhere else (measured 2.1e-2 on one configuration; every other tensor <= 4e-3).
-    tol = lambda k: 3e-2 if k == "in.c.b" else 2e-2
-    bad = {k: round(v, 4) for k, v in errs.items() if not v <= tol(k)}
-    assert not bad, f"gradient tensors off by more than 2e-2 (in.c.b: 3e-2) rel-L2: {bad}; all: { {k: round(v, 4) for k, v in errs.items()} }"
+    # (The stem's bias gradient is the one cancellation-dominated tensor -- a sum over every pixel of the batch of ReLU-masked terms
+    # whose unmasked sum is exactly zero behind the BatchNorm -- and was at 2.1e-2 while the oracle emulated the BatchNorm-on-load with
+    # two roundings; the oracle now rounds once like the kernels (unet_oracle._AffineF16) and the one bound holds for every tensor.)
+    bad = {k: round(v, 4) for k, v in errs.items() if not v <= 2e-2}
+    assert not bad, f"gradient tensors off by more than 2e-2 rel-L2: {bad}; all: { {k: round(v, 4) for k, v in errs.items()} }"
     # BN moving statistics after one step (momentum 0.99)
     for kk in sd_ref:
         if kk.endswith(".mean") or kk.endswith(".var"):
@@ -263,6 +261,98 @@ def test_overflow_skips_step_and_halves_scale(UNet):
     assert torch.equal(before[:m.plan.n_trainable], m.params[:m.plan.n_trainable])
     scale = struct.unpack("f", bytes(m.train_state[ctl_off:ctl_off + 4].cpu().tolist()))[0]
     assert scale == 2.0 ** 39
+
+
+def _ctl(m):
+    """(loss_scale, inv_loss_scale, good_steps, step) of the model's optimizer state (ImkCtl, csrc/imk_elem.h)"""
+    off = m.plan.state_bytes - 256
+    return struct.unpack("ffii", bytes(m.train_state[off:off + 16].cpu().tolist()))
+
+
+def test_loss_scale_doubles_after_2000_finite_steps(UNet):
+    """Keras LossScaleOptimizer (dynamic, defaults): the scale grows by 2 after 2 000 consecutive finite steps and the count starts
+    again.  1 999 good steps are written into the state buffer (as test_overflow_skips_step_and_halves_scale writes the scale), the
+    2 000th is a real step."""
+    cfg = CFGS["isic"]
+    m = UNet(cfg["h"], cfg["w"], 3, 1, 0.5, "sigmoid", seed=43)
+    x, y, _ = make_input(cfg, 44)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.init_train_state()
+    off = m.plan.state_bytes - 256
+    assert _ctl(m) == (32768.0, 1.0 / 32768.0, 0, 0)
+    m.train_state[off + 8:off + 12] = torch.tensor(list(struct.pack("i", 1998)), dtype=torch.uint8).cuda()
+    before = m.params.clone()
+    m.train_step(xd, yd, 0, 3e-3, 1e-4)
+    torch.cuda.synchronize()
+    assert m.stats.cpu().numpy()[1] == 0.0
+    assert _ctl(m) == (32768.0, 1.0 / 32768.0, 1999, 1)          # one short of the growth interval: unchanged
+    m.train_step(xd, yd, 0, 3e-3, 1e-4)
+    torch.cuda.synchronize()
+    st = m.stats.cpu().numpy()
+    assert st[1] == 0.0 and st[2] == 32768.0                        # the step itself still ran at the old scale ...
+    assert _ctl(m) == (65536.0, 1.0 / 65536.0, 0, 2)               # ... the next one runs at twice that
+    assert not torch.equal(before[:m.plan.n_trainable], m.params[:m.plan.n_trainable])
+    m.fwd_bwd(xd, yd, 0)
+    torch.cuda.synchronize()
+    assert m.stats.cpu().numpy()[2] == 65536.0
+
+
+def _trajectory_batch(cfg, step):
+    """a learnable task: the target is a function of the image, so the loss falls over the steps"""
+    x, _, _ = make_input(cfg, 1000 + step)
+    if cfg["loss"] == "mse":
+        y = (x[..., :1] > 140).astype(np.uint8)
+        return x, y, y.astype(np.float32)
+    y = np.minimum(x[..., 0].astype(np.int32) * cfg["k"] // 256, cfg["k"] - 1).astype(np.uint8)
+    return x, y, np.eye(cfg["k"], dtype=np.float32)[y]
+
+
+# measured on the MI355X (round 5), then frozen with head-room: see the assertion messages for the observed values
+TRAJECTORY_TOL = {"isic": dict(loss=2e-2, moving=1e-3, weights=5e-2), "suim": dict(loss=2e-2, moving=1e-3, weights=5e-2)}
+
+
+@pytest.mark.parametrize("name", ["isic", "suim"])
+def test_training_trajectory_tracks_the_oracle(UNet, name):
+    """SURVEY 8a' row a10: "loss after k steps within tolerance from identical init / batches" (functions.py:207-218).  30
+    optimizer steps on 30 different batches, GPU (imk_unet_fwd_bwd + imk_unet_adamw_step, dynamic loss scale) against
+    unet_oracle.train_step(emulate_fp16=True) fed the same batches, the same loss scale and the same skip decisions: the loss of
+    EVERY step, the final BatchNorm moving statistics and the final weights.  No value of the GPU's is handed to the oracle
+    (unlike the one-step gradient test, whose forward values are pinned): this is the end-to-end check that fp16 noise does not
+    push the two trainings apart over a trajectory."""
+    cfg = CFGS[name]
+    c, k, alpha, act = cfg["c"], cfg["k"], cfg["alpha"], cfg["act"]
+    m = UNet(cfg["h"], cfg["w"], c, k, alpha, act, seed=61)
+    sd = {kk: v.clone() for kk, v in m.state_dict().items()}
+    opt = U.new_opt_state(sd)
+    kind = 0 if cfg["loss"] == "mse" else 1
+    m.init_train_state()
+    tol = TRAJECTORY_TOL[name]
+    steps, worst, skipped = 30, 0.0, 0
+    gpu_losses, ref_losses = [], []
+    for s in range(steps):
+        x, y, tgt = _trajectory_batch(cfg, s)
+        scale = _ctl(m)[0]
+        m.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), kind, 3e-3, 1e-4)
+        torch.cuda.synchronize()
+        st = m.stats.cpu().numpy()
+        assert st[2] == scale
+        ok = st[1] == 0.0
+        skipped += not ok
+        ref = U.train_step(sd, opt, x, tgt, c, k, alpha, act, cfg["loss"], emulate_fp16=True, loss_scale=scale, apply=bool(ok))
+        gpu_losses.append(float(st[0])); ref_losses.append(ref)
+        worst = max(worst, abs(st[0] - ref) / max(abs(ref), 1e-6))
+    assert skipped <= 2, f"{skipped} of {steps} steps overflowed"
+    assert ref_losses[-1] < 0.8 * ref_losses[0], ref_losses[::5]                     # it did learn
+    assert worst <= tol["loss"], f"loss curves apart by {worst:.3e} relative; gpu {gpu_losses[::5]} oracle {ref_losses[::5]}"
+    got = m.state_dict()
+    mov = max(float((got[kk].cpu() - sd[kk]).abs().max()) for kk in sd if kk.endswith(".mean") or kk.endswith(".var"))
+    assert mov <= tol["moving"], f"moving statistics apart by {mov:.3e}"
+    wn = [kk for kk in sd if kk.endswith(".w")]
+    werr = {kk: rel_l2(got[kk].cpu().numpy(), sd[kk].numpy()) for kk in wn}
+    wall = rel_l2(np.concatenate([got[kk].cpu().numpy().ravel() for kk in wn]), np.concatenate([sd[kk].numpy().ravel() for kk in wn]))
+    assert wall <= tol["weights"], f"weights apart by {wall:.3e} rel-L2 over all kernels; per tensor {werr}"
+    print(f"trajectory {name}: worst loss gap {worst:.3e}, moving statistics {mov:.3e}, weights {wall:.3e} (worst tensor "
+          f"{max(werr.values()):.3e}), skipped {skipped}")
 
 
 ENSEMBLE_CASES = {   # name -> (config, number of models)
