@@ -136,7 +136,11 @@ class _AffineF16(torch.autograd.Function):
         return g * scale[None, :, None, None], (g * x).sum(dim=(0, 2, 3)), g.sum(dim=(0, 2, 3))
 
 
-def _conv(x, w, b, relu, f16):
+def _conv(x, w, b, relu, f16, round_grad=True):
+    """round_grad=False: the output is rounded to fp16, the gradient that comes back to it is not.  That is the HIP path's conv in
+    front of a BatchNorm: the BatchNorm backward (dz = A dy + B z + C) is applied by the consumers while they load dy and z, so the
+    gradient w.r.t. this output only ever exists in fp32 registers (Backward structure); the gradients that ARE stored
+    -- dy of every BatchNorm, the ReLU-masked gradient between a Conv1x1 and the Conv3x3 in front of it -- are fp16."""
     k = w.shape[0]
     wt = w.permute(3, 2, 0, 1)
     if f16:
@@ -144,7 +148,9 @@ def _conv(x, w, b, relu, f16):
     y = F.conv2d(x, wt, b, padding=k // 2)
     if relu:
         y = F.relu(y)
-    return _r(y, f16)
+    if not f16:
+        return y
+    return _RoundF16.apply(y) if round_grad else _RoundF16Fwd.apply(y)
 
 
 def _bn(x, p, name, training, f16, stats_out):
@@ -183,6 +189,7 @@ def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_f
             taps[name] = t.detach().permute(0, 2, 3, 1).contiguous()
 
     def c(name, t, relu=True):
+        feeds_bn = not name.endswith(".c3")      # unet.py: every conv but a block's 3x3 is followed by a BatchNormalization
         if override is not None and name in override:
             # value := the overriding tensor; gradient := that of (pre-activation * [override > 0]): the ReLU decision
             # follows the overriding values ONLY (not also this oracle's own pre-activation sign)
@@ -191,7 +198,7 @@ def forward(p, x_u8_nhwc, c_in, n_out, alpha, act_out, training=False, emulate_f
             mask = (ov > 0).float() if relu else 1.0
             y = pre * mask + (ov - pre * mask).detach()
         else:
-            y = _conv(t, p[name + ".w"], p[name + ".b"], relu, f16)
+            y = _conv(t, p[name + ".w"], p[name + ".b"], relu, f16, round_grad=not feeds_bn)
         tap(name, y)
         if grad_taps is not None and y.requires_grad:   # gradient w.r.t. this conv's (post-ReLU) output, NHWC
             y.register_hook(lambda g, n=name: grad_taps.__setitem__(n, g.detach().permute(0, 2, 3, 1).contiguous()))
@@ -264,6 +271,10 @@ def train_step(p, opt, x_u8, target, c_in, n_out, alpha, act_out, loss_kind,
     loss = loss_fn(probs, t, loss_kind, logits if act_out == "softmax" else None)
     (loss * loss_scale).backward()
     grads = {k: leaves[k].grad / loss_scale for k in names}
+    # dynamic loss scaling: a step whose (scaled, fp16-rounded) gradients are not finite is skipped; the caller halves the scale
+    finite = all(bool(torch.isfinite(g).all()) for g in grads.values())
+    apply = apply and finite
+    opt["last_finite"], opt["last_applied"] = finite, apply
     if apply:
         opt["step"] += 1
     s = max(opt["step"], 1)

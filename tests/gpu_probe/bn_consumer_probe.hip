@@ -255,7 +255,7 @@ int main(int argc, char **argv) {
     static float h_rows[4096 * 256], h_rows8[8 * 256]; static long long h_acc[32 * 256 * 2];
     for (int cs2 : {16, 32, 128, 256})
         for (int grid : {256, 512, 1024, 1536})
-            for (int mode = first_mode; mode < 8; ++mode) {
+            for (int mode = first_mode; mode < 10; ++mode) {
                 if (mode == 2 && cur_cs2 != (unsigned)cs2) { hipMemset(flag, 0, 256); launches = 0; cur_cs2 = cs2; hipDeviceSynchronize(); }
                 const int R = mode == 4 ? 8 : (mode == 5 ? 32 : 1);        // modes 4 / 5 / 6: chain E with 8 / 32 / 1 replica rows
                 unsigned it_no = 0;
@@ -264,6 +264,8 @@ int main(int argc, char **argv) {
                     if (mode == 0) { producer<<<grid, 256>>>(a, b, n, rows, cs2); finalize<<<cs2, 256>>>(rows, grid, cs2, scale); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }
                     else if (mode == 1) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer<true><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }
                     else if (mode == 2) { producer<<<grid, 256>>>(a, b, n, rows, cs2); ++launches; consumer_lead<<<grid + cs2, 256>>>(b, c, n, rows, grid, cs2, scale, flag, launches * cs2, flag + 32); }
+                    else if (mode == 8) { producer_int<<<grid, 256>>>(a, b, n, acc, 8, cs2); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }   // E's producer side only (totals grow: never read)
+                    else if (mode == 9) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer_int<<<grid, 256>>>(b, c, n, acc, acc + acc_words, 8, cs2); }      // E's consumer side only (stale rows)
                     else if (mode == 7) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }    // floor: no reduction at all (stale scale)
                     else if (mode == 3) { producer_xcd<<<grid, 256>>>(a, b, n, rows, cs2, counters, rows8, xcc_of, split); consumer_rows<<<grid, 256>>>(b, c, n, rows8, 8, cs2); }
                     else {
@@ -277,7 +279,7 @@ int main(int argc, char **argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 static const char *names[] = {"finalize launch (today)", "consumer re-reduces    ", "leading finalize blocks", "XCD-local ticket, 8 rows", "int64 atomics,  8 rows  ",
-                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   ", "FLOOR: two launches, no reduction"};
+                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   ", "FLOOR: two launches, no reduction", "E producer side only (atomics)", "E consumer side only (8 rows) "};
                 printf("%zu MiB, 2cs %3d, %4d rows (%3d KB per consumer workgroup): %s %.2f us per producer + consumer\n", mb, cs2, grid, grid * cs2 * 4 / 1024,
                        names[mode], ms * 1000 / 100);
                 if (mode == 2) { unsigned e = 0; hipMemcpy(&e, flag + 32, 4, hipMemcpyDeviceToHost); if (e) printf("   !! %u poll time-outs\n", e); }
