@@ -622,6 +622,8 @@ def run_config(args, config_name, alpha, env, primary):
         if record is not None:
             record.append((e0, e1, e2))
         info.update(epoch_steps=int(steps), n_train=n_train)
+        if use_dist and world > 1 and record is not None and len(record) == 1:      # once per run: what THIS rank did (stderr)
+            print(f"[bench rank {rank}] epoch_steps={int(steps)} kept={int(keep.sum())} shard={U}", file=sys.stderr, flush=True)
         return torch.stack([ps.sum(), ims.sum(), keep.sum()]).double()      # read after the timed region
 
     def barrier():

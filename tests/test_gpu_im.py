@@ -131,6 +131,21 @@ def test_morph_and_block(im):
     assert np.array_equal(_np(tm), masks * (m == 0)[:, None])
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 7])
+def test_morph_against_scipy(im, k):
+    """imk_morph against an implementation nobody here wrote (scipy.ndimage grey morphology, flat k x k footprint, constant border
+    = the operator's identity; even footprints: anchor k // 2 like cv2.erode / cv2.dilate, functions.py:2858-2864).  The oracle is
+    held to the same second opinion on the CPU (tests/test_cpu_second_opinion.py)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(10 + k)
+    m = (rng.random((4, 61, 83)) > rng.choice([0.3, 0.7])).astype(np.uint8) * 255
+    t = torch.from_numpy(m).cuda()
+    want_e = np.stack([ndimage.grey_erosion(x, size=(k, k), mode="constant", cval=255) for x in m])
+    want_d = np.stack([ndimage.grey_dilation(x, size=(k, k), mode="constant", cval=0, origin=0 if k % 2 else -1) for x in m])
+    assert np.array_equal(_np(im.morph(t, k, "erode")), want_e)
+    assert np.array_equal(_np(im.morph(t, k, "dilate")), want_d)
+
+
 @pytest.mark.parametrize("n,h,w,k", [(3, 256, 256, 9), (2, 208, 416, 35)])
 def test_multiclass_properties_full_size(im, n, h, w, k):
     """Size-independent properties at the BASELINE multiclass shapes (SUIM N=3 K=9; Cityscapes N=2 K=35, 208x416):
