@@ -605,6 +605,11 @@ __global__ __launch_bounds__(256, (DYN && NC8 == 1) ? 4 : 1) void conv_pipe_kern
     // thread t <-> pixel t of a full tile (WG = 1, 2), in bytes of a tensor with the output's channel stride
     const unsigned cso_b = (unsigned)a.cs_out * 2u;
     const unsigned xw_off = (unsigned)((t >> 4) * W + (t & 15)) * cso_b;
+    // (Round 5, measured and removed: an interior-tile path -- 3 of 4 tiles have their whole halo window inside the image and need
+    //  neither the clamps of psrc_load nor the inside / outside select of the staging -- chosen per tile by a scalar branch, same loads,
+    //  bit-identical outputs: the 256-image ISIC forward went 0.843-0.846 -> 0.867-0.872 ms, SUIM 1.052-1.057 -> 1.059-1.067, with or
+    //  without a second copy of the first-stage loop.  The clamps were never on the critical path; the extra branches and the
+    //  rescheduled LDS waits were.  profiles/r05_notes.md.)
     auto issue = [&](const PTile &tc) {
         if constexpr (U8ROWS) {
             rowseg = *reinterpret_cast<const uint4 *>(pix_base(a.x.in, tc.b, H, W, tc.ty0, tc.tx0, (unsigned)u8_cin) + u8_off);
@@ -2279,9 +2284,14 @@ bool imk_conv_can_fuse_wgrad(const ImkConvArgs &a) {
     if (a.wpk2) return false;
     const bool form1 = a.ksize == 1 && a.x.lmode == LM_BNBWD && a.epi == EP_MASK && a.mask && !(a.dystat_z && a.stats_partial);
     const bool form2 = a.x.lmode == LM_RAW && a.epi == EP_PLAIN && a.dystat_z && a.stats_partial;     // 1x1 and 3x3
-    static const bool c3_off = []() { const char *e = getenv("IMK_FUSE_WGRAD_C3"); return e && e[0] == '0'; }();
+    // The 3x3 form doubles the launch's matrix and LDS work (20 MFMAs + 40 transposed reads per wave and tile on top of the dgrad's 20):
+    // at ISIC the half-resolution 16-channel launch takes 42 us fused against ~20 us for the plain dgrad.  Round 5 measured the
+    // alternatives on one box against round 4's library (IMK_FUSE_WGRAD_C3: 0 = never fuse the 3x3 form, 8 = pair layout only, unset =
+    // wherever it applies): ISIC / SUIM / HeLa steps within +-0.5 % of each other under every rule -- what the chain gains, the fork and
+    // the weight-gradient launch beside it give back (profiles/r05_notes.md).  The default stays "wherever it applies".
+    static const int c3_mode = []() { const char *e = getenv("IMK_FUSE_WGRAD_C3"); return e ? atoi(e) : -1; }();
     if (!form1 && !form2) return false;
-    if (a.ksize == 3 && c3_off) return false;
+    if (a.ksize == 3 && (c3_mode == 0 || (c3_mode == 8 && a.cout > 8))) return false;
     if (a.x.cs_in > 16 || a.cout > 16) return false;
     const bool pair = pair_enabled() && a.cout <= 8;
     const bool all_ch = pair || a.cs_out == 16;
