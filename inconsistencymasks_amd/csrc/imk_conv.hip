@@ -27,6 +27,9 @@
 #ifndef IMK_ABL
 #define IMK_ABL 0
 #endif
+#ifndef IMK_INF_WAVES
+#define IMK_INF_WAVES 4      // waves per SIMD the 8-channel inference instantiations of conv_pipe_kernel are compiled for (probe builds: 5)
+#endif
 IMK_STAMP_TABLE(conv)
 IMK_WGSTAMP_TABLE(conv)
 
@@ -450,7 +453,7 @@ constexpr size_t pipe_lds_base(int nc8, bool pair, int wg) {
 template <int LM, int NC8, int CHAIN, bool PAIR, int EPI, bool DYSTAT, bool FULL, int WG = 0, int PRE = 0, bool DYN = false>
 // (inference launches of the 8-channel layers: four workgroups per CU, i.e. <= 128 registers -- the decoder's launch sat at 134 and ran
 //  three waves per SIMD: 0.891 -> 0.873 ms per 256-image forward; the 16-channel and the training variants gain nothing from a cap)
-__global__ __launch_bounds__(256, (DYN && NC8 == 1) ? 4 : 1) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
+__global__ __launch_bounds__(256, (DYN && NC8 == 1) ? IMK_INF_WAVES : 1) void conv_pipe_kernel(ImkConvArgs a, int tiles_x, int tiles_y, int n_tiles,
                                                         unsigned magic_tx, ImkWalk wk) {
     static_assert(!DYN || (EPI == EP_RELU && !DYSTAT && WG == 0), "dynamic walk: results must not depend on the tile -> workgroup map");
     static_assert(PRE == 0 || (WG == 0 && EPI == EP_RELU && !DYSTAT && (LM == LM_U8 || LM == LM_UPADD)), "pre-stage: inference forward only");
@@ -1528,26 +1531,54 @@ __device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx,
     return j;
 }
 
+// Round 5: 16-byte loads.  A (tile, chunk) work item is 256 floats x `chunk` splits; thread (e4 = t & 63, sg = t >> 6) sums the
+// float4 e4 of splits sg, sg + 4, ... (four 16-byte loads in flight per 16 splits instead of sixteen 4-byte ones: a wave's load is
+// 1 KB, not 256 B), the four sub-sums are combined in a fixed order through LDS.  Deterministic; another association than rounds 2-4.
 __global__ __launch_bounds__(256) void wgf_stage1_kernel(ImkWgFinalJobs jobs) {
     IMK_STAMP_BEGIN(conv, 21);
+    __shared__ float4 s_q[4][64];
     const int jn = wgf_find_job(jobs, blockIdx.x, true);
     const ImkWgFinalJob &jb = jobs.j[jn];
     const int local = blockIdx.x - jb.work1_begin;
     const int tile = local / jb.n_chunks, chunk = local - tile * jb.n_chunks;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, e4 = t & 63, sg = t >> 6;
     const int s0 = chunk * jb.chunk, s1 = min(jb.n_split, s0 + jb.chunk);    // jb.chunk: a multiple of WG_RED_CHUNK
-    const size_t stride = (size_t)jb.n_tiles * 256;
-    const float *p = jb.partial + (size_t)tile * 256 + t;
-    float acc = 0.f;
+    const size_t stride4 = (size_t)jb.n_tiles * 64;
+    const float4 *p = reinterpret_cast<const float4 *>(jb.partial) + (size_t)tile * 64 + e4;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int sb = s0; sb < s1; sb += WG_RED_CHUNK) {
-        float v[WG_RED_CHUNK];
+        float4 v[WG_RED_CHUNK / 4];
 #pragma unroll
-        for (int i = 0; i < WG_RED_CHUNK; ++i) v[i] = p[(size_t)min(sb + i, s1 - 1) * stride];   // unconditional: all 16 in flight
+        for (int i = 0; i < WG_RED_CHUNK / 4; ++i) v[i] = p[(size_t)min(sb + sg + 4 * i, s1 - 1) * stride4];   // unconditional: all in flight
 #pragma unroll
-        for (int i = 0; i < WG_RED_CHUNK; ++i) acc += (sb + i < s1) ? v[i] : 0.f;
+        for (int i = 0; i < WG_RED_CHUNK / 4; ++i) {
+            const float live = (sb + sg + 4 * i < s1) ? 1.f : 0.f;
+            acc.x += live * v[i].x; acc.y += live * v[i].y; acc.z += live * v[i].z; acc.w += live * v[i].w;
+        }
     }
-    jb.red[((size_t)chunk * jb.n_tiles + tile) * 256 + t] = acc;
+    s_q[sg][e4] = acc;
+    __syncthreads();
+    if (sg == 0) {
+        const float4 a = s_q[0][e4], b = s_q[1][e4], c = s_q[2][e4], d = s_q[3][e4];
+        float4 r;
+        r.x = (a.x + b.x) + (c.x + d.x); r.y = (a.y + b.y) + (c.y + d.y); r.z = (a.z + b.z) + (c.z + d.z); r.w = (a.w + b.w) + (c.w + d.w);
+        reinterpret_cast<float4 *>(jb.red)[((size_t)chunk * jb.n_tiles + tile) * 64 + e4] = r;
+    }
     IMK_STAMP_END(1);
+}
+
+// Stage 2: one 1024-thread block per tile, sub-group sg = t >> 8 sums chunks sg, sg + 4, ... (at most 16 each).  Round 5: only as
+// many loads as the job has chunks -- the deep layers of the wide nets have thousands of tiles with 1-4 chunks each, and sixteen
+// clamped loads per thread for every one of them made this launch 5 % of a Cityscapes alpha = 2 step (42 us per launch).
+template <int N>
+__device__ __forceinline__ float wgf_sum_chunks(const float *p, size_t stride, int sg, int n_chunks) {
+    float v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[(size_t)min(sg + 4 * i, n_chunks - 1) * stride];   // unconditional loads
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc += (sg + 4 * i < n_chunks) ? v[i] : 0.f;
+    return acc;
 }
 
 __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, const float *__restrict__ inv_scale_ptr,
@@ -1559,12 +1590,13 @@ __global__ __launch_bounds__(1024) void wgf_stage2_kernel(ImkWgFinalJobs jobs, c
     const int e = threadIdx.x & 255, sg = threadIdx.x >> 8;
     const size_t stride = (size_t)jb.n_tiles * 256;
     const float *p = jb.red + (size_t)tile * 256 + e;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = p[(size_t)min(sg + 4 * i, jb.n_chunks - 1) * stride];   // unconditional loads
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc += (sg + 4 * i < jb.n_chunks) ? v[i] : 0.f;
+    const int per = (jb.n_chunks + 3) >> 2;            // chunks per sub-group (uniform over the block); same order of additions for any N >= per
+    float acc;
+    if (per <= 1) acc = wgf_sum_chunks<1>(p, stride, sg, jb.n_chunks);
+    else if (per <= 2) acc = wgf_sum_chunks<2>(p, stride, sg, jb.n_chunks);
+    else if (per <= 4) acc = wgf_sum_chunks<4>(p, stride, sg, jb.n_chunks);
+    else if (per <= 8) acc = wgf_sum_chunks<8>(p, stride, sg, jb.n_chunks);
+    else acc = wgf_sum_chunks<16>(p, stride, sg, jb.n_chunks);
     s_p[sg][e] = acc;
     __syncthreads();
     if (sg != 0) return;

@@ -469,6 +469,10 @@ int launch_conv_gemm_k(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t 
 bool imk_conv_gemm_ok(const ImkConvArgs &a) {
     if (!gemm_env_on()) return false;
     if (a.wpk2 || a.pre_wpk || a.wg_partial) return false;
+    // (Round 5, measured and removed: the pooled-input 3x3 with 16 -> 32 channels -- the second encoder block at alpha 1, the third at
+    //  alpha 0.5; on the per-tile kernel the largest single item of an alpha = 1 inference call, 1.0-1.2 TB/s -- on THIS kernel with
+    //  half of its 64-channel tile padding: bit-identical, and slower: 584-image ISIC forward 1.80 -> 1.89 ms, 128-image SUIM 1.05 ->
+    //  1.13, HeLa 1.01 -> 1.08, Cityscapes 1.68 -> 1.77; training steps +0.5-1 %.  profiles/r05_notes.md.)
     if (a.x.cs_in <= 32 && a.cout <= 32) return false;
     if (a.x.cs_in > 512) return false;
     switch (a.x.lmode) {

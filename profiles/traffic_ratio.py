@@ -7,24 +7,29 @@ import os
 import sys
 RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 HERE = os.path.dirname(os.path.abspath(__file__))
-# per kernel variant: the row of the stage in which it spends the most time (from round 5 on the file has one row per stage and variant)
-tr = {}
+# From round 5 on the timed-region file has one row per (stage, variant) and the bench runs other batch sizes outside the clock (the
+# T(B) fit: 8 / 16 images): a variant is compared only where the two populations are the same -- it runs in ONE stage of the
+# generation, and of its PMC rows (one per grid size) the one with the most launches is that stage's.
+tr, n_stage = {}, {}
 for r in csv.DictReader(open(os.path.join(HERE, f"{RND}_timed_region_kernel_stats.csv"))):
-    if r["kernel"] not in tr or float(r["total_ms"]) > float(tr[r["kernel"]]["total_ms"]):
-        tr[r["kernel"]] = r
-rows = []
+    n_stage[r["kernel"]] = n_stage.get(r["kernel"], 0) + 1
+    tr[r["kernel"]] = r
+pmc = {}
 for r in csv.DictReader(open(os.path.join(HERE, f"{RND}_pmc_traffic.csv"))):
-    k = r["kernel"]
+    if r["kernel"] not in pmc or int(r["launches"]) > int(pmc[r["kernel"]]["launches"]):
+        pmc[r["kernel"]] = r
+rows = []
+for k, r in pmc.items():
     t = tr.get(k)
-    if not (k.startswith("conv_pipe") or k.startswith("conv_wide")) or not t or not t["algorithmic_MB_per_launch"]:
+    if not (k.startswith("conv_pipe") or k.startswith("conv_wide")) or not t or not t["algorithmic_MB_per_launch"] or n_stage.get(k, 0) != 1:
         continue
     alg, hbm = float(t["algorithmic_MB_per_launch"]), float(r["hbm_MB_per_launch_corrected(2*fetch+write)"])
-    rows.append([k, int(r["launches"]), alg, hbm, round(hbm / alg, 3), float(t["avg_us"]), float(t["frac_of_8TBps"])])
+    rows.append([k, int(r["launches"]), alg, hbm, round(hbm / alg, 3), float(t["avg_us"]), float(t["frac_of_8TBps"]), t.get("stage", "")])
 rows.sort(key=lambda x: -x[1] * x[3])
 ta, th = sum(r[1] * r[2] for r in rows), sum(r[1] * r[3] for r in rows)
 with open(os.path.join(HERE, f"{RND}_traffic_vs_algorithmic.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["kernel", "launches_in_pmc_pass", "algorithmic_MB_per_launch", "pmc_MB_per_launch(2*fetch+write)", "ratio", "rocprof_avg_us_timed_region", "frac_of_8TBps"])
+    w.writerow(["kernel", "launches_in_pmc_pass", "algorithmic_MB_per_launch", "pmc_MB_per_launch(2*fetch+write)", "ratio", "rocprof_avg_us_timed_region", "frac_of_8TBps", "stage"])
     w.writerows(rows)
-    w.writerow(["FAMILY (launch-weighted)", sum(r[1] for r in rows), round(ta / sum(r[1] for r in rows), 1), round(th / sum(r[1] for r in rows), 1), round(th / ta, 3), "", ""])
+    w.writerow(["FAMILY (launch-weighted)", sum(r[1] for r in rows), round(ta / sum(r[1] for r in rows), 1), round(th / sum(r[1] for r in rows), 1), round(th / ta, 3), "", "", ""])
 print("family ratio", round(th / ta, 3))

@@ -232,6 +232,42 @@ __global__ __launch_bounds__(256) void consumer_int(const uint4 *__restrict__ in
     }
 }
 
+// ---- write-through stores (round 5): does a kernel that leaves nothing dirty in the L2s hand over faster?  The floor chain with
+// every 16-byte output store as `global_store_dwordx4 ... sc1`.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(uint4 *p, uint4 v) {
+    const u32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+template <int WT>
+__global__ __launch_bounds__(256) void producer_wt(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n, float *__restrict__ rows, int cs2) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint4 v = in[i];
+        acc += __uint_as_float((v.x & 0x007fffffu) | 0x3f800000u);
+        if (WT == 1) store_sc1(out + i, v); else if (WT == 2) __builtin_nontemporal_store(v.x, &out[i].x), __builtin_nontemporal_store(v.y, &out[i].y), __builtin_nontemporal_store(v.z, &out[i].z), __builtin_nontemporal_store(v.w, &out[i].w); else out[i] = v;
+    }
+    __shared__ float s[256];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < cs2) rows[(size_t)blockIdx.x * cs2 + threadIdx.x] = s[threadIdx.x] + s[(threadIdx.x + 64) & 255] + s[(threadIdx.x + 128) & 255];
+}
+template <int WT>
+__global__ __launch_bounds__(256) void consumer_wt(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n, int cs2, const float *__restrict__ scale) {
+    __shared__ float s_sc[256];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint4 v = i < n ? in[i] : uint4{0, 0, 0, 0};
+    if (threadIdx.x < cs2) s_sc[threadIdx.x] = scale[threadIdx.x];
+    __syncthreads();
+    const float sc = s_sc[threadIdx.x % cs2];
+    for (; i < n; i += (size_t)gridDim.x * 256) {
+        v.x = __float_as_uint(__uint_as_float(v.x) * sc);
+        if (WT == 1) store_sc1(out + i, v); else out[i] = v;
+        const size_t nx = i + (size_t)gridDim.x * 256;
+        if (nx < n) v = in[nx];
+    }
+}
+
 int main(int argc, char **argv) {
     const size_t mb = argc > 1 ? atoi(argv[1]) : 32;
     const int first_mode = argc > 2 ? atoi(argv[2]) : 0;
@@ -255,7 +291,7 @@ int main(int argc, char **argv) {
     static float h_rows[4096 * 256], h_rows8[8 * 256]; static long long h_acc[32 * 256 * 2];
     for (int cs2 : {16, 32, 128, 256})
         for (int grid : {256, 512, 1024, 1536})
-            for (int mode = first_mode; mode < 10; ++mode) {
+            for (int mode = first_mode; mode < 12; ++mode) {
                 if (mode == 2 && cur_cs2 != (unsigned)cs2) { hipMemset(flag, 0, 256); launches = 0; cur_cs2 = cs2; hipDeviceSynchronize(); }
                 const int R = mode == 4 ? 8 : (mode == 5 ? 32 : 1);        // modes 4 / 5 / 6: chain E with 8 / 32 / 1 replica rows
                 unsigned it_no = 0;
@@ -266,6 +302,8 @@ int main(int argc, char **argv) {
                     else if (mode == 2) { producer<<<grid, 256>>>(a, b, n, rows, cs2); ++launches; consumer_lead<<<grid + cs2, 256>>>(b, c, n, rows, grid, cs2, scale, flag, launches * cs2, flag + 32); }
                     else if (mode == 8) { producer_int<<<grid, 256>>>(a, b, n, acc, 8, cs2); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }   // E's producer side only (totals grow: never read)
                     else if (mode == 9) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer_int<<<grid, 256>>>(b, c, n, acc, acc + acc_words, 8, cs2); }      // E's consumer side only (stale rows)
+                    else if (mode == 10) { producer_wt<1><<<grid, 256>>>(a, b, n, rows, cs2); consumer_wt<1><<<grid, 256>>>(b, c, n, cs2, scale); }     // floor, write-through stores
+                    else if (mode == 11) { producer_wt<0><<<grid, 256>>>(a, b, n, rows, cs2); consumer_wt<0><<<grid, 256>>>(b, c, n, cs2, scale); }     // floor, plain stores (same kernels)
                     else if (mode == 7) { producer<<<grid, 256>>>(a, b, n, rows, cs2); consumer<false><<<grid, 256>>>(b, c, n, rows, grid, cs2, scale); }    // floor: no reduction at all (stale scale)
                     else if (mode == 3) { producer_xcd<<<grid, 256>>>(a, b, n, rows, cs2, counters, rows8, xcc_of, split); consumer_rows<<<grid, 256>>>(b, c, n, rows8, 8, cs2); }
                     else {
@@ -279,7 +317,7 @@ int main(int argc, char **argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 static const char *names[] = {"finalize launch (today)", "consumer re-reduces    ", "leading finalize blocks", "XCD-local ticket, 8 rows", "int64 atomics,  8 rows  ",
-                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   ", "FLOOR: two launches, no reduction", "E producer side only (atomics)", "E consumer side only (8 rows) "};
+                                              "int64 atomics, 32 rows  ", "int64 atomics,  1 row   ", "FLOOR: two launches, no reduction", "E producer side only (atomics)", "E consumer side only (8 rows) ", "FLOOR, sc1 (write-through) stores", "FLOOR, plain stores (same code) "};
                 printf("%zu MiB, 2cs %3d, %4d rows (%3d KB per consumer workgroup): %s %.2f us per producer + consumer\n", mb, cs2, grid, grid * cs2 * 4 / 1024,
                        names[mode], ms * 1000 / 100);
                 if (mode == 2) { unsigned e = 0; hipMemcpy(&e, flag + 32, 4, hipMemcpyDeviceToHost); if (e) printf("   !! %u poll time-outs\n", e); }
