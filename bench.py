@@ -321,25 +321,45 @@ def cpu_baseline(cfg, n_unl, n_lab, fwd_flops):
 
 
 def png_io_rate(images):
-    """PNG encode / decode rate of the host path the directory API uses (Pillow on a thread pool; SURVEY H5: excluded
-    from the headline on both the GPU and the CPU side, reported separately)."""
+    """PNG encode / decode rate of the host path the directory API uses (libimk's own codec, csrc/imk_png.cpp, one file per call on a
+    thread pool -- ctypes drops the interpreter lock; SURVEY H5: excluded from the headline on both the GPU and the CPU side,
+    reported separately), with Pillow on the same pool beside it (what rounds 1-4 used)."""
+    import ctypes
     import io
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    threads = int(os.environ.get("IMK_IO_THREADS", min(16, os.cpu_count() or 8)))
+    from inconsistencymasks_amd import functions as F
+    from inconsistencymasks_amd._lib import lib
+    threads = F._IO_THREADS
     sq = lambda a: a[..., 0] if a.shape[-1] == 1 else a
+    h, w, c = images[0].shape
     def enc(a):
+        a = np.ascontiguousarray(a)
+        buf = np.empty(a.nbytes + h + a.nbytes // 500 + 4096, dtype=np.uint8)
+        n = ctypes.c_int64()
+        assert lib.imk_png_encode(a.ctypes.data, h, w, c, 1, buf.ctypes.data, buf.nbytes, ctypes.byref(n)) == 0
+        return buf[:n.value].tobytes()
+    def dec(b):
+        out = np.empty((h, w, c), dtype=np.uint8)
+        assert lib.imk_png_decode(b, len(b), c, out.ctypes.data, out.nbytes, None, None) == 0
+        return out
+    def enc_p(a):
         b = io.BytesIO()
         Image.fromarray(sq(a)).save(b, format="PNG", compress_level=1)
         return b.getvalue()
-    def dec(b):
+    def dec_p(b):
         return np.asarray(Image.open(io.BytesIO(b)))
     with ThreadPoolExecutor(max_workers=threads) as pool:
         t0 = time.perf_counter(); blobs = list(pool.map(enc, images)); t1 = time.perf_counter()
         back = list(pool.map(dec, blobs)); t2 = time.perf_counter()
-    assert np.array_equal(back[0], sq(images[0]))
+        t3 = time.perf_counter(); blobs_p = list(pool.map(enc_p, images)); t4 = time.perf_counter()
+        back_p = list(pool.map(dec_p, blobs_p)); t5 = time.perf_counter()
+    assert all(np.array_equal(b, a) for a, b in zip(images, back)) and np.array_equal(sq(back_p[0]), sq(images[0]))
+    assert np.array_equal(dec_p(blobs[0]).reshape(images[0].shape), images[0])       # Pillow reads what the native encoder wrote
     return {"encode_images_per_s": round(len(images) / (t1 - t0), 1), "decode_images_per_s": round(len(images) / (t2 - t1), 1),
-            "threads": threads, "sample": f"{len(images)} images {'x'.join(map(str, images[0].shape))}, Pillow compress_level=1"}
+            "threads": threads, "codec": "libimk (imk_png_encode / imk_png_decode: zlib level 1, filters None / Sub / Up per row)",
+            "pillow_encode_images_per_s": round(len(images) / (t4 - t3), 1), "pillow_decode_images_per_s": round(len(images) / (t5 - t4), 1),
+            "sample": f"{len(images)} images {'x'.join(map(str, images[0].shape))}"}
 
 
 FAMILIES = ["conv_mfma_kernel<16,1>", "conv_mfma_kernel<16,2>", "conv_mfma_kernel<16,4>", "conv_mfma_kernel<8,1>",
@@ -962,7 +982,7 @@ def run_config(args, config_name, alpha, env, primary):
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is a 1-GPU-run item (rank 0 only)
             out["cpu_baseline"] = cpu_baseline(cfg, U_total, L_total, fwd_flops)
             out["cpu_baseline"]["parity_sample"] = parity_sample(cfg, models, x_unl)
-            out["png_io"] = png_io_rate(x_unl[:64].cpu().numpy())
+            out["png_io"] = png_io_rate(x_unl[:512].cpu().numpy())
     prof.close()
     return out if rank == 0 else None
 

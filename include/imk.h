@@ -307,6 +307,21 @@ IMK_API int imk_unet_plan_get_bn_momentum(const imk_unet_plan *plan, float *mome
  *     back to back), so that per-kernel timings are exclusive.  Results are identical either way. */
 IMK_API int imk_unet_plan_debug(imk_unet_plan *plan, int materialize, int single_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host-side PNG codec of the directory API (csrc/imk_png.cpp).  Replaces cv2.imread / cv2.imwrite of the
+ * reference's writers and parsers (functions.py:2846, 2885-2887, 955-1048) for the files this path reads and writes.  ALL
+ * pointers are HOST pointers; no GPU call is made; thread-safe and re-entrant (one file per call: callers parallelise over files,
+ * ctypes drops the interpreter lock around the call).  Decoder: 8-bit greyscale / RGB / palette / greyscale + alpha / RGBA,
+ * non-interlaced; anything else returns IMK_EUNSUPPORTED (the Python layer then uses Pillow).  want_c = 3: RGB (alpha dropped,
+ * palette expanded, grey replicated); want_c = 1: Pillow's convert("L").  Encoder: 8-bit greyscale (c = 1) or RGB (c = 3),
+ * deflate level 0-9.
+ * ---------------------------------------------------------------------------------------------- */
+IMK_API int imk_png_info(const char *path, int *h, int *w, int *color_type, int *bit_depth);
+IMK_API int imk_png_read_file(const char *path, int want_c, uint8_t *out, int64_t out_cap, int *h_out, int *w_out);
+IMK_API int imk_png_decode(const uint8_t *data, int64_t len, int want_c, uint8_t *out, int64_t out_cap, int *h_out, int *w_out);
+IMK_API int imk_png_encode(const uint8_t *pixels, int h, int w, int c, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+IMK_API int imk_png_write_file(const char *path, const uint8_t *pixels, int h, int w, int c, int level);
+
 /* Runtime environment checks.  imk_runtime_warnings() returns a bit mask of conditions the library has noticed so far in this
  * process (it also prints each once to stderr):
  *   IMK_WARN_HW_QUEUES  a side stream was requested (training step, ensemble forward) while GPU_MAX_HW_QUEUES is unset or

@@ -92,6 +92,11 @@ SIGNATURES = {
     "imk_prof_set_period": (c_int, [c_void_p, c_int]),
     "imk_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_double)]),
+    "imk_png_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "imk_png_read_file": (c_int, [ctypes.c_char_p, c_int, c_void_p, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "imk_png_decode": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "imk_png_encode": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
+    "imk_png_write_file": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_int]),
     "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_float, c_float, c_float, c_void_p]),
 }

@@ -42,7 +42,7 @@ def build_lib(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
     if force or procs or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]      # zlib: the host PNG codec (imk_png.cpp)
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -40,9 +40,10 @@ NUM_EPOCHS = int(_D.get("NUM_EPOCHS", 50))
 NUM_EPOCHS_CS = int(_D.get("NUM_EPOCHS_CS", 100))
 
 INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 256))
-# PNG decode / encode threads (Pillow releases the GIL inside the codecs; measured on the MI355X host, 256 x 256 x 3 images:
-# 8 / 16 / 32 / 64 threads -> encode 1.5 / 2.3 / 3.2 / 1.4 k images/s, decode 2.8 / 4.4 / 2.7 / 2.8 k images/s)
-_IO_THREADS = int(os.environ.get("IMK_IO_THREADS", min(16, os.cpu_count() or 8)))
+# PNG decode / encode threads.  Pillow on a thread pool (rounds 1-4) stopped scaling at ~32 threads on the 256-CPU MI355X host
+# (256 x 256 x 3 images: 8 / 16 / 32 / 64 / 128 threads -> 1.4 / 2.7 / 3.5 / 3.3 / 3.1 k encoded images/s: the interpreter lock);
+# the native codec (csrc/imk_png.cpp) holds no lock, so the pool is as wide as half the host's CPUs, at most 64.
+_IO_THREADS = int(os.environ.get("IMK_IO_THREADS", min(64, max(4, (os.cpu_count() or 8) // 2))))      # native codec: scales with cores
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -84,19 +85,45 @@ def shard_list(items, rank=None, world=None):
 # ---------------------------------------------------------------------------------------------------
 # PNG I/O (host)
 # ---------------------------------------------------------------------------------------------------
-def read_png(path, channels):
-    """uint8 [H,W,C] in RGB order (C=3) or [H,W,1] (C=1).  The reference reads BGR with cv2 and converts
-    to RGB for the net (functions.py:2846-2848); on-disk channel order is preserved either way."""
+# PNG files go through libimk's own host codec (csrc/imk_png.cpp: zlib + the PNG container, one file per call, no interpreter lock
+# held) -- Pillow on a thread pool stopped scaling at 2.7 k encoded images/s, an eighth of what the GPU stages produce.  Pillow
+# stays the decoder of what the native one declines (16-bit, 1/2/4-bit, interlaced files) and can be forced for both directions
+# with IMK_PNG=pillow.
+_NATIVE_PNG = os.environ.get("IMK_PNG", "native").lower() != "pillow"
+
+
+def _read_png_pillow(path, channels):
     with Image.open(path) as im:
         im = im.convert("RGB" if channels == 3 else "L")
         a = np.asarray(im, dtype=np.uint8)
     return a if a.ndim == 3 else a[..., None]
 
 
+def read_png(path, channels):
+    """uint8 [H,W,C] in RGB order (C=3) or [H,W,1] (C=1).  The reference reads BGR with cv2 and converts
+    to RGB for the net (functions.py:2846-2848); on-disk channel order is preserved either way."""
+    if _NATIVE_PNG:
+        import ctypes
+        from ._lib import lib
+        h, w = ctypes.c_int(), ctypes.c_int()
+        bpath = os.fsencode(path)
+        if lib.imk_png_info(bpath, ctypes.byref(h), ctypes.byref(w), None, None) == 0:
+            out = np.empty((h.value, w.value, 3 if channels == 3 else 1), dtype=np.uint8)
+            if lib.imk_png_read_file(bpath, 3 if channels == 3 else 1, out.ctypes.data, out.nbytes, None, None) == 0:
+                return out
+    return _read_png_pillow(path, channels)
+
+
 def write_png(path, arr):
     arr = np.asarray(arr, dtype=np.uint8)
     if arr.ndim == 3 and arr.shape[2] == 1:
         arr = arr[..., 0]
+    if _NATIVE_PNG and (arr.ndim == 2 or (arr.ndim == 3 and arr.shape[2] == 3)):
+        from ._lib import check, lib
+        a = np.ascontiguousarray(arr)
+        check(lib.imk_png_write_file(os.fsencode(path), a.ctypes.data, a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3, 1),
+              f"imk_png_write_file({path})")
+        return
     Image.fromarray(arr).save(path, format="PNG", compress_level=1)
 
 
