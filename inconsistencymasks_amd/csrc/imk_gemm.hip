@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // workgroup id -> (spatial tile, output-channel group): the groups of one tile are consecutive on one XCD
+    // (Round 5, measured and removed: a persistent walk -- at most 512 / 1 024 workgroups, each taking tile id, id + grid, ..., the next
+    //  tile's first-stage loads and weight fragments issued during the current tile's second-to-last stage so that they land under the
+    //  epilogue; for the instantiations that have the registers, the others one tile per workgroup.  Bit-identical; Cityscapes alpha 2
+    //  step 4.89-4.91 ms against 4.85 for this form, 128-image inference 4.25 against 4.19-4.25, SUIM / HeLa / EvalNet within +-0.5 %
+    //  (profiles/r05_ab6.txt): with two workgroups per CU the other workgroup already fills a tile's prologue.  The affine table
+    //  moved behind the epilogue's LDS and the walk's state alone cost the one-shot path 4 % in inference.)
     const int id = blockIdx.x;
     const int xcd = id & 7, jj = id >> 3;
     const int by = jj % gm.gy;
