@@ -1521,6 +1521,89 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ImkWgradArgs a, ImkWgra
 }
 
 
+// ---- the input block's weight gradient as a streaming reduction (round 5) ------------------------------------------------------
+// dW[ci][co] = sum_px x[px][ci] * dA[px][co] for the Conv1x1 on the uint8 image (unet.py:5-6: 1-4 input channels, <= 8 outputs),
+// dA = the BatchNorm backward + ReLU mask of (dy, z) formed on load -- the LAST weight gradient of a step, alone on the chip with the
+// optimizer waiting behind it.  The MFMA kernel staged 256-pixel tiles through LDS for a 3 x 8 result and moved its 70 MB at 2.9 TB/s;
+// here a thread walks pixels (two in flight), keeps the 4 x 8 + 8 sums in registers, and a workgroup leaves one partial row in the
+// layout wgf_stage1 / 2 expect (element r * 64 + l <-> ci = 4 (l >> 4) + r, co = l & 15; the bias row's element co).  Same operands
+// as the matrix-core form (x and dA rounded to fp16, products and sums in fp32), another summation order.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t *__restrict__ x, int cin, float u8_div, const f16 *__restrict__ dy,
+                                                         const f16 *__restrict__ z, const float *__restrict__ coef /*[3][8]*/,
+                                                         long long n_pix, float *__restrict__ partial) {
+    __shared__ float s_c[3][8];
+    __shared__ float s_red[4][40];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 24) s_c[t >> 3][t & 7] = coef[t];
+    __syncthreads();
+    float A[8], Bc[8], Cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { A[j] = s_c[0][j]; Bc[j] = s_c[1][j]; Cc[j] = s_c[2][j]; }
+    float acc[4][8], bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bsum[j] = 0.f; acc[0][j] = acc[1][j] = acc[2][j] = acc[3][j] = 0.f; }
+    const float inv = 1.0f / u8_div;
+    const long long stride = (long long)gridDim.x * 256;
+    struct Px { f16x8 d, zz; uint32_t xb; };
+    auto load = [&](long long p, Px &q) {
+        q.d = *reinterpret_cast<const f16x8 *>(dy + p * 8);
+        q.zz = *reinterpret_cast<const f16x8 *>(z + p * 8);
+        // one unaligned dword per pixel (byte loads made this gradient issue-bound: imk_stage.h); the tensor's last pixels take theirs a
+        // few bytes early, so nothing behind the images is read
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        const long long rem = (n_pix - p) * cin;
+        const int back = rem >= 4 ? 0 : (int)(4 - rem);
+        const uint32_t v = *reinterpret_cast<const u32_unaligned *>(x + p * cin - back) >> (8 * back);
+        q.xb = cin >= 4 ? v : (v & ((1u << (8 * cin)) - 1u));
+    };
+    auto use = [&](const Px &q) {
+        float xf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xf[c] = (float)(f16)((float)((q.xb >> (8 * c)) & 0xffu) * inv);      // == x / u8_div in fp16 for every byte (imk_stage.h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zf = (float)q.zz[j];
+            const float g = zf > 0.f ? (float)(f16)(A[j] * (float)q.d[j] + Bc[j] * zf + Cc[j]) : 0.f;
+            bsum[j] += g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c][j] += xf[c] * g;
+        }
+    };
+    long long p = (long long)blockIdx.x * 256 + t;
+    if (p < n_pix) {
+        Px cur, nxt;
+        load(p, cur);
+        while (true) {
+            const long long pn = p + stride;
+            const bool more = pn < n_pix;
+            load(more ? pn : p, nxt);
+            use(cur);
+            if (!more) break;
+            cur = nxt;
+            p = pn;
+        }
+    }
+    // lanes (butterfly), then the four waves in order: fixed association
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wave_sum<64>(acc[c][j]);
+            if (lane == 0) s_red[wave][c * 8 + j] = v;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = wave_sum<64>(bsum[j]);
+        if (lane == 0) s_red[wave][32 + j] = v;
+    }
+    __syncthreads();
+    auto tot = [&](int i) { return (s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i]); };
+    float *row = partial + (size_t)blockIdx.x * 2 * 256;
+    const int r = t >> 6, l = t & 63, ci = 4 * (l >> 4) + r, co = l & 15;
+    row[t] = (ci < 4 && co < 8) ? tot(ci * 8 + co) : 0.f;
+    row[256 + t] = t < 8 ? tot(32 + t) : 0.f;
+}
+
 // ---- batched, deterministic reduction of all layers' weight-gradient partials -----------------------------
 __device__ __forceinline__ int wgf_find_job(const ImkWgFinalJobs &jobs, int idx, bool stage1) {
     int j = 0;
@@ -2445,6 +2528,16 @@ static double wgrad_algorithmic_bytes(const ImkWgradArgs &a, const WgradLaunch &
 }
 
 int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
+    // the input block (uint8 image -> <= 8 channels, BatchNorm behind it): a streaming reduction, not a matrix-core kernel
+    static const bool stem_off = []() { const char *e = getenv("IMK_STEM_WGRAD"); return e && e[0] == '0'; }();
+    if (!stem_off && a.x.lmode == LM_U8 && a.ksize == 1 && a.dA_z && a.dA_coef && a.cs_out == 8 && a.x.cin <= 4 && a.n_split >= 1) {
+        const long long n_pix = (long long)a.B * a.H * a.W;
+        ImkProfScope prof(PF_WGRAD, (double)n_pix * (a.x.cin + 32) + (double)a.n_split * 2 * 1024, stream, imk_wgrad_flops(a));
+        stem_wgrad_kernel<<<a.n_split, 256, 0, stream>>>(reinterpret_cast<const uint8_t *>(a.x.in), a.x.cin, a.x.u8_div, a.dA, a.dA_z, a.dA_coef,
+                                                        n_pix, a.partial);
+        IMK_LAUNCH_CHECK();
+        return IMK_OK;
+    }
     if (imk_wgrad_gemm_ok(a.x.lmode, a.dA_z != nullptr, a.ksize, a.x.cs_in, a.cs_out, (long long)a.B * a.H * a.W)) return imk_launch_wgrad_gemm(a, stream);
     WgradLaunch L{};
     int rc = plan_wgrad(a, L);
