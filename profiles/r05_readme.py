@@ -77,7 +77,8 @@ def main():
     out.append(f"""Headline (`r05_bench.json`): **{b['value']:.0f} images/s per IM generation on 1 GPU** -- {b['ms_per_step']} ms per generation =
 {b['stage_ms']['ensemble_infer_plus_im']} ms (ensemble forward + fused head / IM, calls of {b['config']['infer_batch']} images) + {b['stage_ms']['train_epoch']} ms ({b['config']['epoch_steps']} training steps of
 {r['step']['train_step']['ms']} ms; {b['config'].get('kept')} of the 2 335 pseudo-labelled pairs kept) -- next to {cb['value']} images/s for the CPU restatement ({cb['cpu_model']},
-{cb['threads_forward']} / {cb['threads_train_step']} threads).  Round 4 ended at 24 793 (94.18 ms).  Boxes differ by 1-3 %: the round's one-box comparisons against round 4's library show the
+{cb['threads_forward']} / {cb['threads_train_step']} threads).  Round 4 ended at 24 793 (94.18 ms); this build measured 25 006 (93.38 ms, 78 steps) and 25 177 on the round's other
+boxes -- boxes differ by 1-3 % and the step count (78 / 80) follows how many pairs the ensemble keeps: the round's one-box comparisons against round 4's library show the
 training step unchanged (0.985-0.991 ms either way, `r05_ab3.txt`) and the inference stage 2 % shorter (calls of 584 instead of 256 images).
 `cpu_baseline.parity_sample`: max |dp| {ps['max_abs_dp']} on the trained ensemble, {ps['fixed_weights'].get('max_abs_dp')} on fixed weights, {ps['decision_flip_rate']:.1e} of the decisions
 flip, {ps['im_pixels_differing']} of {ps['im_pixels_total']} IM pixels differ (SURVEY H4: IM masks are bit-identical GIVEN identical probabilities; GPU-vs-CPU probabilities differ by fp16 rounding).
