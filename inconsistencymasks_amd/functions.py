@@ -140,10 +140,15 @@ _PENDING = {}                                       # thread id -> futures that 
 _PENDING_LOCK = __import__("threading").Lock()      # candidates training on threads (im_driver) queue writes concurrently
 
 
-def write_png_async(path, arr):
+def _submit_write(job):
+    """queue `job()` (a PNG write, possibly with its last host-side preparation) on the writer pool, on the calling thread's account"""
     with _PENDING_LOCK:
         _ensure_write_pool()
-        _PENDING.setdefault(__import__("threading").get_ident(), []).append(_WRITE_POOL.submit(write_png, path, arr))
+        _PENDING.setdefault(__import__("threading").get_ident(), []).append(_WRITE_POOL.submit(job))
+
+
+def write_png_async(path, arr):
+    _submit_write(lambda: write_png(path, arr))
 
 
 def _ensure_write_pool():
@@ -942,12 +947,22 @@ def get_IoU_multi_unique(pred, gt):
     return total / len(classes)
 
 
-def convert_class_to_color_mask(class_mask, output_path, class_to_color_mapping):
-    """functions.py:6127-6149 (the mapping is colour -> class value; file written in RGB order on disk)."""
-    color = np.zeros(tuple(class_mask.shape) + (3,), dtype=np.uint8)
+def _color_lut(class_to_color_mapping):
+    """class id -> RGB as a 256-row table: what the reference's loop `color[class_mask == cls] = col` over the colour -> class dict
+    computes (functions.py:6127-6149; for a class listed twice the LAST colour wins, classes that are not listed stay black)"""
+    lut = np.zeros((256, 3), dtype=np.uint8)
     for col, cls in class_to_color_mapping.items():
-        color[class_mask == cls] = col
-    write_png_async(output_path, color)
+        lut[int(cls) & 255] = col
+    return lut
+
+
+def convert_class_to_color_mask(class_mask, output_path, class_to_color_mapping):
+    """functions.py:6127-6149 (the mapping is colour -> class value; file written in RGB order on disk).  One table gather instead of
+    a masked assignment per class: the loop cost 1 ms per 256 x 256 map on the caller's thread -- half of a multiclass candidate's
+    wall time in a real SUIM run (tests/gpu_probe/full_driver_run_suim.py) -- and the gather runs on the writer pool with the encode."""
+    lut = _color_lut(class_to_color_mapping)
+    cm = np.asarray(class_mask, dtype=np.uint8)
+    _submit_write(lambda: write_png(output_path, lut[cm]))
 
 
 class MeanIoU:

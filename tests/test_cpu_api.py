@@ -503,3 +503,21 @@ def test_dp_bn_momentum_rule(monkeypatch):
     monkeypatch.setenv("IMK_DP_BN_MOMENTUM", "bogus")
     with pytest.raises(ValueError):
         F.dp_bn_momentum_rule(2)
+
+
+def test_color_mask_table_equals_the_reference_loop(tmp_path):
+    """convert_class_to_color_mask (functions.py:6127-6149) as one table gather: identical to the reference's per-class masked
+    assignment for the SUIM and Cityscapes palettes, for ids without a colour (black) and for a class listed twice (last wins)."""
+    from inconsistencymasks_amd import functions as F, im_driver
+    rng = np.random.default_rng(0)
+    cases = [(im_driver.color_mapping("SUIM", 9), 11), (im_driver.color_mapping("Cityscapes", 35), 40),
+             ({(1, 2, 3): 1, (9, 9, 9): 1, (5, 5, 5): 2}, 4)]
+    for i, (mapping, hi) in enumerate(cases):
+        cm = rng.integers(0, hi, (37, 53)).astype(np.uint8)
+        want = np.zeros(cm.shape + (3,), np.uint8)
+        for col, cls in mapping.items():
+            want[cm == cls] = col
+        p = str(tmp_path / f"c{i}.png")
+        F.convert_class_to_color_mask(cm, p, mapping)
+        F.flush_writes()
+        assert np.array_equal(F.read_png(p, 3), want)
