@@ -322,6 +322,25 @@ IMK_API int imk_png_decode(const uint8_t *data, int64_t len, int want_c, uint8_t
 IMK_API int imk_png_encode(const uint8_t *pixels, int h, int w, int c, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
 IMK_API int imk_png_write_file(const char *path, const uint8_t *pixels, int h, int w, int c, int level);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host-side geometry of the HeLa position masks (csrc/imk_geom.cpp).  HOST pointers, no GPU call,
+ * thread-safe and re-entrant (one image per call).  Replace the reference's OpenCV calls:
+ *   imk_pos_contours  functions.py:6181-6218 get_pos_contours: cv2.erode (erode_kernel x erode_kernel, odd or 0/1 for none) ->
+ *                     threshold > 10 -> cv2.findContours(RETR_TREE) -> cv2.moments -> (int(m10 / m00) + 1, int(m01 / m00) + 1)
+ *                     for every contour with m00 != 0 (blobs in raster order of their first pixel, each followed by its holes).
+ *                     Writes up to `cap` (x, y) pairs, returns the number found (> cap: call again with a larger buffer) or a
+ *                     negative IMK_E* code.
+ *   imk_mod_pos_size  functions.py:6255-6292 mod_pos_size: blobs (3 x 3 erosion) re-drawn with cv2.circle of radius
+ *                     clamp(min_dist // 4, min_r, max_r); blur2 != 0: cv2.blur (2, 2), < 254 -> 0.  lone_dist: the distance
+ *                     used when the mask holds exactly one position (0 in mod_pos_size; 99 and blur2 = 0 in the pseudo-label
+ *                     writer, functions.py:2952-2966).  out: h x w uint8 in {0, 255}.
+ *   imk_cell_count    functions.py:6298-6371 get_cell_count: counts = {alive, dead, unclear} over the positions.
+ * ---------------------------------------------------------------------------------------------- */
+IMK_API int imk_pos_contours(const uint8_t *img, int h, int w, int erode_kernel, int32_t *xy, int cap);
+IMK_API int imk_mod_pos_size(const uint8_t *img, int h, int w, int max_r, int min_r, int lone_dist, int blur2, uint8_t *out);
+IMK_API int imk_cell_count(const int32_t *xy, int n, const uint8_t *alive, const uint8_t *dead, int h, int w,
+                           int measuring_range, int32_t counts[3]);
+
 /* Runtime environment checks.  imk_runtime_warnings() returns a bit mask of conditions the library has noticed so far in this
  * process (it also prints each once to stderr):
  *   IMK_WARN_HW_QUEUES  a side stream was requested (training step, ensemble forward) while GPU_MAX_HW_QUEUES is unset or

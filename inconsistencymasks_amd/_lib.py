@@ -97,6 +97,9 @@ SIGNATURES = {
     "imk_png_decode": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "imk_png_encode": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     "imk_png_write_file": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "imk_pos_contours": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
+    "imk_mod_pos_size": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "imk_cell_count": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "imk_unet_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_float, c_float, c_float, c_void_p]),
 }

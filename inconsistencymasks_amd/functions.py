@@ -1080,87 +1080,37 @@ def _erode3(mask):
     return ndimage.grey_erosion(mask, size=(3, 3), mode="constant", cval=255)
 
 
-def _trace_outer_border(comp):
-    """Outer border of one 8-connected component (boolean array, padded by one background pixel on every side), followed
-    clockwise from its top-left pixel with Moore-neighbour tracing -- the closed polygon through the border pixels' centres
-    that cv2.findContours reports for an outer contour (CHAIN_APPROX_SIMPLE only drops collinear points, which changes
-    neither the area nor the moments).  Returns the vertices as (x, y) in visiting order."""
-    ys, xs = np.nonzero(comp)
-    y0 = int(ys.min())
-    x0 = int(xs[ys == y0].min())
-    nbr = [(-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1)]     # (dy, dx), clockwise from north
-    pts = [(x0, y0)]
-    cy, cx, back = y0, x0, 6          # we "came from" the west: the pixel left of the start is background
-    first_move = None
-    for _ in range(4 * comp.size + 8):
-        for k in range(1, 9):          # first foreground pixel clockwise after the backtrack direction
-            d = (back + k) % 8
-            ny, nx = cy + nbr[d][0], cx + nbr[d][1]
-            if comp[ny, nx]:
-                break
-        else:
-            return pts                 # isolated pixel
-        if first_move is None:
-            first_move = (cy, cx, d)
-        elif (cy, cx, d) == first_move:
-            return pts[:-1]            # back at the start, about to repeat the first move: the polygon is closed
-        cy, cx = ny, nx
-        back = (d + 4) % 8             # direction pointing back to where we came from
-        pts.append((cx, cy))
-    return pts
-
-
-def _polygon_moments(pts):
-    """m00, m10, m01 of a closed polygon (Green's theorem), as cv2.moments computes them for a contour"""
-    a = m10 = m01 = 0.0
-    n = len(pts)
-    for i in range(n):
-        x0, y0 = pts[i]
-        x1, y1 = pts[(i + 1) % n]
-        cr = x0 * y1 - x1 * y0
-        a += cr
-        m10 += (x0 + x1) * cr
-        m01 += (y0 + y1) * cr
-    return a / 2.0, m10 / 6.0, m01 / 6.0
+def _u8_plane(img):
+    """one contiguous uint8 plane of a 2-D / [h, w, 1] / [h, w, 3] image (functions.py:6186-6194: BGR -> grey)"""
+    a = np.asarray(img)
+    assert a.ndim in (2, 3), "Invalid image dimensions."
+    if a.ndim == 3:
+        a = a[..., 0] if a.shape[2] == 1 else (0.114 * a[..., 0] + 0.587 * a[..., 1] + 0.299 * a[..., 2]).astype(np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
 
 
 def get_pos_contours(img, erode_kernel=3):
     """functions.py:6181-6218: centres (x, y) of the blobs of a position mask.  The reference erodes, thresholds at 10,
     takes cv2.findContours + cv2.moments of every contour and reports (int(m10 / m00) + 1, int(m01 / m00) + 1), skipping
-    contours whose polygon area m00 is zero (single pixels, one-pixel-wide lines).  Restated here with connected components
-    (scipy), Moore-neighbour border tracing and Green's-theorem polygon moments.  RETR_TREE also reports every HOLE of a blob
-    as a contour of its own -- the blob's pixels that have a pixel of the hole in their 4-neighbourhood (Suzuki-Abe border
-    following with 8-connected blobs and 4-connected holes) -- and the reference's loop adds a position for each: here a hole is a
-    4-connected background component that does not reach the blob's bounding box, and its contour is traced as the outer border of
-    (hole + that ring of blob pixels).  Unpinned: OpenCV is not available to the reference in this environment."""
-    from scipy import ndimage
-    a = np.asarray(img)
-    assert a.ndim in (2, 3), "Invalid image dimensions."
-    if a.ndim == 3:
-        a = a[..., 0] if a.shape[2] == 1 else (0.114 * a[..., 0] + 0.587 * a[..., 1] + 0.299 * a[..., 2]).astype(np.uint8)
-    if erode_kernel > 0:
-        a = ndimage.grey_erosion(a.astype(np.uint8), size=(erode_kernel, erode_kernel), mode="constant", cval=255)
-    lab, n = ndimage.label(a > 10, structure=np.ones((3, 3)))
-    cross = ndimage.generate_binary_structure(2, 1)
-    pos = []
-    for sl, idx in zip(ndimage.find_objects(lab), range(1, n + 1)):
-        comp = np.pad(lab[sl] == idx, 1)
-        pts = _trace_outer_border(comp)
-        m00, m10, m01 = _polygon_moments(pts)
-        if m00 != 0:
-            cx = m10 / m00 + sl[1].start - 1        # back to image coordinates (the component was cropped and padded)
-            cy = m01 / m00 + sl[0].start - 1
-            pos.append((int(cx) + 1, int(cy) + 1))
-        bg, nb = ndimage.label(~comp, structure=cross)
-        for h in range(1, nb + 1):
-            if h == bg[0, 0]:                        # the outside (the padding ring belongs to it)
-                continue
-            hole = bg == h
-            ring = ndimage.binary_dilation(hole, structure=cross) & comp
-            m00, m10, m01 = _polygon_moments(_trace_outer_border(hole | ring))
-            if m00 != 0:
-                pos.append((int(m10 / m00 + sl[1].start - 1) + 1, int(m01 / m00 + sl[0].start - 1) + 1))
-    return pos
+    contours whose polygon area m00 is zero (single pixels, one-pixel-wide lines); RETR_TREE also reports every HOLE of a blob
+    as a contour of its own and the reference's loop adds a position for each.  Host C++ (csrc/imk_geom.cpp imk_pos_contours:
+    connected components, Moore-neighbour border tracing, Green's-theorem polygon moments; the interpreter lock is released
+    around the call), checked bit for bit against the numpy / scipy restatement in oracle/hela_geometry.py.  Unpinned: OpenCV
+    is not available to the reference in this environment."""
+    a = _u8_plane(img)
+    k = int(erode_kernel)
+    if k > 1 and k % 2 == 0:          # an even window has no centre: scipy's placement, then the native path without erosion
+        from scipy import ndimage
+        a, k = np.ascontiguousarray(ndimage.grey_erosion(a, size=(k, k), mode="constant", cval=255)), 0
+    cap = 256
+    while True:
+        xy = np.empty((cap, 2), np.int32)
+        n = lib.imk_pos_contours(a.ctypes.data, a.shape[0], a.shape[1], max(k, 0), xy.ctypes.data, cap)
+        if n < 0:
+            check(n, "imk_pos_contours")
+        if n <= cap:
+            return [(int(x), int(y)) for x, y in xy[:n]]
+        cap = n
 
 
 def get_min_dist(xy, positions):
@@ -1170,68 +1120,31 @@ def get_min_dist(xy, positions):
     return 0 if d.size == 0 else float(np.min(d))
 
 
-def _disc(img, cx, cy, r, value):
-    """cv2.circle(img, (cx, cy), r, value, -1): the filled circle of OpenCV's integer midpoint rasteriser (restated from
-    the published algorithm of imgproc's drawing code: horizontal spans cy +- dy: [cx - dx, cx + dx] and cy +- dx:
-    [cx - dy, cx + dy] while dx >= dy, error update err += 2 dy + 1, step dx inwards when err > 0), clipped to the image.
-    Not the Euclidean disc: r = 3 gives rows of 1, 5, 5, 7, 5, 5, 1 pixels.  Unpinned (needs OpenCV in the reference)."""
-    h, w = img.shape[:2]
-
-    def span(y, x0, x1):
-        if 0 <= y < h:
-            x0, x1 = max(x0, 0), min(x1, w - 1)
-            if x0 <= x1:
-                img[y, x0:x1 + 1] = value
-
-    err, dx, dy, plus, minus = 0, int(r), 0, 1, 2 * int(r) - 1
-    while dx >= dy:
-        span(cy - dy, cx - dx, cx + dx); span(cy + dy, cx - dx, cx + dx)
-        span(cy - dx, cx - dy, cx + dy); span(cy + dx, cx - dy, cx + dy)
-        dy += 1
-        err += plus
-        plus += 2
-        if err > 0:
-            err -= minus
-            dx -= 1
-            minus -= 2
+def _redraw_positions(gray_img, max_r, min_r, lone_dist, blur2):
+    a = _u8_plane(gray_img)
+    out = np.empty(a.shape, np.uint8)
+    check(lib.imk_mod_pos_size(a.ctypes.data, a.shape[0], a.shape[1], int(max_r), int(min_r), int(lone_dist), int(blur2),
+                               out.ctypes.data), "imk_mod_pos_size")
+    return out
 
 
 def mod_pos_size(gray_img, max_pos_circle_size=8, min_pos_circle_size=3):
     """functions.py:6255-6292: redraw every position blob as a filled circle of radius clamp(min_dist // 4, 3, 8), then
     `cv2.blur(out, (2, 2))` and `out[out < 254] = 0`: a pixel survives iff its whole 2x2 window (itself, left, upper,
-    upper-left neighbour; BORDER_REFLECT_101 at the image edge) is set."""
-    positions = get_pos_contours(gray_img)
-    out = np.zeros(gray_img.shape, np.uint8)
-    for p in positions:
-        r = int(get_min_dist(p, positions) // 4)
-        r = max(min(r, max_pos_circle_size), min_pos_circle_size)
-        _disc(out, p[0], p[1], r, 255)
-    on = np.pad(out > 0, ((1, 0), (1, 0)), mode="reflect")            # row / column -1 -> row / column 1
-    keep = on[1:, 1:] & on[1:, :-1] & on[:-1, 1:] & on[:-1, :-1]
-    return np.where(keep, 255, 0).astype(np.uint8)
+    upper-left neighbour; BORDER_REFLECT_101 at the image edge) is set.  Host C++ (imk_mod_pos_size)."""
+    return _redraw_positions(gray_img, max_pos_circle_size, min_pos_circle_size, 0, 1)
 
 
 def get_cell_count(positions, img_alive, img_dead, measuring_range=3):
-    """functions.py:6298-6371."""
-    a = (np.asarray(img_alive) > 10).astype(np.int64) * 255
-    dd = (np.asarray(img_dead) > 10).astype(np.int64) * 255
-    ih, iw = a.shape[:2]
-    alive = dead = unclear = 0
-    m = measuring_range
-    for x, y in positions:
-        if x - m <= 0:
-            x += m
-        if x + m > iw:
-            x = iw - m
-        if y - m < 0:
-            y += m
-        if y + m > ih:
-            y = ih - m
-        sa, sd = a[y - m:y + m, x - m:x + m].sum(), dd[y - m:y + m, x - m:x + m].sum()
-        alive += sa > sd
-        dead += sd > sa
-        unclear += sa == sd
-    return int(alive), int(dead), int(unclear)
+    """functions.py:6298-6371.  Host C++ (imk_cell_count)."""
+    a = np.ascontiguousarray(img_alive, dtype=np.uint8)
+    d = np.ascontiguousarray(img_dead, dtype=np.uint8)
+    xy = np.ascontiguousarray(np.asarray(positions, np.int32).reshape(-1, 2))
+    counts = np.zeros(3, np.int32)
+    check(lib.imk_cell_count(xy.ctypes.data, xy.shape[0], a.ctypes.data, d.ctypes.data, a.shape[0], a.shape[1],
+                                   int(measuring_range), counts.ctypes.data), "imk_cell_count")
+    return int(counts[0]), int(counts[1]), int(counts[2])
+
 
 
 def parse_image_hela(path_brightfield, IMG_CHANNELS=1, Position_weight=3):
@@ -1269,24 +1182,22 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
                 im = _im.morph(im, dilate_kernel, "dilate")
             masks_np, im_np = masks.cpu().numpy(), im.cpu().numpy()
             ims = r["im_size"].sum(1).cpu().numpy()
-            jobs = []
-            for j, name in enumerate(chunk):
-                sum_im += int(ims[j]); count += 1
-                pos = np.zeros((h, w, 3), np.uint8)
-                positions = get_pos_contours(masks_np[j, 2])
-                for p in positions:
-                    md = get_min_dist(p, positions) if len(positions) > 1 else 99
-                    rad = max(min(int(md // 4), max_pos_circle_size), min_pos_circle_size)
-                    _disc(pos, p[0], p[1], rad, (255, 255, 255))
+            sum_im += int(ims.sum()); count += len(chunk)
+
+            def one(j):      # functions.py:2952-2966: circles from the RAW position mask, a lone cell drawn with distance 99
+                pos = _redraw_positions(masks_np[j, 2], max_pos_circle_size, min_pos_circle_size, 99, 0)
+                pos = np.repeat(pos[..., None], 3, 2)
                 bf, alive, dead = imgs[j][..., 0].copy(), masks_np[j, 0].copy(), masks_np[j, 1].copy()
                 hit = im_np[j] > 0
                 if block_input:
                     bf[hit] = 0
                 if block_output:
                     alive[hit] = 0; dead[hit] = 0; pos[hit] = 0
-                jobs += [(os.path.join(out["brightfield"], name), bf), (os.path.join(out["alive"], name), alive),
-                         (os.path.join(out["dead"], name), dead), (os.path.join(out["mod_position"], name), pos),
-                         (os.path.join(out["im"], name), im_np[j])]
+                name = chunk[j]
+                return [(os.path.join(out["brightfield"], name), bf), (os.path.join(out["alive"], name), alive),
+                        (os.path.join(out["dead"], name), dead), (os.path.join(out["mod_position"], name), pos),
+                        (os.path.join(out["im"], name), im_np[j])]
+            jobs = [job for per_image in pool.map(one, range(len(chunk))) for job in per_image]
             for job in jobs:
                 write_png_async(*job)
     flush_writes()
@@ -1303,25 +1214,32 @@ def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_s
     names = _bench_names(os.path.join(gt_main_dir, "brightfield"))
     mious, mious_ad, delta = [], [], 0
     rd = lambda k, n: read_png(os.path.join(gt_main_dir, k, n), 1)[..., 0]
-    for i in range(0, len(names), batch_size):
-        chunk = names[i:i + batch_size]
-        x = torch.from_numpy(np.stack([read_png(os.path.join(gt_main_dir, "brightfield", n), c) for n in chunk], 0)).cuda()
-        probs = model.predict_device(x).cpu().numpy()
-        for j, n in enumerate(chunk):
-            a_u, d_u, p_u = [((probs[j, ..., k] > threshold) * 255).astype(np.uint8) for k in range(3)]
-            if mod_position:
-                p_u = mod_pos_size(p_u)
-            if benchmark:
-                ga, gd, gp = rd("alive", n), rd("dead", n), rd("mod_position", n)
-                ia, idd, ip = (round(float(get_IoU_binary(g, p)), 4) for g, p in ((ga, a_u), (gd, d_u), (gp, p_u)))
-                mious.append((ia + idd + ip) / 3); mious_ad.append((ia + idd) / 2)
-                pa, pd, _ = get_cell_count(get_pos_contours(p_u), a_u, d_u)
-                qa, qd, _ = get_cell_count(get_pos_contours(gp), ga, gd)
-                delta += abs(pa - qa) + abs(pd - qd)
-            if save_output:
-                write_png_async(os.path.join(pred_dir, "alive", n), a_u)
-                write_png_async(os.path.join(pred_dir, "dead", n), d_u)
-                write_png_async(os.path.join(pred_dir, sub, n), p_u)
+    with _pool() as pool:        # per image: PNG decode + native geometry, both outside the interpreter lock
+        for i in range(0, len(names), batch_size):
+            chunk = names[i:i + batch_size]
+            imgs = list(pool.map(lambda n: read_png(os.path.join(gt_main_dir, "brightfield", n), c), chunk))
+            probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda()).cpu().numpy()
+
+            def one(j):
+                n = chunk[j]
+                a_u, d_u, p_u = [((probs[j, ..., k] > threshold) * 255).astype(np.uint8) for k in range(3)]
+                if mod_position:
+                    p_u = mod_pos_size(p_u)
+                score = None
+                if benchmark:
+                    ga, gd, gp = rd("alive", n), rd("dead", n), rd("mod_position", n)
+                    ia, idd, ip = (round(float(get_IoU_binary(g, p)), 4) for g, p in ((ga, a_u), (gd, d_u), (gp, p_u)))
+                    pa, pd, _ = get_cell_count(get_pos_contours(p_u), a_u, d_u)
+                    qa, qd, _ = get_cell_count(get_pos_contours(gp), ga, gd)
+                    score = ((ia + idd + ip) / 3, (ia + idd) / 2, abs(pa - qa) + abs(pd - qd))
+                return score, (a_u, d_u, p_u)
+            for n, (score, (a_u, d_u, p_u)) in zip(chunk, pool.map(one, range(len(chunk)))):
+                if score is not None:
+                    mious.append(score[0]); mious_ad.append(score[1]); delta += score[2]
+                if save_output:
+                    write_png_async(os.path.join(pred_dir, "alive", n), a_u)
+                    write_png_async(os.path.join(pred_dir, "dead", n), d_u)
+                    write_png_async(os.path.join(pred_dir, sub, n), p_u)
     mious, mious_ad, deltas = _gather_lists(mious, mious_ad, [delta])
     delta = sum(deltas)
     return (round(float(np.sum(mious) / len(mious)), 3), round(float(np.sum(mious_ad) / len(mious_ad)), 3),

@@ -432,6 +432,7 @@ def test_position_contour_centres_known_answers():
     rectangle's centre, a disc's centre, and NO position for blobs whose contour polygon has zero area (a single pixel, a
     one-pixel-wide line) -- cv2.moments gives m00 = 0 for those and the reference skips them."""
     from inconsistencymasks_amd import functions as F
+    from oracle import hela_geometry as G
     m = np.zeros((40, 40), np.uint8)
     m[10:21, 5:16] = 255                                   # rows 10..20, columns 5..15: centre (x 10, y 15)
     assert F.get_pos_contours(m, erode_kernel=0) == [(11, 16)]
@@ -445,7 +446,7 @@ def test_position_contour_centres_known_answers():
     assert F.get_pos_contours(disc, erode_kernel=0) == [(21, 31)]
     # the polygon of a 3x3 ring of pixels is the 2x2 square through their centres
     ring = np.pad(np.array([[1, 1, 1], [1, 0, 1], [1, 1, 1]], bool), 1)
-    assert F._polygon_moments(F._trace_outer_border(ring)) == (4.0, 8.0, 8.0)
+    assert G._polygon_moments(G._trace_outer_border(ring)) == (4.0, 8.0, 8.0)
     # RETR_TREE: a hole is a contour of its own (the blob pixels around it) and adds a position -- a square frame has two
     # concentric contours, both centred on the frame; a one-pixel hole's contour is the diamond of its 4 neighbours (area 2)
     frame = np.zeros((40, 40), np.uint8)

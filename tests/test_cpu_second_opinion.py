@@ -11,6 +11,7 @@ import pytest
 from scipy import ndimage
 
 from oracle import aug_oracle as A
+from oracle import hela_geometry as G
 from oracle import im_oracle as O
 
 
@@ -114,8 +115,8 @@ def test_contour_centres_against_scipy_centre_of_mass_and_picks_theorem():
         assert abs(com_x - cx) < 1e-9 and abs(com_y - cy) < 1e-9
         assert F.get_pos_contours(m, erode_kernel=0) == [(int(com_x) + 1, int(com_y) + 1)]
         comp = np.pad(lab == 1, 1)
-        pts = F._trace_outer_border(comp)
-        m00, m10, m01 = F._polygon_moments(pts)
+        pts = G._trace_outer_border(comp)
+        m00, m10, m01 = G._polygon_moments(pts)
         interior = ndimage.binary_erosion(comp, structure=ndimage.generate_binary_structure(2, 1))     # pixels whose 4 neighbours are all blob
         border = int(comp.sum() - interior.sum())
         assert len(set(pts)) == border                           # the trace visits every border pixel of a convex blob once
@@ -134,7 +135,7 @@ def test_position_disc_rasteriser_against_the_distance_definition():
     contain every pixel within r - 0.5 of the centre, none beyond r + 0.5, be symmetric under the 8 reflections, and its area must
     be within the lattice-point bounds of a disc of that radius"""
     from inconsistencymasks_amd import functions as F
-    draw = F._disc
+    draw = G._disc
     for r in range(1, 10):
         img = np.zeros((41, 41), np.uint8)
         draw(img, 20, 20, r, 255)
