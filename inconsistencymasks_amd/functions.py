@@ -1205,32 +1205,60 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
     return round(tot_im / tot_n, 0) if tot_n else 0.0
 
 
+_HELA_GT_COUNTS = {}      # id(position-mask tensor of a cached decoded set) -> (weak reference to it, [(alive, dead)] ground-truth cell counts)
+
+
+def _hela_gt_cell_counts(pool, gp_dev, gp, ga, gd):
+    """get_cell_count(get_pos_contours(gt position), gt alive, gt dead) of every image of a benchmark directory: a property of
+    the files, computed once per decoded set (the candidates of a generation score against the same three directories)"""
+    import weakref
+    with _CACHE_LOCK:
+        for k in [k for k, (ref, _) in _HELA_GT_COUNTS.items() if ref() is None]:
+            del _HELA_GT_COUNTS[k]
+        hit = _HELA_GT_COUNTS.get(id(gp_dev))
+        if hit is None or hit[0]() is not gp_dev:
+            hit = (weakref.ref(gp_dev),
+                   list(pool.map(lambda j: get_cell_count(get_pos_contours(gp[j]), ga[j], gd[j])[:2], range(len(gp)))))
+            _HELA_GT_COUNTS[id(gp_dev)] = hit
+        return hit[1]
+
+
 def benchmark_hela(model, gt_main_dir, pred_dir, h, w, c, threshold=0.5, batch_size=64, save_output=True, benchmark=True,
                    mod_position=True):
-    """functions.py:1155-1260: returns (mIoU, mIoU_ad, mean_cell_count_error)."""
+    """functions.py:1155-1260: returns (mIoU, mIoU_ad, mean_cell_count_error).  Thresholds and the alive / dead pixel counts run
+    in imk_eval_binary (the ratios are formed on the host with the reference's float expression); the position map goes through
+    the host geometry (mod_pos_size, get_pos_contours, get_cell_count: libimk, one image per pool thread)."""
     sub = "mod_position" if mod_position else "position"
     for k in ("alive", "dead", sub):
         os.makedirs(os.path.join(pred_dir, k), exist_ok=True)
     names = _bench_names(os.path.join(gt_main_dir, "brightfield"))
     mious, mious_ad, delta = [], [], 0
-    rd = lambda k, n: read_png(os.path.join(gt_main_dir, k, n), 1)[..., 0]
-    with _pool() as pool:        # per image: PNG decode + native geometry, both outside the interpreter lock
+    iou = lambda cnt: round(float(np.int64(cnt[0]) / (np.int64(cnt[1]) + 1e-7)), 4)      # get_IoU_binary (functions.py:1767-1788)
+    with _pool() as pool:
+        dirs = [("brightfield", c)] + ([("alive", 1), ("dead", 1), ("mod_position", 1)] if benchmark else [])
+        sets = _decoded_set(pool, [(os.path.join(gt_main_dir, k), ch) for k, ch in dirs], names) if names else None
+        if names and benchmark:
+            ga_all, gd_all, gp_all = (t[..., 0].cpu().numpy() for t in sets[1:])
+            gt_counts = _hela_gt_cell_counts(pool, sets[3], gp_all, ga_all, gd_all)
         for i in range(0, len(names), batch_size):
             chunk = names[i:i + batch_size]
-            imgs = list(pool.map(lambda n: read_png(os.path.join(gt_main_dir, "brightfield", n), c), chunk))
-            probs = model.predict_device(torch.from_numpy(np.stack(imgs, 0)).cuda()).cpu().numpy()
+            probs = model.predict_device(sets[0][i:i + batch_size])
+            preds, counts = [], []
+            for k in range(3):
+                gt_k = sets[1 + k][i:i + batch_size, ..., 0] if benchmark else torch.zeros_like(probs[..., k], dtype=torch.uint8)
+                pr, cnt = _ev.eval_binary(probs[..., k].contiguous(), gt_k, threshold, False, want_pred=True)
+                preds.append(pr.cpu().numpy()); counts.append(cnt)
 
             def one(j):
-                n = chunk[j]
-                a_u, d_u, p_u = [((probs[j, ..., k] > threshold) * 255).astype(np.uint8) for k in range(3)]
+                a_u, d_u, p_u = preds[0][j], preds[1][j], preds[2][j]
                 if mod_position:
                     p_u = mod_pos_size(p_u)
                 score = None
                 if benchmark:
-                    ga, gd, gp = rd("alive", n), rd("dead", n), rd("mod_position", n)
-                    ia, idd, ip = (round(float(get_IoU_binary(g, p)), 4) for g, p in ((ga, a_u), (gd, d_u), (gp, p_u)))
+                    ia, idd = iou(counts[0][j]), iou(counts[1][j])
+                    ip = round(float(get_IoU_binary(gp_all[i + j], p_u)), 4) if mod_position else iou(counts[2][j])
                     pa, pd, _ = get_cell_count(get_pos_contours(p_u), a_u, d_u)
-                    qa, qd, _ = get_cell_count(get_pos_contours(gp), ga, gd)
+                    qa, qd = gt_counts[i + j]
                     score = ((ia + idd + ip) / 3, (ia + idd) / 2, abs(pa - qa) + abs(pd - qd))
                 return score, (a_u, d_u, p_u)
             for n, (score, (a_u, d_u, p_u)) in zip(chunk, pool.map(one, range(len(chunk)))):

@@ -1,0 +1,68 @@
+"""GPU: the Cityscapes IM driver (Cityscapes/09_Cityscapes_IM.py) at the dataset's size on synthetic images through the PNG directories: 2 677
+unlabeled + 298 labelled + 250 validation + 250 test images of 208 x 416 x 3, 35 outputs, alpha 1, n = 2, generation 0,
+IM_CANDIDATES x NUM_EPOCHS as given (default 2 x 10: this is a host-side profile, not a training run).  Prints the wall time of every
+stage (IM_TIMING) and the driver's top host functions by cumulative time (cProfile).
+Usage: python tests/gpu_probe/full_driver_run_city.py [workdir]"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/im_full_run_city"
+os.makedirs(work, exist_ok=True)
+cfg = os.path.join(work, "config.ini")
+text = open(os.path.join(ROOT, "config.ini")).read().replace("./data/Cityscapes/", os.path.join(work, "data") + "/")
+text = text.replace("NUM_EPOCHS = 50", "NUM_EPOCHS = " + os.environ.get("EPOCHS", "10"))
+open(cfg, "w").write(text)
+env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1")}
+SETUP = f"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {ROOT!r})
+import torch
+from concurrent.futures import ThreadPoolExecutor
+from inconsistencymasks_amd import functions as F, paths
+from inconsistencymasks_amd.unet import get_unet
+t0 = time.perf_counter()
+yy, xx = np.mgrid[0:208, 0:416].astype(np.float32)
+def sample(n, d_img, d_mask, seed):
+    os.makedirs(d_img, exist_ok=True); os.makedirs(d_mask, exist_ok=True)
+    def one(i):
+        r = np.random.default_rng(seed * 100003 + i)
+        f = sum(np.cos(r.uniform(0.01, 0.05) * xx + r.uniform(0.01, 0.05) * yy + r.uniform(0, 6)) for _ in range(4))
+        cls = (1 + np.clip((f + 4) / 8 * 33, 0, 32)).astype(np.uint8)               # classes 1 .. 33 from the smooth field
+        cy, cx, a, b = r.uniform(60, 150), r.uniform(80, 330), r.uniform(25, 70), r.uniform(25, 70)
+        cls[((yy - cy) / a) ** 2 + ((xx - cx) / b) ** 2 < 1] = 34
+        img = np.stack([20 + 6 * cls, 230 - 6 * cls, 40 + 23 * ((cls * 5) % 9)], -1) + r.uniform(-4, 4, (208, 416, 3))
+        F.write_png(os.path.join(d_img, f"s_{{i:05d}}.png"), img.clip(0, 255).astype(np.uint8))
+        F.write_png(os.path.join(d_mask, f"s_{{i:05d}}.png"), cls)
+    with ThreadPoolExecutor(16) as pool:
+        list(pool.map(one, range(n)))
+sample(298, paths.CITYSCAPES_TRAIN_LABELED_IMAGES_DIR, paths.CITYSCAPES_TRAIN_LABELED_MASKS_DIR, 1)
+sample(2677, paths.CITYSCAPES_TRAIN_UNLABELED_IMAGES_DIR, paths.CITYSCAPES_TRAIN_UNLABELED_MASKS_DIR, 2)
+sample(250, paths.CITYSCAPES_VAL_IMAGES_DIR, paths.CITYSCAPES_VAL_MASKS_DIR, 3)
+sample(250, paths.CITYSCAPES_TEST_IMAGES_DIR, paths.CITYSCAPES_TEST_MASKS_DIR, 4)
+print(f"[timing] synthetic dataset written: {{time.perf_counter() - t0:.2f}} s", flush=True)
+t0 = time.perf_counter()
+os.makedirs(paths.CITYSCAPES_MODEL_DIR, exist_ok=True)
+d = paths.CITYSCAPES_TRAIN_LABELED_IMAGES_DIR
+names = sorted(os.listdir(d))
+x = torch.from_numpy(np.stack([F.read_png(os.path.join(d, n), 3) for n in names])).cuda()
+y = torch.from_numpy(np.stack([F.read_png(os.path.join(paths.CITYSCAPES_TRAIN_LABELED_MASKS_DIR, n), 1)[..., 0] for n in names])).cuda()
+g = torch.Generator(device="cuda").manual_seed(0)
+for j in (1, 2):
+    m = get_unet(208, 416, 3, 35, 1.0, "relu", "softmax", seed=j)
+    for it in range(900):
+        idx = torch.randint(0, len(names), (32,), device="cuda", generator=g)
+        m.train_step(x[idx].contiguous(), y[idx].contiguous(), 1, 3e-3 if it < 500 else 0.0, 1e-4 if it < 500 else 0.0)
+    m.repack()
+    F.save_model(m, os.path.join(paths.CITYSCAPES_MODEL_DIR, f"CITYSCAPES_subset_1_topK_{{j}}.h5"))
+print(f"[timing] generation-0 ensemble (2 models x 900 steps): {{time.perf_counter() - t0:.2f}} s", flush=True)
+"""
+t0 = time.perf_counter()
+subprocess.run([sys.executable, "-c", SETUP], env=env, check=True, cwd=work)
+t1 = time.perf_counter()
+prof = os.path.join(work, "driver.prof")
+subprocess.run([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "Cityscapes", "09_Cityscapes_IM.py")], env=env, check=True, cwd=work)
+t2 = time.perf_counter()
+print(f"[timing] setup {t1 - t0:.1f} s; Cityscapes/09_Cityscapes_IM.py (n = 2, generation 0, candidates {env['IM_CANDIDATES']} x {os.environ.get('EPOCHS', '10')} epochs): {t2 - t1:.1f} s")
+import pstats
+st = pstats.Stats(prof)
+st.sort_stats("cumulative").print_stats(28)
