@@ -80,8 +80,8 @@ def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_p
                     ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
                 for s in range(0, len(idx_all), F.INFER_BATCH):
                     idx = idx_all[s:s + F.INFER_BATCH]
-                    x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
-                    gt = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1), idx)), 0)).cuda()
+                    x = torch.from_numpy(F.read_png_stack(pool, [os.path.join(images_path, names[i]) for i in idx], c)).cuda()
+                    gt = torch.from_numpy(F.read_png_stack(pool, [os.path.join(masks_path, names[i]) for i in idx], 1)).cuda()
                     r = ensembles[subset].run(x.flip(-1).contiguous() if flip else x, F.THRESHOLD, False, False, False)
                     im = _random_morph(r["im"], plan, idx)
                     masks, img = r["masks"], x.clone()
@@ -103,8 +103,9 @@ def create_training_data_evalnet_im_binary(models, h, w, c, images_path, masks_p
                         loop_rows[i] = (out_name, round(float(ious[row]), 4))
                         jobs.append((os.path.join(iout, out_name), img_np[row]))
                         jobs.append((os.path.join(mout, out_name), mk_np[row, :, :, 0]))
-                    list(pool.map(lambda a: F.write_png(*a), jobs))
+                    F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
             rows += [loop_rows[i] for i in range(len(names))]
+    F.flush_writes()
     with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
         wr = csv.writer(f, delimiter=";")
         for row in rows:
@@ -181,7 +182,7 @@ def create_training_data_evalnet_miou_im_multiclass(models, h, w, c, num_classes
                     ensembles[subset] = F.EnsembleIM([models[j] for j in subset])
                 for s in range(0, len(idx_all), F.INFER_BATCH):
                     idx = idx_all[s:s + F.INFER_BATCH]
-                    x = torch.from_numpy(np.stack(list(pool.map(lambda i: F.read_png(os.path.join(images_path, names[i]), c), idx)), 0)).cuda()
+                    x = torch.from_numpy(F.read_png_stack(pool, [os.path.join(images_path, names[i]) for i in idx], c)).cuda()
                     gts = list(pool.map(lambda i: F.read_png(os.path.join(masks_path, names[i]), 1)[..., 0], idx))
                     r = ensembles[subset].run(x.flip(-1).contiguous() if flip else x, F.THRESHOLD, False, False, False)
                     im = _random_morph(r["im"], plan, idx)
@@ -208,8 +209,9 @@ def create_training_data_evalnet_miou_im_multiclass(models, h, w, c, num_classes
                         loop_rows[i] = (out_name, *ious, *det)
                         jobs.append((os.path.join(iout, out_name), img_np[row]))
                         jobs.append((os.path.join(mout, out_name), mk_np[row, :, :, 0]))
-                    list(pool.map(lambda a: F.write_png(*a), jobs))
+                    F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
             rows += [loop_rows[i] for i in range(len(names))]
+    F.flush_writes()
     with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
         wr = csv.writer(f, delimiter=";")
         for row in rows:
@@ -279,8 +281,9 @@ def create_training_data_evalnet_miou_im_hela(models, h, w, c, main_input_path, 
                         jobs.append((os.path.join(dout["brightfield"], out_name), bf_np[row, :, :, 0]))
                         for k, key in enumerate(("alive", "dead", "mod_position")):
                             jobs.append((os.path.join(dout[key], out_name), m_np[row, k]))
-                    list(pool.map(lambda a: F.write_png(*a), jobs))
+                    F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
             rows += [loop_rows[i] for i in range(len(names))]
+    F.flush_writes()
     with open(os.path.join(main_output_path, "labels.csv"), "a", encoding="utf-8", newline="") as f:
         wr = csv.writer(f, delimiter=";")
         for row in rows:
@@ -511,7 +514,7 @@ def create_augment_images_and_masks_with_evalnet_ensemble_hela(evalnets, h, w, c
     with F._pool() as pool:
         for s in range(0, len(mine), F.INFER_BATCH):
             chunk = mine[s:s + F.INFER_BATCH]
-            rd = lambda k: torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(din[k], n), 1), chunk)), 0)).cuda()
+            rd = lambda k: torch.from_numpy(F.read_png_stack(pool, [os.path.join(din[k], n) for n in chunk], 1)).cuda()
             bf = rd("brightfield")
             m255 = torch.cat([rd("alive"), rd("dead"), rd("mod_position")], 3)
             m01 = (m255.float() / 255.0).round().clamp(0, 255).to(torch.uint8)      # what predict() receives: mask / 255
@@ -534,7 +537,8 @@ def create_augment_images_and_masks_with_evalnet_ensemble_hela(evalnets, h, w, c
                     jobs.append((os.path.join(dout["brightfield"], name), o[row, :, :, 0]))
                     for ci, key in enumerate(("alive", "dead", "mod_position")):
                         jobs.append((os.path.join(dout[key], name), om[row, :, :, ci]))
-            list(pool.map(lambda a: F.write_png(*a), jobs))
+            F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
+    F.flush_writes()
     if F._dist():
         F._dist().barrier()
 
@@ -558,8 +562,8 @@ def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w,
     with F._pool() as pool:
         for s in range(0, len(mine), F.INFER_BATCH):
             chunk = mine[s:s + F.INFER_BATCH]
-            x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
-            m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
+            x = torch.from_numpy(F.read_png_stack(pool, [os.path.join(iin, n) for n in chunk], c)).cuda()
+            m = torch.from_numpy(F.read_png_stack(pool, [os.path.join(min_, n) for n in chunk], 1)).cuda()
             xin = x.flip(-1).contiguous() if flip else x
             mean_iou = torch.stack([e.predict_device(xin, m) for e in evalnets], 0).double().mean(0)[:, 0].cpu().numpy()
             n_augs = torch.tensor([num_augs_from_miou(v, min_threshold, max_threshold) for v in mean_iou], device="cuda")
@@ -574,7 +578,8 @@ def create_augment_images_and_masks_with_evalnet_ensemble_binary(evalnets, h, w,
                     name = f"{chunk[i][:-4]}___{j}.png"
                     jobs.append((os.path.join(iout, name), o[row]))
                     jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
-            list(pool.map(lambda a: F.write_png(*a), jobs))
+            F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
+    F.flush_writes()
     if F._dist():
         F._dist().barrier()
 
@@ -597,7 +602,7 @@ def create_augment_images_and_masks_with_gt(main_gt_input_path, min_threshold, m
     with F._pool() as pool:
         for s in range(0, len(mine), F.INFER_BATCH):
             chunk = mine[s:s + F.INFER_BATCH]
-            rd = lambda d, ch: np.stack(list(pool.map(lambda n: F.read_png(os.path.join(d, n), ch), chunk)), 0)
+            rd = lambda d, ch: F.read_png_stack(pool, [os.path.join(d, n) for n in chunk], ch)
             x_np, m_np, im_np, gt_np = rd(iin, 3), rd(min_, 1), rd(imin, 1), rd(main_gt_input_path, 1)
             n_augs = []
             for i in range(len(chunk)):
@@ -617,7 +622,8 @@ def create_augment_images_and_masks_with_gt(main_gt_input_path, min_threshold, m
                     name = f"{chunk[i][:-4]}___{j}.png"
                     jobs.append((os.path.join(iout, name), o[row]))
                     jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
-            list(pool.map(lambda a: F.write_png(*a), jobs))
+            F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
+    F.flush_writes()
     if F._dist():
         F._dist().barrier()
 
@@ -641,8 +647,8 @@ def create_augment_images_and_masks_with_evalnet_ensemble_multiclass(evalnets, h
     with F._pool() as pool:
         for s in range(0, len(mine), F.INFER_BATCH):
             chunk = mine[s:s + F.INFER_BATCH]
-            x = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(iin, n), c), chunk)), 0)).cuda()
-            m = torch.from_numpy(np.stack(list(pool.map(lambda n: F.read_png(os.path.join(min_, n), 1), chunk)), 0)).cuda()
+            x = torch.from_numpy(F.read_png_stack(pool, [os.path.join(iin, n) for n in chunk], c)).cuda()
+            m = torch.from_numpy(F.read_png_stack(pool, [os.path.join(min_, n) for n in chunk], 1)).cuda()
             xin = x.flip(-1).contiguous() if flip else x
             outs = torch.stack([e.predict_device(xin, m) for e in evalnets], 0).double().mean(0).cpu().numpy()
             n_augs = []
@@ -661,6 +667,7 @@ def create_augment_images_and_masks_with_evalnet_ensemble_multiclass(evalnets, h
                     name = f"{chunk[i][:-4]}___{j}.png"
                     jobs.append((os.path.join(iout, name), o[row]))
                     jobs.append((os.path.join(mout, name), om[row, :, :, 0]))
-            list(pool.map(lambda a: F.write_png(*a), jobs))
+            F.write_pngs_async(jobs)      # on the writer pool: the next batch's decode, network pass and augmentation run meanwhile
+    F.flush_writes()
     if F._dist():
         F._dist().barrier()

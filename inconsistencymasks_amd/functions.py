@@ -114,6 +114,29 @@ def read_png(path, channels):
     return _read_png_pillow(path, channels)
 
 
+def _read_png_into(path, channels, row):
+    """decode `path` into `row` (uint8 [H,W,C], C-contiguous): one open, no intermediate array when the native codec takes the file"""
+    if _NATIVE_PNG:
+        import ctypes
+        from ._lib import lib
+        h, w = ctypes.c_int(), ctypes.c_int()
+        if lib.imk_png_read_file(os.fsencode(path), 3 if channels == 3 else 1, row.ctypes.data, row.nbytes, ctypes.byref(h),
+                                 ctypes.byref(w)) == 0 and (h.value, w.value) == row.shape[:2]:
+            return
+    row[...] = read_png(path, channels)      # Pillow's formats; a file of another size raises here
+
+
+def read_png_stack(pool, paths, channels):
+    """uint8 [N,H,W,C] of N same-sized PNG files: every pool thread decodes its files straight into their rows (no per-file array,
+    no np.stack pass over the set)"""
+    paths = list(paths)
+    first = read_png(paths[0], channels)
+    out = np.empty((len(paths),) + first.shape, np.uint8)
+    out[0] = first
+    pool.map(lambda i: _read_png_into(paths[i], channels, out[i]), range(1, len(paths)))
+    return out
+
+
 def write_png(path, arr):
     arr = np.asarray(arr, dtype=np.uint8)
     if arr.ndim == 3 and arr.shape[2] == 1:
@@ -127,8 +150,48 @@ def write_png(path, arr):
     Image.fromarray(arr).save(path, format="PNG", compress_level=1)
 
 
+class _ReaderPool:
+    """The package's ONE pool of reader threads (PNG decode, per-image host geometry: work that runs outside the interpreter lock).
+    `with _pool() as pool:` hands it out and leaving the block leaves it running -- a real generation used to start 850 threads for
+    its ~130 short-lived executors.  map() keeps the order and, for long lists, hands every thread a few contiguous slices instead of
+    one future per item (a 12 000-file training set was 24 000 submits of ~45 us each on the calling thread).  Not for use from
+    inside one of its own tasks (a task waiting for the pool it runs on can starve it)."""
+
+    def __init__(self):
+        self._ex = None
+        self._lock = __import__("threading").Lock()
+
+    def _executor(self):
+        with self._lock:
+            if self._ex is None:
+                self._ex = ThreadPoolExecutor(max_workers=_IO_THREADS, thread_name_prefix="imk-read")
+            return self._ex
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def submit(self, fn, *args, **kw):
+        return self._executor().submit(fn, *args, **kw)
+
+    def map(self, fn, items):
+        items = list(items)
+        ex = self._executor()
+        if len(items) <= 4 * _IO_THREADS:
+            futures = [ex.submit(fn, it) for it in items]
+            return [f.result() for f in futures]
+        step = -(-len(items) // (4 * _IO_THREADS))
+        futures = [ex.submit(lambda lo=lo: [fn(it) for it in items[lo:lo + step]]) for lo in range(0, len(items), step)]
+        return [r for f in futures for r in f.result()]
+
+
+_READER_POOL = _ReaderPool()
+
+
 def _pool():
-    return ThreadPoolExecutor(max_workers=_IO_THREADS)
+    return _READER_POOL
 
 
 # PNG encoding is the slowest part of a real generation (1.6 k images/s against 20 k images/s for the GPU stages), so file
@@ -149,6 +212,14 @@ def _submit_write(job):
 
 def write_png_async(path, arr):
     _submit_write(lambda: write_png(path, arr))
+
+
+def write_pngs_async(jobs, per_task=8):
+    """queue a batch of (path, array) writes, `per_task` files to a task: a writer's batch is ~1 500 files and one submit per file
+    (~35 us on the calling thread) was a tenth of an IM++ generation's host time"""
+    jobs = list(jobs)
+    for lo in range(0, len(jobs), per_task):
+        _submit_write(lambda part=jobs[lo:lo + per_task]: [write_png(*j) for j in part])
 
 
 def _ensure_write_pool():
@@ -396,8 +467,8 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
     with _pool() as pool:
         for i in range(0, len(mine), INFER_BATCH):
             chunk = mine[i:i + INFER_BATCH]
-            imgs = list(pool.map(lambda n: read_png(os.path.join(images_path, n), c), chunk))
-            x = torch.from_numpy(np.stack(imgs, 0)).cuda()
+            imgs = read_png_stack(pool, [os.path.join(images_path, n) for n in chunk], c)
+            x = torch.from_numpy(imgs).cuda()
             if flip_channels:
                 x = x.flip(-1).contiguous()
             r = ens.run(x, THRESHOLD, False, block_input and fused_block, block_output and fused_block,
@@ -425,8 +496,7 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
                     jobs.append((os.path.join(out_dirs["images"], name), img_np[j]))
                     jobs.append((os.path.join(out_dirs["masks"], name), m_np[j, 0]))
                 jobs.append((os.path.join(out_dirs["im"], name), im_np[j]))
-            for job in jobs:
-                write_png_async(*job)      # encoded while the next batch is decoded and run
+            write_pngs_async(jobs)      # encoded while the next batch is decoded and run
     flush_writes()
     tot_im, tot_n = _all_reduce_sum([sum_im, count])
     return round(tot_im / tot_n, 0) if tot_n else 0.0
@@ -628,19 +698,41 @@ class _EpochLoader:
     """list_files(seed).map(parse).batch(B).repeat(): seeded shuffle per pass, one short batch per pass
     (functions.py:207-209), PNG decode on a thread pool, whole set cached on the device after the first pass."""
 
-    def __init__(self, files, parse, batch, seed):
+    def __init__(self, files, parse, batch, seed, parse_key=None):
         self.files = sorted(files)
         self.parse = parse
+        self.parse_key = parse_key      # names what `parse` does to a file: with it the decoded set is shared between loaders
         self.batch = batch
         self.rng = np.random.default_rng(seed)
         self.x = self.y = None
         self._order = []
 
     def _load(self):
-        with _pool() as pool:
-            items = list(pool.map(self.parse, self.files))
-        self.x = torch.from_numpy(np.stack([i[0] for i in items], 0)).cuda()
-        self.y = torch.from_numpy(np.stack([i[1] for i in items], 0)).cuda()
+        """decode the whole set once: every pool thread parses a slice of the files straight into its rows of two host arrays
+        (no per-item list, no np.stack pass).  The candidates of a generation train on the same directory, so the device copy is
+        kept in the decode cache under (parse_key, names, sizes, newest mtime) and the next candidate starts without decoding."""
+        key = None
+        if self.parse_key is not None and self.files:
+            st = [os.stat(f) for f in self.files]
+            key = ("train", self.parse_key, tuple(self.files), sum(x.st_size for x in st), max(x.st_mtime_ns for x in st))
+        with _CACHE_LOCK:
+            hit = _DECODE_CACHE.get(key) if key is not None else None
+            if hit is not None:
+                self.x, self.y = _used_here(hit)
+                return
+            x0, y0 = self.parse(self.files[0])
+            n = len(self.files)
+            xs, ys = np.empty((n,) + x0.shape, x0.dtype), np.empty((n,) + y0.shape, y0.dtype)
+            xs[0], ys[0] = x0, y0
+
+            def fill(i):
+                xs[i], ys[i] = self.parse(self.files[i])
+            with _pool() as pool:
+                pool.map(fill, range(1, n))
+            self.x, self.y = torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()
+            if key is not None:
+                _uploaded()
+                _decode_cache_put(key, [self.x, self.y])
 
     def next_batch(self):
         if self.x is None:
@@ -820,6 +912,16 @@ _DECODE_CACHE = {}
 _DECODE_CACHE_BYTES = int(float(os.environ.get("IMK_DECODE_CACHE_GB", 16)) * 2 ** 30)
 
 
+def _decode_cache_put(key, tensors):
+    """keep `tensors` under `key` if they fit the cache's budget, dropping the oldest entries to make room (callers hold _CACHE_LOCK)"""
+    nbytes = sum(t.numel() * t.element_size() for t in tensors)
+    if 0 < nbytes <= _DECODE_CACHE_BYTES:
+        held = lambda: sum(sum(t.numel() * t.element_size() for t in v) for v in _DECODE_CACHE.values())
+        while _DECODE_CACHE and held() + nbytes > _DECODE_CACHE_BYTES:
+            _DECODE_CACHE.pop(next(iter(_DECODE_CACHE)))
+        _DECODE_CACHE[key] = tensors
+
+
 def _decoded_set(pool, dirs_and_channels, names):
     """[(directory, channels)] x names -> list of uint8 device tensors [N,H,W,C] (one per directory), cached"""
     def sig(d):
@@ -832,14 +934,9 @@ def _decoded_set(pool, dirs_and_channels, names):
             return _used_here(hit)
         out = []
         for d, c in dirs_and_channels:
-            arrs = list(pool.map(lambda n: read_png(os.path.join(d, n), c), names))
-            out.append(torch.from_numpy(np.stack(arrs, 0)).cuda())
+            out.append(torch.from_numpy(read_png_stack(pool, [os.path.join(d, n) for n in names], c)).cuda())
         _uploaded()
-        nbytes = sum(t.numel() for t in out)
-        if 0 < nbytes <= _DECODE_CACHE_BYTES:
-            while _DECODE_CACHE and sum(sum(t.numel() for t in v) for v in _DECODE_CACHE.values()) + nbytes > _DECODE_CACHE_BYTES:
-                _DECODE_CACHE.pop(next(iter(_DECODE_CACHE)))
-            _DECODE_CACHE[key] = out
+        _decode_cache_put(key, out)
         return out
 
 
@@ -903,7 +1000,7 @@ def train_ISIC_2018(train_images_dir, val_images_dir, val_masks_dir, test_images
     if loss_func != "mse":
         raise NotImplementedError("the ISIC scripts train with 'mse'")
     files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
-    loader = _EpochLoader(files, lambda p: parse_image_ISIC_2018(p, c), BATCH_SIZE, SEED)
+    loader = _EpochLoader(files, lambda p: parse_image_ISIC_2018(p, c), BATCH_SIZE, SEED, ("isic", c))
     best = {"iou": -1.0}
 
     def on_epoch_end(ep, loss):      # ModelCheckpoint(save_best_only, monitor='val_binary_io_u', mode='max')
@@ -1031,7 +1128,7 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
     """functions.py:275-316.  loss_func: anything (the SUIM / Cityscapes scripts pass CategoricalCrossentropy());
     the fused loss kernel implements exactly that loss on class-id masks."""
     files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
-    loader = _EpochLoader(files, lambda p: parse_image_multiclass(p, n_classes, c), BATCH_SIZE, SEED)
+    loader = _EpochLoader(files, lambda p: parse_image_multiclass(p, n_classes, c), BATCH_SIZE, SEED, ("multi", n_classes, c))
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
     best = {"miou": -1.0}
 
@@ -1170,8 +1267,8 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
     with _pool() as pool:
         for i in range(0, len(mine), INFER_BATCH):
             chunk = mine[i:i + INFER_BATCH]
-            imgs = list(pool.map(lambda n: read_png(os.path.join(images_path, n), c), chunk))
-            x = torch.from_numpy(np.stack(imgs, 0)).cuda()
+            imgs = read_png_stack(pool, [os.path.join(images_path, n) for n in chunk], c)
+            x = torch.from_numpy(imgs).cuda()
             r = ens.run(x, 0.5, True, False, False)          # blocking happens after the host-side position step
             im, masks = r["im"], r["masks"]
             if erode_kernel > 0:       # functions.py:2940-2946: erode the combined IM, dilate_mask on alive and dead
@@ -1198,8 +1295,7 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
                         (os.path.join(out["dead"], name), dead), (os.path.join(out["mod_position"], name), pos),
                         (os.path.join(out["im"], name), im_np[j])]
             jobs = [job for per_image in pool.map(one, range(len(chunk))) for job in per_image]
-            for job in jobs:
-                write_png_async(*job)
+            write_pngs_async(jobs)      # encoded while the next batch is decoded and run
     flush_writes()
     tot_im, tot_n = _all_reduce_sum([sum_im, count])
     return round(tot_im / tot_n, 0) if tot_n else 0.0
@@ -1280,7 +1376,7 @@ def train_hela(train_images_dir, val_images_dir, val_gt_dir, test_gt_dir, unlabe
     if loss_func != "mse":
         raise NotImplementedError("the HeLa scripts train with 'mse'")
     files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
-    loader = _EpochLoader(files, lambda p: parse_image_hela(p, c), BATCH_SIZE, SEED)
+    loader = _EpochLoader(files, lambda p: parse_image_hela(p, c), BATCH_SIZE, SEED, ("hela", c))
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
     best = {"loss": float("inf")}
 

@@ -10,8 +10,11 @@ os.makedirs(work, exist_ok=True)
 cfg = os.path.join(work, "config.ini")
 text = open(os.path.join(ROOT, "config.ini")).read().replace("./data/Cityscapes/", os.path.join(work, "data") + "/")
 text = text.replace("NUM_EPOCHS = 50", "NUM_EPOCHS = " + os.environ.get("EPOCHS", "10"))
+text = text.replace("NUM_EPOCHS_EVALNET = 50", "NUM_EPOCHS_EVALNET = " + os.environ.get("EPOCHS_EVALNET", "10"))
 open(cfg, "w").write(text)
-env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1")}
+DRIVER = os.environ.get("DRIVER", "09_Cityscapes_IM.py")      # e.g. DRIVER=12_HeLa_IM++.py / 13_SUIM_IM++.py: the IM++ driver on the same data
+env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1"),
+       "IM_EVALNET_CANDIDATES": os.environ.get("IM_EVALNET_CANDIDATES", "0,1")}
 SETUP = f"""
 import os, sys, time
 import numpy as np
@@ -60,9 +63,9 @@ t0 = time.perf_counter()
 subprocess.run([sys.executable, "-c", SETUP], env=env, check=True, cwd=work)
 t1 = time.perf_counter()
 prof = os.path.join(work, "driver.prof")
-subprocess.run([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "Cityscapes", "09_Cityscapes_IM.py")], env=env, check=True, cwd=work)
+subprocess.run([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "Cityscapes", DRIVER)], env=env, check=True, cwd=work)
 t2 = time.perf_counter()
-print(f"[timing] setup {t1 - t0:.1f} s; Cityscapes/09_Cityscapes_IM.py (n = 2, generation 0, candidates {env['IM_CANDIDATES']} x {os.environ.get('EPOCHS', '10')} epochs): {t2 - t1:.1f} s")
+print(f"[timing] setup {t1 - t0:.1f} s; Cityscapes/{DRIVER} (n = 2, generation 0, candidates {env['IM_CANDIDATES']} x {os.environ.get('EPOCHS', '10')} epochs): {t2 - t1:.1f} s")
 import pstats
 st = pstats.Stats(prof)
 st.sort_stats("cumulative").print_stats(28)

@@ -154,3 +154,34 @@ def test_pillow_can_be_forced(tmp_path, monkeypatch):
     p = str(tmp_path / "p.png")
     F.write_png(p, a)
     assert np.array_equal(F.read_png(p, 3), a)
+
+
+def test_stack_reader_equals_file_by_file_reads(tmp_path):
+    """read_png_stack (every pool thread decodes straight into its rows of one array) against read_png per file: more files than the
+    pool's one-future-per-item limit (so the sliced path runs), a 16-bit file among them (Pillow's route into the row), RGB and grey,
+    and a file of another size is an error, not a silently reshaped row"""
+    rng = np.random.default_rng(12)
+    n = 4 * F._IO_THREADS + 37
+    paths = []
+    for i in range(n):
+        p = str(tmp_path / f"{i:04d}.png")
+        if i == 5:
+            Image.fromarray(rng.integers(0, 65536, (24, 40)).astype(np.uint16)).save(p)      # 16-bit greyscale: declined by libimk
+        else:
+            F.write_png(p, rng.integers(0, 256, (24, 40, 3)).astype(np.uint8))
+        paths.append(p)
+    with F._pool() as pool:
+        for c in (3, 1):
+            got = F.read_png_stack(pool, paths, c)
+            assert got.shape == (n, 24, 40, c) and got.dtype == np.uint8 and got.flags["C_CONTIGUOUS"]
+            for i in (0, 1, 5, 6, n // 2, n - 1):
+                assert np.array_equal(got[i], F.read_png(paths[i], c)), (c, i)
+        assert np.array_equal(F.read_png_stack(pool, paths[:1], 3)[0], F.read_png(paths[0], 3))
+        odd = str(tmp_path / "odd.png")
+        F.write_png(odd, np.zeros((24, 41, 3), np.uint8))
+        with pytest.raises(Exception):
+            F.read_png_stack(pool, paths[:3] + [odd], 3)
+        # the pool keeps the order of a long list and passes a task's exception on
+        assert pool.map(lambda v: v * v, range(1000)) == [v * v for v in range(1000)]
+        with pytest.raises(ZeroDivisionError):
+            pool.map(lambda v: 1 // (v - 700), range(1000))
