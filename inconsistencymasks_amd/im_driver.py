@@ -121,6 +121,55 @@ def _candidate_streams(n):
     return pool[:n]
 
 
+PARALLEL_CANDIDATES_DEFAULT = 3
+
+
+def train_candidates(cands, train_candidate, world, tick=None, parallel=None):
+    """rows of `train_candidate(i, side_by_side)` for i in cands, in that order.
+
+    The reference trains a generation's candidates one after the other (ISIC_2018/09_ISIC_2018_IM.py:90).  They are independent
+    (own seed, own files), and one model's training step leaves most of the chip idle in its deep levels, so on ONE rank k of
+    them train side by side -- one host thread and one stream each, without side streams of their own; 3 interleaved candidates
+    reach 1.58x the model-steps per second of one (tests/gpu_probe/concurrent_candidates.py) and a real ISIC generation of 5
+    candidates x 50 epochs takes 17.9 s instead of 27.5 s (profiles/r05_notes.md).  Every candidate computes exactly what it computes
+    alone: CSVs, checkpoints and prediction files equal the sequential run's byte for byte (tests/test_gpu_driver.py).
+    k = `parallel`, else IM_PARALLEL_CANDIDATES, else 3; 1 is the reference's order.  Several ranks: always 1 (collectives issued
+    from several threads would not line up across ranks)."""
+    tick = tick or (lambda what: None)
+    par = parallel if parallel is not None else int(os.environ.get("IM_PARALLEL_CANDIDATES", PARALLEL_CANDIDATES_DEFAULT))
+    if world > 1 or len(cands) < 2:
+        par = 1
+    par = min(par, len(cands))
+    if par <= 1:
+        rows = []
+        for i in cands:
+            rows.append(train_candidate(i, False))
+            tick(f"candidate {i}: training + 3 benchmarks")
+        return rows
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    dev_index = torch.cuda.current_device()
+    free = queue.SimpleQueue()                    # a fixed set of streams, reused over candidates and generations;
+    for st in _candidate_streams(par):            # a worker holds one for the whole candidate
+        free.put(st)
+
+    def worker(i):
+        torch.cuda.set_device(dev_index)          # the current device is per thread
+        st = free.get()
+        try:
+            with torch.cuda.stream(st):
+                row = train_candidate(i, True)
+                st.synchronize()
+        finally:
+            free.put(st)
+        return row
+    with ThreadPoolExecutor(max_workers=par) as pool:
+        rows = list(pool.map(worker, cands))
+    F.flush_writes(all_threads=True)              # every candidate's prediction PNGs are on disk
+    tick(f"{len(cands)} candidates, {par} side by side: training + 3 benchmarks each")
+    return rows
+
+
 def run(dataset, approach="IM", parallel_candidates=None):
     ds = DATASETS[dataset]
     S = F.config[ds["section"]]
@@ -225,44 +274,7 @@ def run(dataset, approach="IM", parallel_candidates=None):
                     del model
                     return (name_i,) + tuple(res)
 
-                # The reference trains the generation's candidates one after the other (ISIC_2018/09_ISIC_2018_IM.py:90).  They are
-                # independent (own seed, own files), and one model's training step leaves most of the chip idle in its deep levels:
-                # IM_PARALLEL_CANDIDATES=k (or parallel_candidates=k) trains k of them side by side, one host thread and one stream
-                # each, without their own side streams -- 3 candidates interleaved reach 1.58x the model-steps per second of one
-                # (tests/gpu_probe/concurrent_candidates.py).  Every candidate computes exactly what it computes alone: the CSVs and
-                # checkpoints equal the sequential run's.  One rank only (collectives from several threads would not line up).
-                cands = _ints("IM_CANDIDATES", [0, 1, 2, 3, 4])
-                par = parallel_candidates if parallel_candidates is not None else int(os.environ.get("IM_PARALLEL_CANDIDATES", "1"))
-                if world > 1 or len(cands) < 2:
-                    par = 1
-                if par > 1:
-                    from concurrent.futures import ThreadPoolExecutor
-                    dev_index = torch.cuda.current_device()
-
-                    import queue
-                    free = queue.SimpleQueue()                    # a fixed set of streams, reused over candidates and generations;
-                    for st in _candidate_streams(par):            # a worker holds one for the whole candidate
-                        free.put(st)
-
-                    def worker(i):
-                        torch.cuda.set_device(dev_index)          # the current device is per thread
-                        st = free.get()
-                        try:
-                            with torch.cuda.stream(st):
-                                row = train_candidate(i, True)
-                                st.synchronize()
-                        finally:
-                            free.put(st)
-                        return row
-                    with ThreadPoolExecutor(max_workers=par) as pool:
-                        rows = list(pool.map(worker, cands))
-                    F.flush_writes(all_threads=True)              # every candidate's prediction PNGs are on disk
-                    tick(f"{len(cands)} candidates, {par} side by side: training + 3 benchmarks each")
-                else:
-                    rows = []
-                    for i in cands:
-                        rows.append(train_candidate(i))
-                        tick(f"candidate {i}: training + 3 benchmarks")
+                rows = train_candidates(_ints("IM_CANDIDATES", [0, 1, 2, 3, 4]), train_candidate, world, tick, parallel_candidates)
 
                 if rank == 0:
                     top = sorted(rows, key=lambda r: r[ds["rank"]], reverse=True)[:top_k]

@@ -18,7 +18,7 @@ import torch
 from . import functions as F
 from . import paths
 from .evalnet import get_evalnet, get_evalnet_miou
-from .im_driver import DATASETS, _ints, color_mapping
+from .im_driver import DATASETS, _ints, color_mapping, train_candidates
 from .unet import get_unet
 
 _HELA = dict(   # HeLa/14_HeLa_aug_IM++.py:53-57 (identical in 12_HeLa_IM++.py)
@@ -161,12 +161,13 @@ def run(dataset, aug=False, train_new_evalnet=True, gt=False):
                 steps = max(len(os.listdir(train_dir)) // batch // world, 1)
                 if gt:      # :126-132: never fewer steps than an epoch over the full training set
                     steps = max(steps, len(os.listdir(P("TRAIN_FULL_IMAGES_DIR"))) // batch // world)
-                rows = []
-                for i in _ints("IM_CANDIDATES", [0, 1, 2, 3, 4]):
+                def train_candidate(i, side_by_side=False):
                     name_i = f"{modelname}_{i}"
                     h5 = os.path.join(model_dir, name_i + ".h5")
                     preds = [os.path.join(base, f"{k}_predictions", approach, name_i) for k in ("val", "test", "train_unlabeled")]
                     model = get_unet(H, W, C, K, sch["alphas"][gen], actifu, actifu_out, seed=1000 * runid + 100 * gen + i)
+                    if side_by_side:      # the other candidates' streams fill this one's gaps: no side stream of its own (results identical)
+                        model.debug(single_stream=True)
                     if hela:
                         res = F.train_hela(train_dir, os.path.join(P("VAL_DIR"), "brightfield"), P("VAL_DIR"), P("TEST_DIR"),
                                            P("TRAIN_UNLABELED_DIR"), name_i, h5, model, "mse", steps, H, W, C, *preds)
@@ -179,8 +180,10 @@ def run(dataset, aug=False, train_new_evalnet=True, gt=False):
                         res = F.train_ISIC_2018(train_dir, P("VAL_IMAGES_DIR"), P("VAL_MASKS_DIR"), P("TEST_IMAGES_DIR"),
                                                 P("TEST_MASKS_DIR"), P("TRAIN_UNLABELED_IMAGES_DIR"), P("TRAIN_UNLABELED_MASKS_DIR"),
                                                 name_i, h5, model, "mse", steps, H, W, C, *preds)
-                    rows.append((name_i,) + tuple(res))
                     del model
+                    return (name_i,) + tuple(res)
+                # one rank: IM_PARALLEL_CANDIDATES (default 3) of them side by side, results identical (im_driver.train_candidates)
+                rows = train_candidates(_ints("IM_CANDIDATES", [0, 1, 2, 3, 4]), train_candidate, world)
                 if rank == 0:
                     rank_col = DATASETS[dataset]["rank"]
                     top = sorted(rows, key=lambda r: r[rank_col], reverse=True)[:top_k]

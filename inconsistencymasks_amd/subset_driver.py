@@ -16,7 +16,7 @@ import torch
 
 from . import functions as F
 from . import paths
-from .im_driver import DATASETS, _ints, color_mapping
+from .im_driver import DATASETS, _ints, color_mapping, train_candidates
 from .unet import get_unet
 
 # (index of the ranking value in the row, descending?) -- ISIC_2018/03_ISIC_2018_subset.py:82, SUIM/04_SUIM_subset.py:84,
@@ -68,14 +68,18 @@ def run(dataset, aug=False):
     idx, desc = _RANK[ds["kind"]]
     for runid in _ints("IM_RUNIDS", [1, 2, 3]):
         modelname = f"{tag}_{approach}_{runid}"
-        rows = []
-        for i in _ints("IM_CANDIDATES", list(range(10))):
+        def one(i, side_by_side=False):
             name_i = f"{modelname}_{i}"
             h5 = os.path.join(model_dir, name_i + ".h5")
             preds = [os.path.join(base, f"{k}_predictions", approach, name_i) for k in ("val", "test", "train_unlabeled")]
             model = get_unet(H, W, C, K, alpha, S["ACTIFU"], S["ACTIFU_OUTPUT"], seed=7000 * runid + i)
-            rows.append((name_i,) + tuple(train_candidate(ds, dataset, train_dir, name_i, h5, model, steps, H, W, C, K, preds)))
+            if side_by_side:
+                model.debug(single_stream=True)
+            row = (name_i,) + tuple(train_candidate(ds, dataset, train_dir, name_i, h5, model, steps, H, W, C, K, preds))
             del model
+            return row
+        # one rank: IM_PARALLEL_CANDIDATES (default 3) of the ten side by side, results identical (im_driver.train_candidates)
+        rows = train_candidates(_ints("IM_CANDIDATES", list(range(10))), one, world)
         if rank == 0:
             top = sorted(rows, key=lambda r: r[idx], reverse=desc)[:top_k]
             print(top)

@@ -894,8 +894,7 @@ def test_isic_driver_candidates_side_by_side(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "09_ISIC_2018_IM.py")], env=env, cwd=work,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        if par > 1:
-            assert "3 side by side" in r.stdout
+        assert ("3 side by side" in r.stdout) == (par > 1)      # IM_PARALLEL_CANDIDATES=1 is the reference's order
         outs[par] = base
     stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
     for name in (f"results_{stem}.csv", f"mean_im_size_{stem}.csv"):
@@ -912,3 +911,47 @@ def test_isic_driver_candidates_side_by_side(tmp_path):
         assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) == 8
         for n in os.listdir(a):
             assert (a / n).read_bytes() == (b / n).read_bytes(), (i, n)
+
+
+@pytest.mark.parametrize("which", ["hela_im", "suim_im", "isic_subset"])
+def test_other_drivers_candidates_side_by_side(tmp_path, which):
+    """the default on one rank (three candidates side by side: im_driver.train_candidates) against IM_PARALLEL_CANDIDATES=1 (the
+    reference's order) for the drivers whose runs are seeded end to end: HeLa/09_HeLa_IM.py (host geometry + benchmark_hela on the
+    candidates' threads), SUIM/10_SUIM_IM.py (colour masks on the writer pool) and ISIC_2018/03_ISIC_2018_subset.py (ten
+    candidates): every CSV and every surviving checkpoint equal"""
+    config, setup, script, cands = {
+        "hela_im": (HELA_CONFIG, HELA_SETUP, os.path.join("HeLa", "09_HeLa_IM.py"), "0,1,2"),
+        "suim_im": (MULTI_CONFIG, MULTI_SETUP, os.path.join("SUIM", "10_SUIM_IM.py"), "0,1,2"),
+        "isic_subset": (CONFIG, SETUP, os.path.join("ISIC_2018", "03_ISIC_2018_subset.py"), "0,1,2,3"),
+    }[which]
+    outs = {}
+    for par in ("1", None):
+        work = tmp_path / f"p{par}"
+        base = work / "data"
+        work.mkdir()
+        cfg = work / "config.ini"
+        cfg.write_text(config.format(base=base))
+        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": cands}
+        env.pop("IM_PARALLEL_CANDIDATES", None)
+        if par:
+            env["IM_PARALLEL_CANDIDATES"] = par
+        subprocess.run([sys.executable, "-c", setup.format(root=ROOT)], env=env, check=True, cwd=work)
+        if which == "isic_subset":      # the set-up script's stand-in ensemble would collide with the subset driver's own names
+            for f in os.listdir(base / "models"):
+                os.remove(base / "models" / f)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script)], env=env, cwd=work, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[par] = base
+    csvs = sorted(os.listdir(outs["1"] / "csv"))
+    assert csvs and csvs == sorted(os.listdir(outs[None] / "csv"))
+    for name in csvs:
+        assert (outs["1"] / "csv" / name).read_text() == (outs[None] / "csv" / name).read_text(), name
+    from safetensors import safe_open
+    tops = sorted(n for n in os.listdir(outs["1"] / "models") if "_topK_" in n and (which == "isic_subset" or "_IM_" in n))
+    assert tops and all((outs[None] / "models" / n).exists() for n in tops)
+    for n in tops:
+        sd = []
+        for p in ("1", None):
+            with safe_open(str(outs[p] / "models" / n), framework="np") as f:
+                sd.append({k: f.get_tensor(k) for k in f.keys()})
+        assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), n
