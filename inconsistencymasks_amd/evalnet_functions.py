@@ -302,6 +302,22 @@ def _read_labels(main_path, num_classes=3):
     return rows
 
 
+def _cached_evalnet_set(kind, main_path, load):
+    """the EvalNet candidates of a run train on the same two directories: decode them once (device decode cache, keyed by the
+    directory, its labels.csv and what `kind` of set it is read as)"""
+    F = _F()
+    st = os.stat(os.path.join(main_path, "labels.csv"))
+    key = ("evalnet", kind, os.path.abspath(main_path), st.st_size, st.st_mtime_ns)
+    with F._CACHE_LOCK:
+        hit = F._DECODE_CACHE.get(key)
+        if hit is not None:
+            return tuple(F._used_here(hit))
+        out = list(load())
+        F._uploaded()
+        F._decode_cache_put(key, out)
+        return tuple(out)
+
+
 def _load_evalnet_set(main_path, rows, pool):
     """brightfield (grey) [N,H,W,1], masks alive|dead|mod_position [N,H,W,3] (raw uint8 values), labels [N,6] on the device"""
     F = _F()
@@ -322,15 +338,18 @@ def _load_evalnet_set(main_path, rows, pool):
 
 def _evaluate_evalnet(model, xa, xb, y, batch_size, steps, k):
     """model.evaluate(generator, steps): inference-mode forward over `steps` batches -> (total, mse, bce, mae, acc)"""
-    tot = np.zeros(4)
+    rows = []
     for s in range(steps):
         sl = slice(s * batch_size, (s + 1) * batch_size)
         out = model.predict_device(xa[sl].contiguous(), xb[sl].contiguous()).double()
         t = y[sl].double()
         p_iou, p_det, t_iou, t_det = out[:, :k], out[:, k:], t[:, :k], t[:, k:]
         pc = p_det.clamp(1e-7, 1 - 1e-7)
-        tot += np.array([float(((p_iou - t_iou) ** 2).mean()), float(-(t_det * pc.log() + (1 - t_det) * (1 - pc).log()).mean()),
-                         float((p_iou - t_iou).abs().mean()), float(((p_det > 0.5).double() == t_det).double().mean())])
+        rows.append(torch.stack([((p_iou - t_iou) ** 2).mean(), -(t_det * pc.log() + (1 - t_det) * (1 - pc).log()).mean(),
+                                 (p_iou - t_iou).abs().mean(), ((p_det > 0.5).double() == t_det).double().mean()]))
+    tot = np.zeros(4)
+    for r in (torch.stack(rows).cpu().numpy() if rows else []):      # one transfer; the batches' float64 values summed in order
+        tot += r
     mse, bce, mae, acc = tot / max(steps, 1)
     return mse + bce, mse, bce, mae, acc
 
@@ -407,8 +426,8 @@ def train_evalnet_miou_model_hela(model, train_main_path, val_main_path, filepat
     F = _F()
     k = model.plan.n_out
     with F._pool() as pool:
-        tr = _load_evalnet_set(train_main_path, _read_labels(train_main_path, k), pool)
-        va = _load_evalnet_set(val_main_path, _read_labels(val_main_path, k), pool)
+        tr = _cached_evalnet_set(("hela", k), train_main_path, lambda: _load_evalnet_set(train_main_path, _read_labels(train_main_path, k), pool))
+        va = _cached_evalnet_set(("hela", k), val_main_path, lambda: _load_evalnet_set(val_main_path, _read_labels(val_main_path, k), pool))
     ev = lambda m, st, steps: _evaluate_evalnet(m, st[0], st[1], st[2], batch_size, steps, k)
     return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 0, seed)
 
@@ -437,14 +456,18 @@ def train_evalnet_ISIC_2018(model, train_main_path, val_main_path, filepath_h5, 
     val_mean_absolute_error (min).  Returns (mse, mae) of the best model on the validation generator."""
     F = _F()
     with F._pool() as pool:
-        tr, va = _load_binary_evalnet_set(train_main_path, pool), _load_binary_evalnet_set(val_main_path, pool)
+        tr = _cached_evalnet_set("binary", train_main_path, lambda: _load_binary_evalnet_set(train_main_path, pool))
+        va = _cached_evalnet_set("binary", val_main_path, lambda: _load_binary_evalnet_set(val_main_path, pool))
 
     def ev(m, st, steps):
-        tot = np.zeros(2)
+        rows = []
         for s in range(steps):
             sl = slice(s * batch_size, (s + 1) * batch_size)
             d = m.predict_device(st[0][sl].contiguous(), st[1][sl].contiguous()).double() - st[2][sl].double()
-            tot += np.array([float((d ** 2).mean()), float(d.abs().mean())])
+            rows.append(torch.stack([(d ** 2).mean(), d.abs().mean()]))
+        tot = np.zeros(2)
+        for r in (torch.stack(rows).cpu().numpy() if rows else []):      # one transfer; summed on the host in batch order
+            tot += r
         return tuple(tot / max(steps, 1))
 
     return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 1, seed)
@@ -473,8 +496,8 @@ def train_evalnet_miou_model_multiclass(model, h, w, train_main_path, val_main_p
     if not model.plan.b_onehot or model.plan.n_out != num_classes:
         raise ValueError("needs a get_evalnet_miou(..., inputB_channels=num_classes) model with a one-hot input B")
     with F._pool() as pool:
-        tr = _load_multiclass_evalnet_set(train_main_path, num_classes, pool)
-        va = _load_multiclass_evalnet_set(val_main_path, num_classes, pool)
+        tr = _cached_evalnet_set(("multi", num_classes), train_main_path, lambda: _load_multiclass_evalnet_set(train_main_path, num_classes, pool))
+        va = _cached_evalnet_set(("multi", num_classes), val_main_path, lambda: _load_multiclass_evalnet_set(val_main_path, num_classes, pool))
     ev = lambda m, st, steps: _evaluate_evalnet(m, st[0], st[1], st[2], batch_size, steps, num_classes)
     return _fit_evalnet(model, tr, va, filepath_h5, batch_size, epochs, ev, 0, seed)
 

@@ -82,24 +82,29 @@ def run(dataset, aug=False, train_new_evalnet=True, gt=False):
                                                                  P(f"{split}_MASKS_DIR"), os.path.join(ev_dir, sub), loops)
             barrier()
             del subset_models
-            rows = []
-            for i in _ints("IM_EVALNET_CANDIDATES", [0, 1, 2, 3, 4]):
+            def train_evalnet_candidate(i, side_by_side=False):
                 name = f"{evalnet_tag}_{runid}_{i}"
                 h5 = os.path.join(model_dir, name + ".h5")
                 if hela:
                     evalnet = get_evalnet_miou(H, W, C, K, alpha_evalnet, seed=7000 * runid + i)
+                elif multi:
+                    evalnet = get_evalnet_miou(H, W, C, K, alpha_evalnet, seed=7000 * runid + i, onehot_B=True)
+                else:
+                    evalnet = get_evalnet(H, W, C, K, alpha_evalnet, normalize_B=True, seed=7000 * runid + i)
+                if side_by_side:      # no side stream of its own: the other candidates fill the gaps (results identical)
+                    evalnet.debug(single_stream=True)
+                if hela:
                     res = F.train_evalnet_miou_model_hela(evalnet, os.path.join(ev_dir, "train"), os.path.join(ev_dir, "val"), h5,
                                                           bs_evalnet, ep_evalnet)
                 elif multi:
-                    evalnet = get_evalnet_miou(H, W, C, K, alpha_evalnet, seed=7000 * runid + i, onehot_B=True)
                     res = F.train_evalnet_miou_model_multiclass(evalnet, H, W, os.path.join(ev_dir, "train"),
                                                                 os.path.join(ev_dir, "val"), h5, bs_evalnet, K, ep_evalnet)
                 else:
-                    evalnet = get_evalnet(H, W, C, K, alpha_evalnet, normalize_B=True, seed=7000 * runid + i)
                     res = F.train_evalnet_ISIC_2018(evalnet, os.path.join(ev_dir, "train"), os.path.join(ev_dir, "val"), h5,
                                                     bs_evalnet, ep_evalnet)
-                rows.append((name,) + tuple(res))
                 del evalnet
+                return (name,) + tuple(res)
+            rows = train_candidates(_ints("IM_EVALNET_CANDIDATES", [0, 1, 2, 3, 4]), train_evalnet_candidate, world)
             if rank == 0:
                 # ascending: HeLa by iou_mae (14_HeLa...:131), SUIM by total_loss (13_SUIM...:129), ISIC by mae (12_ISIC...:124)
                 top = sorted(rows, key=lambda r: r[4 if hela else (1 if multi else 2)])[:top_k]

@@ -913,7 +913,7 @@ def test_isic_driver_candidates_side_by_side(tmp_path):
             assert (a / n).read_bytes() == (b / n).read_bytes(), (i, n)
 
 
-@pytest.mark.parametrize("which", ["hela_im", "suim_im", "isic_subset"])
+@pytest.mark.parametrize("which", ["hela_im", "suim_im", "isic_subset", "isic_impp_evalnets"])
 def test_other_drivers_candidates_side_by_side(tmp_path, which):
     """the default on one rank (three candidates side by side: im_driver.train_candidates) against IM_PARALLEL_CANDIDATES=1 (the
     reference's order) for the drivers whose runs are seeded end to end: HeLa/09_HeLa_IM.py (host geometry + benchmark_hela on the
@@ -923,7 +923,14 @@ def test_other_drivers_candidates_side_by_side(tmp_path, which):
         "hela_im": (HELA_CONFIG, HELA_SETUP, os.path.join("HeLa", "09_HeLa_IM.py"), "0,1,2"),
         "suim_im": (MULTI_CONFIG, MULTI_SETUP, os.path.join("SUIM", "10_SUIM_IM.py"), "0,1,2"),
         "isic_subset": (CONFIG, SETUP, os.path.join("ISIC_2018", "03_ISIC_2018_subset.py"), "0,1,2,3"),
+        # IM++: the EvalNet stage is seeded end to end (training data, 3 EvalNet candidates); the U-Net stage behind it draws its
+        # augmentations unseeded, so only the EvalNet CSV and checkpoints are compared
+        "isic_impp_evalnets": (CONFIG.replace("TOP_Ks = 2\n", "TOP_Ks = 2\nNUM_EPOCHS_EVALNET = 2\nBATCH_SIZE_EVALNET = 8\nNUM_LOOPS_TRAIN = 2\n"
+                                                                 "NUM_LOOPS_VAL = 1\n")
+                               + "FREE_ROTATION = True\nALPHA_EVALNET = 0.5\nMIN_THRESHOLD = 0.3\nMAX_THRESHOLD = 0.8\n",
+                               SETUP, os.path.join("ISIC_2018", "12_ISIC_2018_IM++.py"), "0,1"),
     }[which]
+    only = (lambda n: "evalnet" in n) if which == "isic_impp_evalnets" else (lambda n: True)
     outs = {}
     for par in ("1", None):
         work = tmp_path / f"p{par}"
@@ -931,7 +938,8 @@ def test_other_drivers_candidates_side_by_side(tmp_path, which):
         work.mkdir()
         cfg = work / "config.ini"
         cfg.write_text(config.format(base=base))
-        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": cands}
+        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": cands,
+               "IM_EVALNET_CANDIDATES": "0,1,2"}
         env.pop("IM_PARALLEL_CANDIDATES", None)
         if par:
             env["IM_PARALLEL_CANDIDATES"] = par
@@ -942,12 +950,13 @@ def test_other_drivers_candidates_side_by_side(tmp_path, which):
         r = subprocess.run([sys.executable, os.path.join(ROOT, script)], env=env, cwd=work, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[par] = base
-    csvs = sorted(os.listdir(outs["1"] / "csv"))
-    assert csvs and csvs == sorted(os.listdir(outs[None] / "csv"))
+    csvs = sorted(n for n in os.listdir(outs["1"] / "csv") if only(n))
+    assert csvs and csvs == sorted(n for n in os.listdir(outs[None] / "csv") if only(n))
     for name in csvs:
         assert (outs["1"] / "csv" / name).read_text() == (outs[None] / "csv" / name).read_text(), name
     from safetensors import safe_open
-    tops = sorted(n for n in os.listdir(outs["1"] / "models") if "_topK_" in n and (which == "isic_subset" or "_IM_" in n))
+    tops = sorted(n for n in os.listdir(outs["1"] / "models")
+                  if "_topK_" in n and {"isic_subset": True, "isic_impp_evalnets": "evalnet" in n}.get(which, "_IM_" in n))
     assert tops and all((outs[None] / "models" / n).exists() for n in tops)
     for n in tops:
         sd = []
