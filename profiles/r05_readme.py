@@ -73,6 +73,7 @@ def main():
 | `r05_ab1.txt` ... `r05_ab6.txt`, `r05_infer_batch.txt` | raw output of the round's one-box A/B runs (`tests/gpu_probe/ab_r05.sh` in its successive forms; what each compared: notes, section 2) |
 | `r05_full_driver_run.txt` | `ISIC_2018/09_ISIC_2018_IM.py` through PNG directories at the dataset's real size, sequential candidates, native PNG codec + the reader pool / decoded-set cache: 23.8 s per generation (round 4: 35.3 s; with the codec alone: 25.5 s) |
 | `r05_full_driver_run_sequential.txt`, `r05_full_driver_run_parallel3.txt` | the same driver on one (slower) box, sequential against the new one-rank default of three candidates side by side: 27.5 -> 17.9 s, identical results CSV |
+| `r05_full_driver_run_five_generations.txt` | the same driver over generations 0-4 (25 candidates x 50 epochs, three side by side): 79.7 s |
 | `r05_full_driver_run_hela.txt` | `HeLa/09_HeLa_IM.py` at real size (2 candidates x 10 epochs) with cProfile: 11.0 s (31.7 s with the numpy / scipy position geometry; `csrc/imk_geom.cpp`) |
 | `r05_full_driver_run_impp.txt` | `ISIC_2018/12_ISIC_2018_IM++.py` at real size (2 EvalNets + 2 candidates x 10 epochs) with cProfile: 21.4 s (26.0 s before the shared reader pool, `read_png_stack` and the decoded training set kept across candidates) |
 | `r05_trajectory_diag_suim.txt` | `tests/gpu_probe/trajectory_diag.py`: per tensor, how far a GPU training run and the oracle's are apart after 1 ... 30 steps |

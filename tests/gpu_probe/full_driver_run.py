@@ -9,7 +9,7 @@ os.makedirs(work, exist_ok=True)
 cfg = os.path.join(work, "config.ini")
 text = open(os.path.join(ROOT, "config.ini")).read().replace("./data/ISIC_2018/", os.path.join(work, "data") + "/")
 open(cfg, "w").write(text)
-env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1"}
+env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": os.environ.get("IM_GENS", "0"), "IM_TIMING": "1"}
 SETUP = f"""
 import os, sys, time
 import numpy as np
@@ -60,6 +60,6 @@ t1 = time.perf_counter()
 subprocess.run([sys.executable, os.path.join(ROOT, "ISIC_2018", "09_ISIC_2018_IM.py")], env=env, check=True, cwd=work)
 t2 = time.perf_counter()
 print(f"[timing] setup {t1 - t0:.1f} s; ISIC_2018/09_ISIC_2018_IM.py (1 run id, n = 2, generation 0, 5 candidates x 50 epochs): {t2 - t1:.1f} s")
-stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+stem = "ISIC_2018_IM_1_n2_gen%s_e0_d0_bi_True_bo_True" % env["IM_GENS"].split(",")[-1]
 print(open(os.path.join(work, "data", "csv", f"results_{stem}.csv")).read())
 print(open(os.path.join(work, "data", "csv", f"mean_im_size_{stem}.csv")).read())
