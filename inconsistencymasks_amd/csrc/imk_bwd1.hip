@@ -42,17 +42,23 @@ struct Bwd1Args {
 // SMALL: at most 32 channels on both sides (2 x 2 tiles, one k-step) -- the full-resolution layers, where the kernel's time
 // is: 4 instead of 2 weight-gradient partial sums per input-channel tile (every wave works: wave = (tile, half of the
 // tile's 4 k-steps), combined in a fixed order at the end), a quarter of the fragment / accumulator registers.
+#ifndef BWD1_SMALL_WGS
+#define BWD1_SMALL_WGS 3
+#endif
 template <int LM, bool SMALL>
-__global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) {
+__global__ __launch_bounds__(256, SMALL ? BWD1_SMALL_WGS : 2) void bwd1x1_kernel(Bwd1Args a) {
     IMK_STAMP_BEGIN(bwd1, 70000 + LM * 10 + (SMALL ? 1 : 0));
     constexpr int NPX = 128, H16 = WG_STRIDE_H;
     constexpr int NF = SMALL ? 2 : 4, NSK = SMALL ? 1 : 2;   // input-channel tiles (= output tiles) and dgrad k-steps at most
     constexpr bool MASK = LM == LM_RAW;
-    constexpr int NS = 4;                                   // staging slots per thread and tensor: 128 pixels x 8 chunks / 256
+    // staging slots per thread and tensor: 128 pixels x CH 8-channel chunks / 256 threads.  SMALL rows have at most 4 chunks: a slot
+    // per chunk that exists (the 8-chunk map left half of the threads loading a clamped duplicate and storing zeros to unused slices)
+    constexpr int CH = SMALL ? 4 : 8, CSH = SMALL ? 2 : 3, NS = NPX * CH / 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    f16 *s_d = reinterpret_cast<f16 *>(smem);               // [4][128][16]  dA slices
-    f16 *s_x = s_d + 4 * NPX * H16;                         // [4][128][16]  x slices
-    f16 *s_o = s_x + 4 * NPX * H16;                         // [128][72]     dX tile for the coalesced copy-out
+    constexpr int NSL = SMALL ? 2 : 4;                      // 16-channel slices per tensor
+    f16 *s_d = reinterpret_cast<f16 *>(smem);               // [NSL][128][16]  dA slices
+    f16 *s_x = s_d + NSL * NPX * H16;                       // [NSL][128][16]  x slices
+    f16 *s_o = s_x + NSL * NPX * H16;                       // [128][72]       dX tile for the coalesced copy-out
     float *s_coef = reinterpret_cast<float *>(s_o + NPX * 72);   // [3][cs_o]
     float *s_aff = s_coef + 3 * a.cs_o;                     // LM_UPADD: [sc | sh | sc2 | sh2][cs_i]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = lane & 15, g = lane >> 4, qq = n >> 2, pp = n & 3;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) 
     const int wci = SMALL ? (wave & 1) : wave, kk0 = SMALL ? 2 * (wave >> 1) : 0;
     constexpr int NKK = SMALL ? 2 : 4;
 
-    // staging: item i = t + 256 k <-> (pixel i >> 3, chunk i & 7) of the tile, the same for dy / z (chunks of cs_o) and x (of cs_i)
+    // staging: item i = t + 256 k <-> (pixel i / CH, chunk i % CH) of the tile, the same for dy / z (chunks of cs_o) and x (of cs_i)
     f16x8 r_dy[NS], r_z[NS];
     RawChunk<LM> r_x[NS];
     unsigned ok_px = 0;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) 
         ok_px = 0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int i = t + 256 * k, pl = i >> 3, c8 = i & 7;
+            const int i = t + 256 * k, pl = i >> CSH, c8 = i & (CH - 1);
             const long long px = p0 + pl;
             const bool in = px < a.n_pix;
             const long long pc = in ? px : a.n_pix - 1;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) 
         // ---- registers -> LDS slices: dA = (A dy + B z + C)[z > 0], x ---------------------------------------------------
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int i = t + 256 * k, pl = i >> 3, c8 = i & 7;
+            const int i = t + 256 * k, pl = i >> CSH, c8 = i & (CH - 1);
             const bool in = (ok_px >> k) & 1u;
             f16x8 d = {0, 0, 0, 0, 0, 0, 0, 0}, xv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (in && c8 < nco8) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 2) void bwd1x1_kernel(Bwd1Args a) 
             const long long p0 = tile * NPX;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const int i = t + 256 * k, pl = i >> 3, c8 = i & 7;
+                const int i = t + 256 * k, pl = i >> CSH, c8 = i & (CH - 1);
                 if (c8 < nci8 && p0 + pl < a.n_pix)
                     *reinterpret_cast<f16x8 *>(a.dx + (p0 + pl) * cs_i + c8 * 8) = *reinterpret_cast<const f16x8 *>(s_o + pl * 72 + c8 * 8);
             }
@@ -255,8 +261,8 @@ bool bwd1_env_on() {
 
 int imk_bwd1x1_rows(long long n_pix, int cs_in, int cs_out) {
     const long long n_tiles = (n_pix + 127) / 128;
-    static const int cap_small = []() { const char *e = getenv("IMK_BWD1X1_ROWS"); return e ? atoi(e) : 768; }();
-    const int cap = (cs_in <= 32 && cs_out <= 32) ? cap_small : 512;   // 3 workgroups per compute unit in the <= 32-channel form, 2 above
+    static const int cap_small = []() { const char *e = getenv("IMK_BWD1X1_ROWS"); return e ? atoi(e) : 256 * BWD1_SMALL_WGS; }();
+    const int cap = (cs_in <= 32 && cs_out <= 32) ? cap_small : 512;   // 3 workgroups per compute unit in the <= 32-channel form (4 fit and measured slower: more partial rows), 2 above
     return (int)(n_tiles < cap ? n_tiles : cap);
 }
 
@@ -278,11 +284,11 @@ int imk_launch_bwd1x1(const ImkInput &x, const f16 *dy, const f16 *z, const floa
     a.n_pix = (long long)B * H * W;
     if (a.n_pass > 2 || a.cit_n > 4 || a.cot_n > 4) return IMK_EUNSUPPORTED;
     const int grid = imk_bwd1x1_rows(a.n_pix, a.cs_i, a.cs_o);
-    const size_t lds = (size_t)(8 * 128 * WG_STRIDE_H + 128 * 72) * sizeof(f16) + (3 * (size_t)a.cs_o + 4 * (size_t)a.cs_i) * sizeof(float);
+    const bool small = a.cit_n <= 2 && a.cot_n <= 2 && a.n_pass == 1;
+    const size_t lds = (size_t)((small ? 4 : 8) * 128 * WG_STRIDE_H + 128 * 72) * sizeof(f16) + (3 * (size_t)a.cs_o + 4 * (size_t)a.cs_i) * sizeof(float);
     const double px = (double)a.n_pix;
     const double bytes = px * a.cs_o * 4 + px * a.cs_i * 2 * (x.lmode == LM_UPADD ? 1.25 : 1.0) + px * a.cs_i * 2;
     ImkProfScope prof(PF_WGRAD_GEMM, bytes, stream, 4.0 * px * x.cin * cout);
-    const bool small = a.cit_n <= 2 && a.cot_n <= 2 && a.n_pass == 1;
     if (x.lmode == LM_RAW) { if (small) bwd1x1_kernel<LM_RAW, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_RAW, false><<<grid, 256, lds, stream>>>(a); }
     else if (x.lmode == LM_UPADD) { if (small) bwd1x1_kernel<LM_UPADD, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_UPADD, false><<<grid, 256, lds, stream>>>(a); }
     else return IMK_EUNSUPPORTED;

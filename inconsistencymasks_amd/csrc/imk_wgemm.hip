@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, NFO == 2 ? 3 : 2) void wgrad_gemm_kernel(ImkWg
     constexpr int halo = KS3 ? 1 : 0, T = KS3 ? 9 : 1;
     constexpr int HT = TR + 2 * halo, WT = TW + 2 * halo;
     constexpr int NPX = HT * WT, NPD = TR * 16;      // pixels of an x slice / a dA slice
-    constexpr int NX = (NPX * 2 * NFI + 255) / 256, ND = (NPD * 8 + 255) / 256;
+    constexpr int DCH = NFO == 2 ? 4 : 8, DSH = NFO == 2 ? 2 : 3;   // dA chunks per pixel: the two-output-tile form has at most 4
+    constexpr int NX = (NPX * 2 * NFI + 255) / 256, ND = (NPD * DCH + 255) / 256;
     constexpr int H16 = WG_STRIDE_H;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16 *s_x = reinterpret_cast<f16 *>(smem);                       // [NFI][NPX][16]
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(256, NFO == 2 ? 3 : 2) void wgrad_gemm_kernel(ImkWg
         return it;
     };
     auto d_item = [&](int k) {
-        const int i = t + 256 * k;                   // NPD * 8 is a multiple of 256: no idle slots
-        const int pix = i >> 3, j = i & 7;
+        const int i = t + 256 * k;                   // NPD * DCH is a multiple of 256: no idle slots
+        const int pix = i >> DSH, j = i & (DCH - 1);
         const int c8 = 2 * cot0 + j;
         Item it;
         it.py = pix >> 4; it.px = pix & 15;
