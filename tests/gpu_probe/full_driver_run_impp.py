@@ -10,6 +10,7 @@ cfg = os.path.join(work, "config.ini")
 text = open(os.path.join(ROOT, "config.ini")).read().replace("./data/ISIC_2018/", os.path.join(work, "data") + "/")
 text = text.replace("NUM_EPOCHS = 50", "NUM_EPOCHS = " + os.environ.get("EPOCHS", "10")).replace("NUM_EPOCHS_EVALNET = 50", "NUM_EPOCHS_EVALNET = " + os.environ.get("EPOCHS_EVALNET", "10"))
 open(cfg, "w").write(text)
+DRIVER = os.environ.get("DRIVER", "12_ISIC_2018_IM++.py")      # DRIVER=11_ISIC_2018_IM+.py / 13_ISIC_2018_aug_IM+.py / 14_ISIC_2018_aug_IM++.py
 env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1"),
        "IM_EVALNET_CANDIDATES": os.environ.get("IM_EVALNET_CANDIDATES", "0,1")}
 SETUP = f"""
@@ -60,8 +61,8 @@ t0 = time.perf_counter()
 subprocess.run([sys.executable, "-c", SETUP], env=env, check=True, cwd=work)
 t1 = time.perf_counter()
 prof = os.path.join(work, "driver.prof")
-subprocess.run([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "ISIC_2018", "12_ISIC_2018_IM++.py")], env=env, check=True, cwd=work)
+subprocess.run([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "ISIC_2018", DRIVER)], env=env, check=True, cwd=work)
 t2 = time.perf_counter()
-print(f"[timing] setup {t1 - t0:.1f} s; ISIC_2018/12_ISIC_2018_IM++.py (n = 2, generation 0, EvalNets {env['IM_EVALNET_CANDIDATES']}, candidates {env['IM_CANDIDATES']}): {t2 - t1:.1f} s")
+print(f"[timing] setup {t1 - t0:.1f} s; ISIC_2018/{DRIVER} (n = 2, generation 0, EvalNets {env['IM_EVALNET_CANDIDATES']}, candidates {env['IM_CANDIDATES']}): {t2 - t1:.1f} s")
 import pstats
 pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
