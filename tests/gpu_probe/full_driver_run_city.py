@@ -13,7 +13,7 @@ text = text.replace("NUM_EPOCHS = 50", "NUM_EPOCHS = " + os.environ.get("EPOCHS"
 text = text.replace("NUM_EPOCHS_EVALNET = 50", "NUM_EPOCHS_EVALNET = " + os.environ.get("EPOCHS_EVALNET", "10"))
 open(cfg, "w").write(text)
 DRIVER = os.environ.get("DRIVER", "09_Cityscapes_IM.py")      # e.g. DRIVER=12_HeLa_IM++.py / 13_SUIM_IM++.py: the IM++ driver on the same data
-env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1"),
+env = {**os.environ, "IM_CONFIG": cfg, "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": os.environ.get("IM_GENS", "0"), "IM_TIMING": "1", "IM_CANDIDATES": os.environ.get("IM_CANDIDATES", "0,1"),
        "IM_EVALNET_CANDIDATES": os.environ.get("IM_EVALNET_CANDIDATES", "0,1")}
 SETUP = f"""
 import os, sys, time
