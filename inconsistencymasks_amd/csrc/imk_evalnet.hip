@@ -253,6 +253,12 @@ extern "C" int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, voi
     const int csF = imk_pad8(e.ch[0]);
     for (int s = 1; s >= 0; --s) {
         const f16 *dcat = reinterpret_cast<const f16 *>(c.base + c.ws.dcat) + s * csF;
+        {   // IMK_EVALNET_TAIL: 0 = round 4's order; 1 = the last tower's weight gradients released with their dgrads and their split
+            // reductions left to the end of the step (Bwd::tail_early, Bwd::defer_finalize); 2 (default) = both towers released early
+            static const int tail = []() { const char *e = getenv("IMK_EVALNET_TAIL"); return e ? atoi(e) : 2; }();
+            if (tail >= 2 || (tail == 1 && s == 0)) b.tail_early = true;
+            if (tail >= 1 && s == 0) b.defer_finalize = true;
+        }
         OK(b.bn_bwd(t.t_bn[s], 1, nullptr, dcat, 2 * csF));
         OK(b.wgrad_dgrad(t.t_c1[s], c.dA(t.t_c3[s]), c.act(t.t_c3[s])));
         OK(b.wgrad_dgrad(t.t_c3[s], c.dy(t.in_bn[s]), nullptr, t.in_bn[s]));

@@ -417,6 +417,10 @@ struct Bwd {
     int hold_conv = -1;
     Pending held{};
     bool has_held = false;
+    // The final block of a backward pass whose last full-resolution 3x3 weight gradient is NOT held back (EvalNet's second tower): released
+    // late it starts when the main chain has nothing left but the input block and is what the step then waits for (141 us alone at the
+    // end of an EvalNet step); released with its dgrad it is done when the chain is (EvalNet step 2.116 -> 2.07 ms).
+    bool tail_early = false;
     int launch_wgrad(int conv, const f16 *dA_override, hipStream_t ws) {
         ImkWgradArgs a{};
         wgrad_args(conv, dA_override, a);
@@ -522,8 +526,14 @@ struct Bwd {
         // Full resolution: the weight gradient is released when the dgrad beside it has FINISHED, not when it starts -- both
         // are bandwidth-bound there, and the dgrad is the one the chain waits for (step -0.9 %, SUIM -1.4 %, HeLa -1.2 %; the
         // same at the lower levels changes nothing).  IMK_FORK_LATE = highest level released late (-1: none).
+        // Round 5, after the input block's streaming weight gradient and the narrower staging maps: at <= 16 channels the early release
+        // wins again (ISIC 0.984 -> 0.967 ms, SUIM 1.664 -> 1.647, HeLa -0.5 %, Cityscapes alpha 1 -0.9 %), from 24 channels up the late
+        // one still does (Cityscapes alpha 1.5 / 2, ISIC alpha 1.5: +0.7-1 % released early) -- the rule follows the layer's width
+        // unless IMK_FORK_LATE is set.
+        static const bool late_set = getenv("IMK_FORK_LATE") != nullptr;
         static const int late_res = []() { const char *e = getenv("IMK_FORK_LATE"); return e ? atoi(e) : 0; }();
-        if (l.res <= late_res) {
+        const bool wide = imk_pad8(l.cin) >= 24 || imk_pad8(l.cout) >= 24;
+        if (l.res <= late_res && !tail_early && (wide || late_set)) {
             int rc = dgrad(conv, dst, mask, stat_bn, s2_bn);
             if (rc) return rc;
             return wgrad(conv);
