@@ -1828,7 +1828,20 @@ int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
     ImkProfScope prof(PF_STEP_TAIL, pk_bytes, stream);
     // blocks per job: the widest layer (147 k fragment slots at alpha = 0.5, 590 k at alpha = 1) then has 2-9 slots per thread --
     // the kernel sits at the very end of the step's dependent chain, and a slot is a chain of index divisions and one load
-    static const int bpj = []() { const char *e = getenv("IMK_PACK_BLOCKS"); return e ? atoi(e) : 64; }();
+    // Round 5: wider nets get more blocks (EvalNet alpha 2 / Cityscapes alpha 2: 2.4 M slots in the widest layer = 144 per thread on
+    // 64 blocks, 44 us per launch): about 8 slots per thread of the widest job, 64 ... 1024 blocks per job (a block whose job has
+    // fewer slots leaves at once).  IMK_PACK_BLOCKS fixes the count.
+    static const int bpj_env = []() { const char *e = getenv("IMK_PACK_BLOCKS"); return e ? atoi(e) : 0; }();
+    int bpj = bpj_env;
+    if (bpj <= 0) {
+        long long widest = 0;
+        for (int i = 0; i < jobs.n; ++i) {
+            const long long slots = (long long)jobs.j[i].ksize * jobs.j[i].ksize * ((jobs.j[i].cin + 15) & ~15) * ((jobs.j[i].cout + 15) & ~15);
+            widest = slots > widest ? slots : widest;
+        }
+        bpj = (int)((widest + 2047) / 2048);
+        bpj = bpj < 64 ? 64 : (bpj > 1024 ? 1024 : bpj);
+    }
     pack_conv_batched_kernel<<<dim3(bpj, jobs.n), 256, 0, stream>>>(jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;

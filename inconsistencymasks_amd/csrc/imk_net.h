@@ -444,6 +444,14 @@ struct Bwd {
         }
         return launch_wgrad(conv, dA_override, c.stream);
     }
+    // End of a resolution block below full resolution: its weight gradients go to the side stream -- every block (IMK_FORK_EVERY=1,
+    // the default) or every k-th one (each fork is an event record on the main stream: ~6 us before the chain's next kernel starts).
+    int n_block_flush = 0;
+    int flush_block() {
+        static const int every = []() { const char *e = getenv("IMK_FORK_EVERY"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+        if (++n_block_flush % every != 0 && n_pending <= 4) return IMK_OK;
+        return flush_wgrads();
+    }
     int flush_wgrads() {
         if (n_pending == 0) return IMK_OK;
         const int si = n_fork % n_side;

@@ -510,14 +510,14 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.bn_bwd(t.d_bna[j], 0, nullptr, nullptr));
         b.sum2_bn = j > 0 ? t.d_bnb[j - 1] : t.b_bn;     // dU's 2x2 sums = dy of the block below: assembled by this dgrad where it can
         OK(b.wgrad_dgrad(t.d_ca[j], dU, nullptr));
-        OK(b.flush_wgrads());   // the block's weight gradients (and the head's, for the first block) -> side stream
+        OK(b.flush_block());    // the block's weight gradients (and the head's, for the first block) -> side stream
         OK(loss_on_side());
     }
     // bottleneck: dy = 2x2 sum of dU[decoder 6]
     OK(b.bn_bwd(t.b_bn, 2, nullptr, reinterpret_cast<f16 *>(c.base + c.ws.dU[0])));
     OK(b.wgrad_dgrad(t.b_c1, c.dA(t.b_c3), c.act(t.b_c3)));
     OK(b.wgrad_dgrad(t.b_c3, reinterpret_cast<f16 *>(c.base + c.ws.dP[3]), nullptr));
-    OK(b.flush_wgrads());
+    OK(b.flush_block());
     // encoders 4..1: dy = skip gradient (dU of decoder 6+(3-i)) + max-pool scatter of dP[i]
     for (int i = 3; i >= 0; --i) {
         if (i == 0) {
@@ -530,7 +530,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
         OK(b.wgrad_dgrad(t.e_c1[i], c.dA(t.e_c3[i]), c.act(t.e_c3[i])));
         f16 *dst = i > 0 ? reinterpret_cast<f16 *>(c.base + c.ws.dP[i - 1]) : c.dy(t.in_bn);
         OK(b.wgrad_dgrad(t.e_c3[i], dst, nullptr, i > 0 ? -1 : t.in_bn));
-        OK(b.flush_wgrads());
+        OK(i > 0 ? b.flush_block() : b.flush_wgrads());
     }
     OK(b.bn_bwd(t.in_bn, 0, nullptr, nullptr));
     if (b.has_held) {
