@@ -144,7 +144,7 @@ extern "C" int imk_gather_pairs(const uint8_t *img, int64_t row_img, const uint8
         const int vec = row_img % 16 == 0 && a16(img) && a16(img_out);
         const int64_t work = vec ? row_img / 16 : row_img;
         const int bx = (int)(work / 256 < 1 ? 1 : (work / 256 > 64 ? 64 : work / 256));
-        gather_rows_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(img, idx, img_out, row_img, vec);
+        imk_klaunch(gather_rows_kernel, dim3(dim3(bx, (unsigned)n)), dim3(256), 0, stream, img, idx, img_out, row_img, vec);
         IMK_LAUNCH_CHECK();
     }
     if (mask) {
@@ -153,10 +153,10 @@ extern "C" int imk_gather_pairs(const uint8_t *img, int64_t row_img, const uint8
             const int vec = row % 16 == 0 && a16(mask) && a16(mask_out);
             const int64_t work = vec ? row / 16 : row;
             const int bx = (int)(work / 256 < 1 ? 1 : (work / 256 > 64 ? 64 : work / 256));
-            gather_rows_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(mask, idx, mask_out, row, vec);
+            imk_klaunch(gather_rows_kernel, dim3(dim3(bx, (unsigned)n)), dim3(256), 0, stream, mask, idx, mask_out, row, vec);
         } else {
             const int bx = (int)(hw / 256 < 1 ? 1 : (hw / 256 > 64 ? 64 : hw / 256));
-            gather_planes_kernel<<<dim3(bx, (unsigned)n), 256, 0, stream>>>(mask, idx, mask_out, planes, hw, div255, mul);
+            imk_klaunch(gather_planes_kernel, dim3(dim3(bx, (unsigned)n)), dim3(256), 0, stream, mask, idx, mask_out, planes, hw, div255, mul);
         }
         IMK_LAUNCH_CHECK();
     }
@@ -171,7 +171,7 @@ extern "C" int imk_augment(const uint8_t *img, const uint8_t *mask, int batch, i
     IMK_CHECK_ARG(img != img_out && (!mask || mask != mask_out));
     if (any_quarter_turn && h != w) return IMK_EUNSUPPORTED;   // the output would change shape
     dim3 grid(imk_cdiv((int64_t)h * w, 256), batch);
-    augment_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(img, mask, h, w, c, cm, params, img_out, mask_out);
+    imk_klaunch(augment_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, img, mask, h, w, c, cm, params, img_out, mask_out);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

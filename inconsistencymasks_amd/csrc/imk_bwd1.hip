@@ -289,8 +289,8 @@ int imk_launch_bwd1x1(const ImkInput &x, const f16 *dy, const f16 *z, const floa
     const double px = (double)a.n_pix;
     const double bytes = px * a.cs_o * 4 + px * a.cs_i * 2 * (x.lmode == LM_UPADD ? 1.25 : 1.0) + px * a.cs_i * 2;
     ImkProfScope prof(PF_WGRAD_GEMM, bytes, stream, 4.0 * px * x.cin * cout);
-    if (x.lmode == LM_RAW) { if (small) bwd1x1_kernel<LM_RAW, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_RAW, false><<<grid, 256, lds, stream>>>(a); }
-    else if (x.lmode == LM_UPADD) { if (small) bwd1x1_kernel<LM_UPADD, true><<<grid, 256, lds, stream>>>(a); else bwd1x1_kernel<LM_UPADD, false><<<grid, 256, lds, stream>>>(a); }
+    if (x.lmode == LM_RAW) { if (small) imk_klaunch(bwd1x1_kernel<LM_RAW, true>, dim3(grid), dim3(256), lds, stream, a); else imk_klaunch(bwd1x1_kernel<LM_RAW, false>, dim3(grid), dim3(256), lds, stream, a); }
+    else if (x.lmode == LM_UPADD) { if (small) imk_klaunch(bwd1x1_kernel<LM_UPADD, true>, dim3(grid), dim3(256), lds, stream, a); else imk_klaunch(bwd1x1_kernel<LM_UPADD, false>, dim3(grid), dim3(256), lds, stream, a); }
     else return IMK_EUNSUPPORTED;
     IMK_LAUNCH_CHECK();
     return IMK_OK;

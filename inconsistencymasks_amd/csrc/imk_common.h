@@ -5,6 +5,50 @@
 #include <stdint.h>
 #include "../../include/imk.h"
 
+#include <hip/hip_ext.h>
+#include <tuple>
+#include <utility>
+
+// ---- kernel launches that can carry a completion event ---------------------------------------------------------------------------
+// Every kernel of the library is launched through imk_klaunch.  While a thread has a stop-event ring installed for a stream (the
+// training step's backward pass: ImkStopRingScope in imk_net.h), a launch on THAT stream binds the ring's next event to the kernel
+// itself (hipExtLaunchKernel's stopEvent: the event completes with the kernel's own completion signal) and remembers it as `last`.
+// A fork to the side stream then waits for `last` instead of recording an event of its own -- a recorded event is a marker packet
+// on the main stream, and the chain's next kernel started 3.6 us later behind it (0.9 us with the kernel-bound event:
+// tests/gpu_probe/fork_probe.hip; ~10 forks per training step).  `last` is only meaningful because EVERY launch goes through here.
+struct ImkStopRing {
+    hipEvent_t *ev;
+    int n, cur;
+    hipStream_t stream;          // the main stream of the pass
+    hipEvent_t last;             // event bound to its most recent kernel
+    hipStream_t side = nullptr;  // (optional) the pass's one side stream: its last kernel's event serves the join at the end
+    hipEvent_t side_last = nullptr;
+};
+inline thread_local ImkStopRing *imk_tls_stop_ring = nullptr;
+
+template <typename... KA, typename... A, size_t... I>
+inline hipError_t imk_klaunch_ext(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t stop,
+                                  std::index_sequence<I...>, A &&...args) {
+    std::tuple<KA...> held{static_cast<KA>(args)...};            // the kernel's own parameter types, as <<<>>> would convert them
+    void *argv[] = {static_cast<void *>(&std::get<I>(held))..., nullptr};
+    return hipExtLaunchKernel(reinterpret_cast<const void *>(kern), grid, block, argv, lds, stream, nullptr, stop, 0);
+}
+
+template <typename... KA, typename... A>
+inline void imk_klaunch(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A &&...args) {
+    static_assert(sizeof...(KA) == sizeof...(A), "kernel argument count");
+    ImkStopRing *r = imk_tls_stop_ring;
+    if (r && (r->stream == stream || (r->side && r->side == stream))) {
+        hipEvent_t e = r->ev[r->cur];
+        r->cur = (r->cur + 1) % r->n;
+        const bool ok = imk_klaunch_ext(kern, grid, block, lds, stream, e, std::index_sequence_for<KA...>{}, std::forward<A>(args)...) == hipSuccess;
+        // (on failure the error stays pending for IMK_LAUNCH_CHECK and forks / joins fall back to recorded events)
+        (r->stream == stream ? r->last : r->side_last) = ok ? e : nullptr;
+        return;
+    }
+    kern<<<grid, block, lds, stream>>>(static_cast<KA>(args)...);
+}
+
 #define IMK_CHECK_ARG(cond) do { if (!(cond)) return IMK_EINVAL; } while (0)
 #define IMK_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 #define IMK_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -1814,9 +1814,9 @@ int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_
     for (int i = 0; i < jobs.n; ++i)   // partials read once, chunk sums written and read once, gradients written
         wgf_bytes += ((double)jobs.j[i].n_split + 2.0 * jobs.j[i].n_chunks + 1.0) * jobs.j[i].n_tiles * 256 * 4;
     ImkProfScope prof(PF_WGF, wgf_bytes, stream);
-    wgf_stage1_kernel<<<jobs.total_work1, 256, 0, stream>>>(jobs);
+    imk_klaunch(wgf_stage1_kernel, dim3(jobs.total_work1), dim3(256), 0, stream, jobs);
     IMK_LAUNCH_CHECK();
-    wgf_stage2_kernel<<<jobs.total_tiles, 1024, 0, stream>>>(jobs, inv_scale_ptr, found_inf);
+    imk_klaunch(wgf_stage2_kernel, dim3(jobs.total_tiles), dim3(1024), 0, stream, jobs, inv_scale_ptr, found_inf);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -1842,7 +1842,7 @@ int imk_launch_pack_jobs(const ImkPackJobs &jobs, hipStream_t stream) {
         bpj = (int)((widest + 2047) / 2048);
         bpj = bpj < 64 ? 64 : (bpj > 1024 ? 1024 : bpj);
     }
-    pack_conv_batched_kernel<<<dim3(bpj, jobs.n), 256, 0, stream>>>(jobs);
+    imk_klaunch(pack_conv_batched_kernel, dim3(dim3(bpj, jobs.n)), dim3(256), 0, stream, jobs);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -1960,7 +1960,7 @@ extern "C" int64_t imk_prof_totals_dump(imk_prof *p, char *buf, int64_t cap) {
 // A marker dispatch on `stream` (kernel imk_mark_kernel, grid size 64 * id): lets a kernel trace be cut at the timed region
 extern "C" int imk_prof_mark(int id, void *stream) {
     IMK_CHECK_ARG(id > 0 && id < 65536);
-    imk_mark_kernel<<<id, 64, 0, (hipStream_t)stream>>>(id);
+    imk_klaunch(imk_mark_kernel, dim3(id), dim3(64), 0, (hipStream_t)stream, id);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -2047,7 +2047,7 @@ static int launch_conv_mfma(const ImkConvArgs &a, hipStream_t stream) {
     auto launch = [&](auto kern) -> int {
         int r = set_lds_limit(kern, L.lds);
         if (r) return r;
-        kern<<<grid, 256, L.lds, stream>>>(a, L.gm);
+        imk_klaunch(kern, dim3(grid), dim3(256), L.lds, stream, a, L.gm);
         return IMK_OK;
     };
     ImkProfScope prof(PF_CONV_MFMA + (L.th == 8 ? 3 : 0) + (L.mt == 4 ? 2 : (L.mt == 2 ? 1 : 0)), imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
@@ -2120,7 +2120,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
         return std::string(b);
     }();
     ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
+    imk_klaunch(kern, dim3(grid), dim3(256), lds, stream, a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -2238,7 +2238,7 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
         return std::string(b);
     }();
     ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
-    kern<<<grid, 256, lds, stream>>>(a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
+    imk_klaunch(kern, dim3(grid), dim3(256), lds, stream, a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
     return IMK_OK;
@@ -2546,7 +2546,7 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     if (!stem_off && a.x.lmode == LM_U8 && a.ksize == 1 && a.dA_z && a.dA_coef && a.cs_out == 8 && a.x.cin <= 4 && a.n_split >= 1) {
         const long long n_pix = (long long)a.B * a.H * a.W;
         ImkProfScope prof(PF_WGRAD, (double)n_pix * (a.x.cin + 32) + (double)a.n_split * 2 * 1024, stream, imk_wgrad_flops(a));
-        stem_wgrad_kernel<<<a.n_split, 256, 0, stream>>>(reinterpret_cast<const uint8_t *>(a.x.in), a.x.cin, a.x.u8_div, a.dA, a.dA_z, a.dA_coef,
+        imk_klaunch(stem_wgrad_kernel, dim3(a.n_split), dim3(256), 0, stream, reinterpret_cast<const uint8_t *>(a.x.in), a.x.cin, a.x.u8_div, a.dA, a.dA_z, a.dA_coef,
                                                         n_pix, a.partial);
         IMK_LAUNCH_CHECK();
         return IMK_OK;
@@ -2558,10 +2558,10 @@ int imk_launch_wgrad(const ImkWgradArgs &a, hipStream_t stream) {
     const dim3 grid(L.gx, L.gy);
     ImkProfScope prof(PF_WGRAD, wgrad_algorithmic_bytes(a, L), stream, imk_wgrad_flops(a));
     switch (a.x.lmode) {
-#define IMK_WG(LM) do { if (a.ksize == 3) { if (a.dA_z) wgrad_mfma_kernel<LM, true, true><<<grid, 256, L.lds, stream>>>(a, L.gm); \
-                                           else wgrad_mfma_kernel<LM, false, true><<<grid, 256, L.lds, stream>>>(a, L.gm); } \
-                        else { if (a.dA_z) wgrad_mfma_kernel<LM, true, false><<<grid, 256, L.lds, stream>>>(a, L.gm); \
-                               else wgrad_mfma_kernel<LM, false, false><<<grid, 256, L.lds, stream>>>(a, L.gm); } } while (0)
+#define IMK_WG(LM) do { if (a.ksize == 3) { if (a.dA_z) imk_klaunch(wgrad_mfma_kernel<LM, true, true>, dim3(grid), dim3(256), L.lds, stream, a, L.gm); \
+                                           else imk_klaunch(wgrad_mfma_kernel<LM, false, true>, dim3(grid), dim3(256), L.lds, stream, a, L.gm); } \
+                        else { if (a.dA_z) imk_klaunch(wgrad_mfma_kernel<LM, true, false>, dim3(grid), dim3(256), L.lds, stream, a, L.gm); \
+                               else imk_klaunch(wgrad_mfma_kernel<LM, false, false>, dim3(grid), dim3(256), L.lds, stream, a, L.gm); } } while (0)
         case LM_RAW: IMK_WG(LM_RAW); break;
         case LM_AFFINE: IMK_WG(LM_AFFINE); break;
         case LM_POOL: IMK_WG(LM_POOL); break;

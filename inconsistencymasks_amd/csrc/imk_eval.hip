@@ -168,9 +168,9 @@ extern "C" int imk_eval_soft_sums(const float *probs, const uint8_t *gt, int64_t
     if (k > 64) return IMK_EUNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     IMK_HIP(hipMemsetAsync(out, 0, (size_t)(SOFT_BLOCKS + 1) * 3 * k * sizeof(double), stream));
-    eval_soft_kernel<<<SOFT_BLOCKS, 256, 0, stream>>>(probs, gt, (long long)n_pix, k, mode, out);
+    imk_klaunch(eval_soft_kernel, dim3(SOFT_BLOCKS), dim3(256), 0, stream, probs, gt, (long long)n_pix, k, mode, out);
     IMK_LAUNCH_CHECK();
-    eval_soft_finalize_kernel<<<imk_cdiv(3 * k, 256), 256, 0, stream>>>(out, 3 * k, SOFT_BLOCKS);
+    imk_klaunch(eval_soft_finalize_kernel, dim3(imk_cdiv(3 * k, 256)), dim3(256), 0, stream, out, 3 * k, SOFT_BLOCKS);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -183,7 +183,7 @@ extern "C" int imk_eval_binary(const float *probs, float thr, int cmp_ge, const 
     const int hw = h * w;
     int bx = (int)imk_cdiv(hw, 1024);
     if (bx > 64) bx = 64;
-    eval_binary_kernel<<<dim3(bx, batch), 256, 0, stream>>>(probs, thr, cmp_ge, gt, hw, pred_out, (unsigned long long *)counts);
+    imk_klaunch(eval_binary_kernel, dim3(dim3(bx, batch)), dim3(256), 0, stream, probs, thr, cmp_ge, gt, hw, pred_out, (unsigned long long *)counts);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -199,7 +199,7 @@ extern "C" int imk_eval_multiclass(const float *probs, const uint8_t *gt, int ba
     const size_t lds = (size_t)256 * (k | 1) * sizeof(float);   // <= 65 KB: one opt-in above the 64 KB default
     if (lds > 64 * 1024)
         IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    eval_multi_kernel<<<dim3(bx, batch), 256, lds, stream>>>(probs, gt, hw, k, pred_out, (unsigned long long *)counts);
+    imk_klaunch(eval_multi_kernel, dim3(dim3(bx, batch)), dim3(256), lds, stream, probs, gt, hw, k, pred_out, (unsigned long long *)counts);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

@@ -233,6 +233,7 @@ extern "C" int imk_evalnet_fwd_bwd(const imk_unet_plan *plan, float *params, voi
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
     const bool side_on = !plan->dbg_single_stream && n_side_env > 0 && ensure_side_streams(plan, n_side_env);
     Bwd b{c, grads, sv.ctl, stats + 1, side_on ? n_side_env : 0, 1LL << 62};
+    ImkStopRingScope stop_ring(plan, stream, b.n_side);      // the backward pass's launches carry their own events (imk_common.h)
     {   // Dense gradients and the loss values: batch reduction of the head kernel's per-sample terms
         const ImkLayer &d0 = plan->layers[t.dense[0]];
         const ImkLayer *d1 = nh > 1 ? &plan->layers[t.dense[1]] : nullptr;

@@ -447,11 +447,11 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
 template <int LM>
 int launch_conv_gemm_chain(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t lds, int grid, hipStream_t stream) {
     if (gm.nc8p == 4) {
-        if (pn == 4) conv_gemm_kernel<LM, true, 4, true, true><<<grid, 256, lds, stream>>>(a, gm);
-        else conv_gemm_kernel<LM, true, 2, true, true><<<grid, 256, lds, stream>>>(a, gm);
+        if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, true, 4, true, true>, dim3(grid), dim3(256), lds, stream, a, gm);
+        else imk_klaunch(conv_gemm_kernel<LM, true, 2, true, true>, dim3(grid), dim3(256), lds, stream, a, gm);
     } else {
-        if (pn == 4) conv_gemm_kernel<LM, true, 4, false, true><<<grid, 256, lds, stream>>>(a, gm);
-        else conv_gemm_kernel<LM, true, 2, false, true><<<grid, 256, lds, stream>>>(a, gm);
+        if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, true, 4, false, true>, dim3(grid), dim3(256), lds, stream, a, gm);
+        else imk_klaunch(conv_gemm_kernel<LM, true, 2, false, true>, dim3(grid), dim3(256), lds, stream, a, gm);
     }
     return IMK_OK;
 }
@@ -459,11 +459,11 @@ int launch_conv_gemm_chain(const ImkConvArgs &a, const GemmGeom &gm, int pn, siz
 template <int LM, bool KS3>
 int launch_conv_gemm_k(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t lds, int grid, hipStream_t stream) {
     if (gm.nc8p == 4) {      // 4 chunks per pass: scalar tile offsets in the k-loop
-        if (pn == 4) conv_gemm_kernel<LM, KS3, 4, true><<<grid, 256, lds, stream>>>(a, gm);
-        else conv_gemm_kernel<LM, KS3, 2, true><<<grid, 256, lds, stream>>>(a, gm);
+        if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, KS3, 4, true>, dim3(grid), dim3(256), lds, stream, a, gm);
+        else imk_klaunch(conv_gemm_kernel<LM, KS3, 2, true>, dim3(grid), dim3(256), lds, stream, a, gm);
     } else {
-        if (pn == 4) conv_gemm_kernel<LM, KS3, 4, false><<<grid, 256, lds, stream>>>(a, gm);
-        else conv_gemm_kernel<LM, KS3, 2, false><<<grid, 256, lds, stream>>>(a, gm);
+        if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, KS3, 4, false>, dim3(grid), dim3(256), lds, stream, a, gm);
+        else imk_klaunch(conv_gemm_kernel<LM, KS3, 2, false>, dim3(grid), dim3(256), lds, stream, a, gm);
     }
     return IMK_OK;
 }

@@ -432,7 +432,7 @@ int imk_launch_head_mse_fused(const f16 *z, const float *sc, const float *sh, co
     HeadCceArgs a{z, sc, sh, w, bias, cin, cs, K, n_pix, y, ctl, stats, dy, loss_partial, dystat_partial, wg_partial, 1};
     const int grid = imk_loss_blocks(n_pix);
     ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + K + cs * 2), stream, 6.0 * n_pix * cin * K);
-    if (cs == 8 && K == 1) head_mse_fused_kernel<8, 1><<<grid, 256, 0, stream>>>(a);
+    if (cs == 8 && K == 1) imk_klaunch(head_mse_fused_kernel<8, 1>, dim3(grid), dim3(256), 0, stream, a);
     else return IMK_EUNSUPPORTED;
     IMK_LAUNCH_CHECK();
     return IMK_OK;
@@ -458,7 +458,7 @@ int imk_launch_head_cce_fused(const f16 *z, const float *sc, const float *sh, co
     const size_t red = ((size_t)4 * (nct * kt + 1) * 256 + 4 * (2 * csv + 1)) * sizeof(float);
     const size_t lds = img > red ? img : red;
     ImkProfScope prof(PF_HEAD_LOSS, (double)n_pix * (cs * 2 + 1 + cs * 2), stream, 6.0 * n_pix * cin * K);
-#define IMK_HF(CSV, KTV) head_cce_fused_kernel<CSV, KTV><<<grid, 256, lds, stream>>>(a)
+#define IMK_HF(CSV, KTV) imk_klaunch(head_cce_fused_kernel<CSV, KTV>, dim3(grid), dim3(256), lds, stream, a)
 #define IMK_HF_KT(CSV) do { if (kt == 1) IMK_HF(CSV, 1); else if (kt == 2) IMK_HF(CSV, 2); else if (kt == 3) IMK_HF(CSV, 3); else IMK_HF(CSV, 4); } while (0)
     if (csv == 16) IMK_HF_KT(16); else IMK_HF_KT(32);
 #undef IMK_HF_KT

@@ -522,7 +522,7 @@ int imk_launch_head_im(const ImkHeadImArgs &a, hipStream_t stream) {
     do {                                                                                                                    \
         if (lds > 64 * 1024)                                                                                                \
             IMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        KERN<<<grid, 256, lds, stream>>>(a, 1, vec_img2);                                                                   \
+        imk_klaunch(KERN, dim3(grid), dim3(256), lds, stream, a, 1, vec_img2);                                                                   \
     } while (0)
     if (a.softmax) {
         const int kt = (a.K + 15) / 16;
@@ -584,14 +584,14 @@ extern "C" int imk_im_binary(const float *preds, int n_models, int batch, int h,
         const int vec_img = img && ((int64_t)hw * c % 16 == 0) && aligned16(img) && aligned16(img_out);
         dim3 grid(imk_cdiv(hw, BIN_CHUNK), batch);
         if (kb == 1)
-            im_binary_vec<1><<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
+            imk_klaunch(im_binary_vec<1>, dim3(grid), dim3(256), 0, stream, preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
                                                        img_out, masks_out, im_out, ims, pss, vec_out, vec_img);
         else
-            im_binary_vec<3><<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
+            imk_klaunch(im_binary_vec<3>, dim3(grid), dim3(256), 0, stream, preds, n_models, batch, hw, thr, cmp_ge, img, c, block_in, block_out,
                                                        img_out, masks_out, im_out, ims, pss, vec_out, vec_img);
     } else {
         dim3 grid(imk_cdiv(hw, 256), batch);
-        im_binary_generic<<<grid, 256, 0, stream>>>(preds, n_models, batch, hw, kb, thr, cmp_ge, img, c, block_in, block_out,
+        imk_klaunch(im_binary_generic, dim3(grid), dim3(256), 0, stream, preds, n_models, batch, hw, kb, thr, cmp_ge, img, c, block_in, block_out,
                                                     img_out, masks_out, im_out, ims, pss);
     }
     IMK_LAUNCH_CHECK();
@@ -619,7 +619,7 @@ extern "C" int imk_im_multiclass(const float *probs, int n_models, int batch, in
     const size_t lds = (size_t)MC_CHUNK * (k | 1) * sizeof(float);
     dim3 grid(imk_cdiv(hw, MC_CHUNK), batch);
     ImkProfScope prof(PF_IM, (double)batch * hw * ((double)n_models * k * 4 + (img ? 2.0 * c : 0.0) + 2), stream);
-    im_multi_kernel<<<grid, 256, lds, stream>>>(probs, n_models, batch, hw, k, magic, img, c, block_in, block_out,
+    imk_klaunch(im_multi_kernel, dim3(grid), dim3(256), lds, stream, probs, n_models, batch, hw, k, magic, img, c, block_in, block_out,
                                                 img_out, final_out, im_out, reinterpret_cast<unsigned long long *>(im_size),
                                                 presence, vec_in, vec_out, vec_img);
     IMK_LAUNCH_CHECK();
@@ -630,7 +630,7 @@ extern "C" int imk_morph(const uint8_t *src, uint8_t *dst, int batch, int h, int
     hipStream_t stream = (hipStream_t)stream_;
     IMK_CHECK_ARG(src && dst && src != dst && batch > 0 && h > 0 && w > 0 && ksize > 0 && ksize <= 31 && (op == 0 || op == 1));
     dim3 grid(imk_cdiv(w, 64), imk_cdiv(h, 4), batch);
-    morph_kernel<<<grid, 256, 0, stream>>>(src, dst, h, w, ksize, op);
+    imk_klaunch(morph_kernel, dim3(grid), dim3(256), 0, stream, src, dst, h, w, ksize, op);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }
@@ -643,7 +643,7 @@ extern "C" int imk_block_apply(const uint8_t *im, uint8_t *img, int c, uint8_t *
     IMK_CHECK_ARG(!masks || n_masks > 0);
     const int hw = h * w;
     dim3 grid(imk_cdiv(hw, 256), batch);
-    block_apply_kernel<<<grid, 256, 0, stream>>>(im, img, c, masks, n_masks, hw);
+    imk_klaunch(block_apply_kernel, dim3(grid), dim3(256), 0, stream, im, img, c, masks, n_masks, hw);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
 }

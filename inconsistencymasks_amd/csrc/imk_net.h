@@ -456,9 +456,17 @@ struct Bwd {
         if (n_pending == 0) return IMK_OK;
         const int si = n_fork % n_side;
         hipStream_t ws = c.p->side[si];
-        hipEvent_t ev = c.p->ev_fork[n_fork++];
-        IMK_HIP(hipEventRecord(ev, c.stream));
-        IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
+        // the side stream waits for the main stream's last kernel: through the event bound to that kernel when the pass runs with a
+        // stop-event ring (imk_common.h: no marker packet in front of the chain's next kernel), else through a recorded event
+        ImkStopRing *ring = imk_tls_stop_ring;
+        if (ring && ring->stream == c.stream && ring->last) {
+            IMK_HIP(hipStreamWaitEvent(ws, ring->last, 0));
+            ++n_fork;
+        } else {
+            hipEvent_t ev = c.p->ev_fork[n_fork++];
+            IMK_HIP(hipEventRecord(ev, c.stream));
+            IMK_HIP(hipStreamWaitEvent(ws, ev, 0));
+        }
         used_side[si] = true;
         for (int i = 0; i < n_pending; ++i) {
             int rc = launch_wgrad(pending[i].conv, pending[i].dA_override, ws);
@@ -560,6 +568,11 @@ struct Bwd {
         n_pending = 0;
         for (int si = 0; si < n_side; ++si) {   // join: the reductions below read the side streams' partials
             if (!used_side[si]) continue;
+            ImkStopRing *ring = imk_tls_stop_ring;
+            if (ring && ring->stream == c.stream && ring->side == c.p->side[si] && ring->side_last) {
+                IMK_HIP(hipStreamWaitEvent(c.stream, ring->side_last, 0));      // the side stream's last kernel's own event
+                continue;
+            }
             IMK_HIP(hipEventRecord(c.p->ev_join[si], c.p->side[si]));
             IMK_HIP(hipStreamWaitEvent(c.stream, c.p->ev_join[si], 0));
         }
@@ -592,6 +605,29 @@ struct Bwd {
     }
 };
 
+// Installs the plan's stop-event ring for `stream` on this thread for the lifetime of the object (a training step's backward pass).
+// IMK_STOP_EVENTS=0: forks record events of their own, as rounds 2-4 did.
+struct ImkStopRingScope {
+    ImkStopRing ring{};
+    ImkStopRing *prev = nullptr;
+    bool on = false;
+    ImkStopRingScope(const imk_unet_plan *plan, hipStream_t stream, int n_side) {
+        const bool want = n_side > 0;
+        // IMK_STOP_EVENTS: 0 = off, 1 (default) = the forks wait for kernel-bound events, 2 = the join at the end of the step as well
+        // (one box, four repetitions: ISIC step 0.964 / 0.954 / 0.957 ms, SUIM 1.631 / 1.614 / 1.620, EvalNet 2.037 / 2.027 / 2.025)
+        static const int mode = []() { const char *e = getenv("IMK_STOP_EVENTS"); return e ? atoi(e) : 1; }();
+        if (!want || mode <= 0 || !plan->ev_ring[0]) return;
+        ring = ImkStopRing{plan->ev_ring, 128, 0, stream, nullptr};
+        if (n_side == 1 && mode >= 2) ring.side = plan->side[0];
+        prev = imk_tls_stop_ring;
+        imk_tls_stop_ring = &ring;
+        on = true;
+    }
+    ~ImkStopRingScope() { if (on) imk_tls_stop_ring = prev; }
+    ImkStopRingScope(const ImkStopRingScope &) = delete;
+    ImkStopRingScope &operator=(const ImkStopRingScope &) = delete;
+};
+
 // Ensemble inference + IM.  Workspace: [N][B,H,W,K] fp32 probabilities, then one model's activations.
 // Side streams (training: weight gradients; ensemble inference: one model per stream) are shared by every plan of the
 // process on a device; the fork / join events are the plan's own.  One pair per PLAN cost 15 % of a SUIM training step
@@ -611,6 +647,7 @@ inline bool ensure_side_streams(const imk_unet_plan *plan, int n = 1) {
         for (int i = 0; i < imk_unet_plan::MAX_SIDE; ++i)
             ok = ok && hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
         for (auto &e : plan->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : plan->ev_ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         plan->side_ok = ok;
     });
     if (!plan->side_ok) return false;

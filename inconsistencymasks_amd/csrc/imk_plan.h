@@ -50,6 +50,7 @@ struct imk_unet_plan {
     mutable hipStream_t side[MAX_SIDE] = {};
     mutable hipEvent_t ev_fork[40] = {};
     mutable hipEvent_t ev_join[MAX_SIDE] = {};
+    mutable hipEvent_t ev_ring[128] = {};     // kernel-bound stop events of the backward pass (ImkStopRing, imk_common.h)
     mutable bool side_ok = false;
     // Debug / measurement switches of THIS plan (imk_unet_plan_debug; the caller owns the plan, the library keeps no global):
     // materialize: inference also stores the intermediates of fused kernels (layer-by-layer parity);

@@ -226,6 +226,7 @@ extern "C" void imk_unet_plan_destroy(imk_unet_plan *plan) {
         if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
     }
     for (auto &e : plan->ev_fork) if (e) (void)hipEventDestroy(e);
+    for (auto &e : plan->ev_ring) if (e) (void)hipEventDestroy(e);
     delete plan;
 }
 
@@ -449,6 +450,7 @@ extern "C" int imk_unet_fwd_bwd(const imk_unet_plan *plan, float *params, void *
                                          return v < 0 ? 0 : (v > imk_unet_plan::MAX_SIDE ? imk_unet_plan::MAX_SIDE : v); }();
     const bool side_on = side_px > 0 && !plan->dbg_single_stream && n_side_env > 0 && ensure_side_streams(plan, n_side_env);
     Bwd b{c, grads, sv.ctl, stats + 1, side_on ? n_side_env : 0, side_px};
+    ImkStopRingScope stop_ring(plan, stream, b.n_side);      // from here on: the backward pass's launches carry their own events
     bool loss_done = false;
     auto loss_on_side = [&]() -> int {      // once, as soon as a fork exists (every fork event is younger than the head's kernel)
         if (loss_done || b.n_side <= 0 || b.n_fork <= 0) return IMK_OK;

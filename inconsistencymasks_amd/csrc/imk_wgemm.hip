@@ -282,13 +282,13 @@ int launch_wgrad_gemm_k(const ImkWgradArgs &a, const WgGemmPlan &P, hipStream_t 
     const dim3 grid(P.n_split, P.gm.gi_n * P.gm.go_n);
     if constexpr (LM == LM_AFFINE && KS3 && !BNB) {
         if (wgrad_nfo2_on() && P.nfi_t == 2 && P.gm.cot_n <= 2) {
-            wgrad_gemm_kernel<LM, BNB, KS3, 2, 2><<<grid, 256, P.lds, stream>>>(a, P.gm);
+            imk_klaunch(wgrad_gemm_kernel<LM, BNB, KS3, 2, 2>, dim3(grid), dim3(256), P.lds, stream, a, P.gm);
             return IMK_OK;
         }
     }
-    if (P.nfi_t == 4) wgrad_gemm_kernel<LM, BNB, KS3, 4><<<grid, 256, P.lds, stream>>>(a, P.gm);
-    else if (P.nfi_t == 2) wgrad_gemm_kernel<LM, BNB, KS3, 2><<<grid, 256, P.lds, stream>>>(a, P.gm);
-    else wgrad_gemm_kernel<LM, BNB, KS3, 1><<<grid, 256, P.lds, stream>>>(a, P.gm);
+    if (P.nfi_t == 4) imk_klaunch(wgrad_gemm_kernel<LM, BNB, KS3, 4>, dim3(grid), dim3(256), P.lds, stream, a, P.gm);
+    else if (P.nfi_t == 2) imk_klaunch(wgrad_gemm_kernel<LM, BNB, KS3, 2>, dim3(grid), dim3(256), P.lds, stream, a, P.gm);
+    else imk_klaunch(wgrad_gemm_kernel<LM, BNB, KS3, 1>, dim3(grid), dim3(256), P.lds, stream, a, P.gm);
     return IMK_OK;
 }
 }  // namespace
