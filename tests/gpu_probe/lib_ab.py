@@ -5,8 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from inconsistencymasks_amd.unet import UNet
-CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "suim": (256, 256, 3, 9, 1.0, "softmax", 1)}
+CFG = {"isic": (256, 256, 3, 1, 0.5, "sigmoid", 0), "suim": (256, 256, 3, 9, 1.0, "softmax", 1),
+       "city": (208, 416, 3, 35, 1.0, "softmax", 1)}
 H, W, C, K, ALPHA, ACT, LOSS = CFG[os.environ.get("CONFIG", "isic")]
+ALPHA = float(os.environ.get("ALPHA", ALPHA))
 sha = lambda t: hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()[:10]
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randint(0, 256, (32, H, W, C), dtype=torch.uint8, device="cuda", generator=g)
