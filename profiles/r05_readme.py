@@ -77,6 +77,10 @@ def main():
 | `r05_full_driver_run_hela.txt` | `HeLa/09_HeLa_IM.py` at real size (2 candidates x 10 epochs) with cProfile: 11.0 s (31.7 s with the numpy / scipy position geometry; `csrc/imk_geom.cpp`) |
 | `r05_full_driver_run_impp.txt` | `ISIC_2018/12_ISIC_2018_IM++.py` at real size (2 EvalNets + 2 candidates x 10 epochs) with cProfile: 21.4 s (26.0 s before the shared reader pool, `read_png_stack` and the decoded training set kept across candidates) |
 | `r05_trajectory_diag_suim.txt` | `tests/gpu_probe/trajectory_diag.py`: per tensor, how far a GPU training run and the oracle's are apart after 1 ... 30 steps |
+| `r05_ab7.txt`, `r05_ab8.txt` | one-box A/B runs of the round's last two kernel changes: the staging maps of `bwd1x1_kernel` / `wgrad_gemm_kernel<.., 2, 2>` (kept) and `conv_gemm_kernel`'s RR form for 80- / 96-channel layers (`tests/gpu_probe/ab_rr.sh`: bit-identical, step-neutral, removed) |
+| `r05_step_timeline_single_stream_city_a1.25.txt`, `_a1.5.txt` | the single-stream timelines of the IM+ width schedule's two middle widths (notes, section 3: kernel time by family, alpha 1 -> 2) |
+| `r05_final_check_bench.json`, `r05_final_check_gpu_tests.txt` | `tests/gpu_probe/final_check.sh` on the round's last commit of `csrc/`, one box: `pytest -m gpu` (172 passed, 3 skipped = the Keras-golden fixtures this image cannot produce), `smoke()`, the default `python bench.py` line (25 344 images/s, 92.13 ms = 14.65 + 77.43) |
+| `r05_bench_2ranks_one_gpu_gloo.json`, `r05_bench_8ranks_one_gpu_gloo.json` | same script: `IMK_BENCH_ONE_GPU=1 IMK_BENCH_BACKEND=gloo python bench.py --gpus 2` / `--gpus 8` -- the self-launching strong-scaling path with 2 / 8 ranks time-slicing ONE GPU (functional: `n_gpus` 2 / 8, shards of 2 335 / 8 = 291-292 images, `sharding_check.equals_sum_over_ranks` true; the throughput means nothing) |
 """)
     out.append(f"""Headline (`r05_bench.json`): **{b['value']:.0f} images/s per IM generation on 1 GPU** -- {b['ms_per_step']} ms per generation =
 {b['stage_ms']['ensemble_infer_plus_im']} ms (ensemble forward + fused head / IM, calls of {b['config']['infer_batch']} images) + {b['stage_ms']['train_epoch']} ms ({b['config']['epoch_steps']} training steps of
