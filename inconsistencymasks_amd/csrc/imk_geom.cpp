@@ -8,7 +8,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
+
+// no C++ exception leaves the C ABI (see imk_png.cpp): a failed allocation is IMK_EWORKSPACE
+#define IMK_NOTHROW(...) try { __VA_ARGS__ } catch (const std::bad_alloc &) { return IMK_EWORKSPACE; } catch (...) { return IMK_EINVAL; }
 
 namespace {
 
@@ -221,11 +225,13 @@ void disc(uint8_t *img, int h, int w, int cx, int cy, int r, uint8_t value) {
 extern "C" IMK_API int imk_pos_contours(const uint8_t *img, int h, int w, int erode_kernel, int32_t *xy, int cap) {
     if (!img || h <= 0 || w <= 0 || (int64_t)h * w > INT32_MAX || cap < 0 || (cap > 0 && !xy)) return IMK_EINVAL;
     if (erode_kernel > 1 && !(erode_kernel & 1)) return IMK_EUNSUPPORTED;    // even windows: the caller erodes
+    IMK_NOTHROW(
     Positions pos;
     pos_contours(img, h, w, erode_kernel, pos);
     int n = (int)pos.v.size();
     for (int i = 0; i < n && i < cap; ++i) { xy[2 * i] = pos.v[i].x; xy[2 * i + 1] = pos.v[i].y; }
     return n;
+    )
 }
 
 // functions.py:6255-6292 mod_pos_size: every blob re-drawn as a filled circle of radius clamp(min_dist // 4, min_r, max_r),
@@ -236,6 +242,7 @@ extern "C" IMK_API int imk_pos_contours(const uint8_t *img, int h, int w, int er
 extern "C" IMK_API int imk_mod_pos_size(const uint8_t *img, int h, int w, int max_r, int min_r, int lone_dist, int blur2,
                                         uint8_t *out) {
     if (!img || !out || h <= 1 || w <= 1 || (int64_t)h * w > INT32_MAX) return IMK_EINVAL;
+    IMK_NOTHROW(
     Positions pos;
     pos_contours(img, h, w, 3, pos);
     std::vector<uint8_t> scratch;
@@ -267,25 +274,26 @@ extern "C" IMK_API int imk_mod_pos_size(const uint8_t *img, int h, int w, int ma
         }
     }
     return IMK_OK;
+    )
 }
 
 // functions.py:6298-6371 get_cell_count: at every position, the class with more pixels > 10 in the 2m x 2m window around it
 // (moved inside the image the way the reference moves it).  counts = {alive, dead, unclear}.
 extern "C" IMK_API int imk_cell_count(const int32_t *xy, int n, const uint8_t *alive, const uint8_t *dead, int h, int w,
                                       int measuring_range, int32_t counts[3]) {
-    int m = measuring_range;
+    const int64_t m = measuring_range;          // 64-bit window arithmetic: positions and the range are the caller's, any int32
     if (n < 0 || (n > 0 && !xy) || !alive || !dead || !counts || m <= 0 || h < 2 * m || w < 2 * m) return IMK_EINVAL;
     counts[0] = counts[1] = counts[2] = 0;
     for (int i = 0; i < n; ++i) {
-        int x = xy[2 * i], y = xy[2 * i + 1];
+        int64_t x = xy[2 * i], y = xy[2 * i + 1];
         if (x - m <= 0) x += m;
         if (x + m > w) x = w - m;
         if (y - m < 0) y += m;
         if (y + m > h) y = h - m;
         if (x - m < 0 || y - m < 0 || x + m > w || y + m > h) return IMK_EINVAL;     // a position outside the image
         int sa = 0, sd = 0;
-        for (int yy = y - m; yy < y + m; ++yy)
-            for (int xx = x - m; xx < x + m; ++xx) {
+        for (int64_t yy = y - m; yy < y + m; ++yy)
+            for (int64_t xx = x - m; xx < x + m; ++xx) {
                 sa += alive[(size_t)yy * w + xx] > 10;
                 sd += dead[(size_t)yy * w + xx] > 10;
             }

@@ -18,9 +18,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
+#include <new>
 #include <vector>
 
 #include "../../include/imk.h"
+
+// The C ABI does not let a C++ exception out (a ctypes / cgo caller cannot catch it: std::terminate): an allocation that fails -- a forged
+// IHDR asking for terabytes -- is IMK_EWORKSPACE, anything else IMK_EINVAL.  (tools/host_sanitize.py: ASan + UBSan over mutated files.)
+#define IMK_NOTHROW(...) try { __VA_ARGS__ } catch (const std::bad_alloc &) { return IMK_EWORKSPACE; } catch (...) { return IMK_EINVAL; }
 
 namespace {
 
@@ -90,7 +96,8 @@ IMK_API int imk_png_info(const char *path, int *h, int *w, int *color_type, int 
 
 /* PNG bytes in memory -> uint8 [h, w, want_c] (want_c = 1: greyscale, 3: RGB) in `out` (host, capacity out_cap bytes). */
 IMK_API int imk_png_decode(const uint8_t *data_in, int64_t len, int want_c, uint8_t *out, int64_t out_cap, int *h_out, int *w_out) {
-    if (!data_in || len < 0 || !out || (want_c != 1 && want_c != 3)) return IMK_EINVAL;
+    if (!data_in || len < 0 || !out || out_cap < 0 || (want_c != 1 && want_c != 3)) return IMK_EINVAL;
+    IMK_NOTHROW(
     struct Span { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; }
                   const uint8_t &operator[](size_t i) const { return p[i]; } } file{data_in, (size_t)len};
     Header hd{};
@@ -108,7 +115,8 @@ IMK_API int imk_png_decode(const uint8_t *data_in, int64_t len, int want_c, uint
     }
     if (h_out) *h_out = hd.h;
     if (w_out) *w_out = hd.w;
-    if ((int64_t)hd.h * hd.w * want_c > out_cap) return IMK_EWORKSPACE;
+    // h, w < 2^31 from the file: h * want_c fits, the product of all three need not (a forged header must not wrap past the check)
+    if ((int64_t)hd.w > out_cap / ((int64_t)hd.h * want_c)) return IMK_EWORKSPACE;
     // chunks: PLTE, IDAT*
     uint8_t pal[256][3];
     memset(pal, 0, sizeof pal);
@@ -173,21 +181,26 @@ IMK_API int imk_png_decode(const uint8_t *data_in, int64_t len, int want_c, uint
         }
     }
     return IMK_OK;
+    )
 }
 
 /* PNG file -> uint8 [h, w, want_c] in `out` (host): imk_png_decode of the file's bytes. */
 IMK_API int imk_png_read_file(const char *path, int want_c, uint8_t *out, int64_t out_cap, int *h_out, int *w_out) {
     if (!path) return IMK_EINVAL;
+    IMK_NOTHROW(
     std::vector<uint8_t> file;
     if (!read_all(path, file)) return IMK_EINVAL;
     return imk_png_decode(file.data(), (int64_t)file.size(), want_c, out, out_cap, h_out, w_out);
+    )
 }
 
 /* uint8 [h, w, c] (c = 1 greyscale, 3 RGB; host) -> PNG bytes in `out` (capacity out_cap), length in *out_len. */
 IMK_API int imk_png_encode(const uint8_t *pixels, int h, int w, int c, int level, uint8_t *out, int64_t out_cap, int64_t *out_len) {
-    if (!pixels || h <= 0 || w <= 0 || (c != 1 && c != 3) || !out || !out_len) return IMK_EINVAL;
+    if (!pixels || h <= 0 || w <= 0 || (c != 1 && c != 3) || !out || out_cap < 0 || !out_len) return IMK_EINVAL;
     if (level < 0 || level > 9) level = 1;
     const size_t stride = (size_t)w * c;
+    if ((stride + 1) > (size_t)UINT_MAX / (size_t)h) return IMK_EUNSUPPORTED;      // zlib's 32-bit counts: one deflate call per image
+    IMK_NOTHROW(
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);
     std::vector<uint8_t> cand(2 * stride);
     for (int r = 0; r < h; ++r) {
@@ -229,11 +242,13 @@ IMK_API int imk_png_encode(const uint8_t *pixels, int h, int w, int c, int level
     if ((int64_t)o.size() > out_cap) return IMK_EWORKSPACE;
     memcpy(out, o.data(), o.size());
     return IMK_OK;
+    )
 }
 
 /* uint8 [h, w, c] (host) -> PNG file. */
 IMK_API int imk_png_write_file(const char *path, const uint8_t *pixels, int h, int w, int c, int level) {
-    if (!path) return IMK_EINVAL;
+    if (!path || !pixels || h <= 0 || w <= 0 || (c != 1 && c != 3)) return IMK_EINVAL;
+    IMK_NOTHROW(
     const int64_t cap = (int64_t)h * w * c + (int64_t)h + (int64_t)h * w * c / 500 + 4096;
     std::vector<uint8_t> buf((size_t)cap);
     int64_t n = 0;
@@ -244,6 +259,7 @@ IMK_API int imk_png_write_file(const char *path, const uint8_t *pixels, int h, i
     const size_t put = fwrite(buf.data(), 1, (size_t)n, f);
     const int cl = fclose(f);
     return (put == (size_t)n && cl == 0) ? IMK_OK : IMK_EINVAL;
+    )
 }
 
 }  // extern "C"

@@ -185,3 +185,30 @@ def test_stack_reader_equals_file_by_file_reads(tmp_path):
         assert pool.map(lambda v: v * v, range(1000)) == [v * v for v in range(1000)]
         with pytest.raises(ZeroDivisionError):
             pool.map(lambda v: 1 // (v - 700), range(1000))
+
+
+def test_forged_header_is_an_error_code_not_a_crash():
+    """A PNG whose IHDR claims 2^31 - 1 pixels a side (round 5, found by tools/host_sanitize.py: h * w * 3 wrapped past the capacity check and
+    the row buffer's allocation then threw through the C ABI): every entry point returns an error code, for any capacity."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    for (w, h) in ((2**31 - 1, 2**31 - 1), (2**31 - 1, 1), (1, 2**31 - 1), (65536, 65536), (1 << 20, 1 << 20)):
+        png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+               + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+        src = np.frombuffer(png, np.uint8).copy()
+        for cap in (0, 16, 1 << 16):
+            out = np.zeros(max(cap, 1), np.uint8)
+            hh, ww = ctypes.c_int(), ctypes.c_int()
+            for want in (1, 3):
+                rc = lib.imk_png_decode(src.ctypes.data, ctypes.c_int64(src.size), want, out.ctypes.data, ctypes.c_int64(cap),
+                                        ctypes.byref(hh), ctypes.byref(ww))
+                assert rc != 0
+    # the writer validates before it sizes its buffer
+    px = np.zeros((4, 4, 3), np.uint8)
+    for (h, w, c) in ((0, 4, 3), (4, -1, 3), (4, 4, 2)):
+        assert lib.imk_png_write_file(os.fsencode("/tmp/_imk_never_written.png"), px.ctypes.data, h, w, c, 1) != 0
+    assert not os.path.exists("/tmp/_imk_never_written.png")
