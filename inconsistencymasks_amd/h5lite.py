@@ -131,6 +131,12 @@ def _parse_space(b, p):
     return tuple(b.len(q + i * b.L) for i in range(rank))
 
 
+# A damaged or hostile file must end in H5Error, not in a hang: links that lead back into their own ancestry, B-tree nodes and
+# header continuations that point at themselves (found by mutating the fixtures: tests/test_cpu_h5lite.py::test_mutated_files_*).
+_MAX_MESSAGES = 1 << 16     # per object header (v1 headers carry a 16-bit count)
+_MAX_TREE_DEPTH = 32        # B-tree levels (libhdf5 itself stays in single digits) and group nesting
+
+
 class _Header:
     """the messages of one object header: [(type, flags, offset of the data, size)]"""
 
@@ -147,8 +153,12 @@ class _Header:
             raise H5Error(f"object header at {addr}: version {b.u(addr, 1)}, expected 1")
         n_msgs = b.u(addr + 2, 2)
         blocks = [(addr + 16, b.u(addr + 8, 4))]
+        seen = set()
         while blocks and len(self.msgs) < n_msgs:
             p, size = blocks.pop(0)
+            if p in seen:
+                raise H5Error(f"object header at {addr}: continuation block {p} linked twice")
+            seen.add(p)
             end = p + size
             while p + 8 <= end and len(self.msgs) < n_msgs:
                 t, s, fl = b.u(p, 2), b.u(p + 2, 2), b.u(p + 4, 1)
@@ -172,8 +182,12 @@ class _Header:
         p += w
         track = bool(fl & 4)
         blocks = [(p, size0)]
+        seen = set()
         while blocks:
             p, size = blocks.pop(0)
+            if p in seen or len(self.msgs) > _MAX_MESSAGES:
+                raise H5Error(f"object header at {addr}: continuation chunk {p} linked twice, or more than {_MAX_MESSAGES} messages")
+            seen.add(p)
             end = p + size                                 # chunk 0: messages end where the checksum starts
             hdr = 4 + (2 if track else 0)
             while p + hdr <= end:
@@ -276,6 +290,14 @@ class _Node:
 
     @property
     def attrs(self):
+        try:
+            return self._get_attrs()
+        except H5Error:
+            raise
+        except (ValueError, OverflowError, IndexError, MemoryError) as e:
+            raise H5Error(f"{self.name}: attributes: {type(e).__name__}: {e}") from None
+
+    def _get_attrs(self):
         if self._attrs is None:
             info = self._h.one(0x15)
             if info is not None:
@@ -343,7 +365,10 @@ class Dataset(_Node):
             if mask & (1 << i):
                 continue
             if fid == 1:
-                raw = zlib.decompress(raw)
+                try:
+                    raw = zlib.decompress(raw)
+                except zlib.error as e:
+                    raise H5Error(f"{self.name}: deflate filter: {e}") from None
             elif fid == 2:
                 es = cd[0] if cd else esize
                 n = len(raw) // es
@@ -355,11 +380,13 @@ class Dataset(_Node):
                 raise H5Unsupported(f"{self.name}: filter {fid} (only deflate, shuffle and fletcher32 are read)")
         return raw
 
-    def _chunks(self, addr, ndim):
+    def _chunks(self, addr, ndim, depth=0):
         """leaf entries of the chunk B-tree: (chunk size in bytes, filter mask, offsets, address)"""
         b = self._b
-        if b.d[addr:addr + 4] != b"TREE" or b.u(addr + 4, 1) != 1:
+        if addr is None or b.d[addr:addr + 4] != b"TREE" or b.u(addr + 4, 1) != 1:
             raise H5Error(f"{self.name}: no chunk B-tree node at {addr}")
+        if depth > _MAX_TREE_DEPTH:
+            raise H5Error(f"{self.name}: chunk B-tree deeper than {_MAX_TREE_DEPTH} levels (a node that links to itself?)")
         level, used = b.u(addr + 5, 1), b.u(addr + 6, 2)
         ks = 8 + 8 * (ndim + 1)
         p = addr + 8 + 2 * b.O
@@ -370,10 +397,19 @@ class Dataset(_Node):
             if level == 0:
                 yield size, mask, offs, child
             else:
-                yield from self._chunks(child, ndim)
+                yield from self._chunks(child, ndim, depth + 1)
             p += ks + b.O
 
     def read(self):
+        """the dataset's values; whatever a damaged file makes numpy / the decoders say comes out as H5Error"""
+        try:
+            return self._read()
+        except H5Error:
+            raise
+        except (ValueError, OverflowError, IndexError, MemoryError) as e:
+            raise H5Error(f"{self.name}: {type(e).__name__}: {e}") from None
+
+    def _read(self):
         b, h, typ = self._b, self._h, self._type
         if self.shape is None:
             return None
@@ -444,10 +480,19 @@ class Group(_Node):
     def __init__(self, b, addr, name):
         super().__init__(b, addr, name)
         self._links = None
+        self._anc = frozenset()                            # object-header addresses of the groups above this one
 
     def _load(self):
         if self._links is not None:
             return self._links
+        try:
+            return self._load_links()
+        except H5Error:
+            raise
+        except (ValueError, OverflowError, IndexError) as e:    # e.g. a link name that is not UTF-8
+            raise H5Error(f"{self.name}: {type(e).__name__}: {e}") from None
+
+    def _load_links(self):
         b, links = self._b, {}
         st = self._h.one(0x11)
         if st is not None:
@@ -488,8 +533,10 @@ class Group(_Node):
         self._links = links
         return links
 
-    def _walk(self, addr, seg, links):
+    def _walk(self, addr, seg, links, depth=0):
         b = self._b
+        if addr is None or depth > _MAX_TREE_DEPTH:
+            raise H5Error(f"{self.name}: group B-tree without a node, or deeper than {_MAX_TREE_DEPTH} levels (a node that links to itself?)")
         if b.d[addr:addr + 4] == b"SNOD":
             n = b.u(addr + 6, 2)
             p = addr + 8
@@ -499,6 +546,8 @@ class Group(_Node):
                 oh = b.off(p + b.O)
                 ct = b.u(p + 2 * b.O, 4)
                 end = b.d.find(b"\0", seg + no)
+                if end < 0:
+                    raise H5Error(f"{self.name}: unterminated link name in the local heap")
                 nm = bytes(b.d[seg + no:end]).decode("utf-8")
                 if ct != 2:                                # 2 = symbolic link (no object header)
                     links[nm] = oh
@@ -509,7 +558,7 @@ class Group(_Node):
         used = b.u(addr + 6, 2)
         p = addr + 8 + 2 * b.O + b.L                       # skip key 0
         for i in range(used):
-            self._walk(b.off(p), seg, links)
+            self._walk(b.off(p), seg, links, depth + 1)
             p += b.O + b.L
 
     def keys(self):
@@ -528,22 +577,32 @@ class Group(_Node):
         except KeyError:
             return False
 
+    def _child(self, part):
+        """the member linked under the ONE name `part` (any string the file holds, also '' or one with a slash in it)"""
+        links = self._load()
+        if part not in links:
+            raise KeyError(f"{part!r} not in {self.name} (members: {', '.join(sorted(links)[:12])}{' ...' if len(links) > 12 else ''})")
+        child = (self.name.rstrip("/") + "/" + part)
+        anc = self._anc | {self._addr}
+        if links[part] in anc or len(anc) > _MAX_TREE_DEPTH:
+            raise H5Error(f"{child}: a hard link back into its own ancestry (or groups nested deeper than {_MAX_TREE_DEPTH})")
+        h = _Header(self._b, links[part])
+        is_group = h.one(0x11) is not None or h.one(0x02) is not None or (h.one(0x08) is None and h.one(0x03) is None)
+        node = Group(self._b, links[part], child) if is_group else Dataset(self._b, links[part], child)
+        if is_group:
+            node._anc = anc
+        return node
+
     def __getitem__(self, path):
         node = self
         for part in [s for s in path.split("/") if s]:
             if not isinstance(node, Group):
                 raise KeyError(f"{node.name} is a dataset, not a group (looking up {path!r} in {self.name})")
-            links = node._load()
-            if part not in links:
-                raise KeyError(f"{part!r} not in {node.name} (members: {', '.join(sorted(links)[:12])}{' ...' if len(links) > 12 else ''})")
-            child = (node.name.rstrip("/") + "/" + part)
-            h = _Header(node._b, links[part])
-            is_group = h.one(0x11) is not None or h.one(0x02) is not None or (h.one(0x08) is None and h.one(0x03) is None)
-            node = Group(node._b, links[part], child) if is_group else Dataset(node._b, links[part], child)
+            node = node._child(part)
         return node
 
     def items(self):
-        return [(k, self[k]) for k in self.keys()]
+        return [(k, self._child(k)) for k in self.keys()]
 
     def visit_datasets(self, prefix=""):
         """every dataset below this group: (path relative to it, Dataset)"""

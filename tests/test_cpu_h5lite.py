@@ -240,3 +240,56 @@ def test_keras_evalnet_fixture_to_state_dict(tmp_path):
         K.state_dict_from_keras_h5(path)
     with pytest.raises(ValueError, match="not an evalnet"):
         K.evalnet_state_dict_from_keras_h5(os.path.join(GOLD, "h5_keras_full_model.h5"))
+
+
+def test_mutated_files_end_in_h5error_not_in_a_hang(tmp_path):
+    """A damaged checkpoint must raise H.H5Error (a ValueError) -- not hang, not exhaust the stack, not leak numpy's or zlib's own
+    exception types.  Round 5: mutating the four fixtures found group links back into their own ancestry (visit_datasets recursed for
+    ever), a link with the empty name (looked up as the group itself), object-header continuations and B-tree nodes pointing at
+    themselves, and zlib / numpy errors coming out raw.  600 seeded mutations (bit flips, 8 random bytes, truncations), each walked in
+    full (every dataset read, every attribute decoded) under a 10 s alarm."""
+    import glob
+    import signal
+    seeds = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(GOLD, "*.h5")))]
+    assert len(seeds) >= 4
+    rng = np.random.default_rng(5)
+
+    class Hang(Exception):
+        pass
+
+    def on_alarm(sig, frame):
+        raise Hang()
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    outcomes = {"ok": 0, "H5Error": 0}
+    try:
+        for it in range(600):
+            s = bytearray(seeds[it % len(seeds)])
+            k = it % 3
+            if k == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    o = int(rng.integers(0, len(s) - 8))
+                    s[o:o + 8] = rng.integers(0, 256, 8).astype("uint8").tobytes()
+            else:
+                s = s[:int(rng.integers(8, len(s)))]
+            p = str(tmp_path / "m.h5")
+            with open(p, "wb") as fh:
+                fh.write(s)
+            signal.alarm(10)
+            try:
+                with H.File(p) as f:
+                    for name, ds in f.visit_datasets():
+                        ds.read()
+                        dict(ds.attrs)
+                    dict(f.attrs)
+                outcomes["ok"] += 1
+            except H.H5Error:
+                outcomes["H5Error"] += 1
+            finally:
+                signal.alarm(0)
+    finally:
+        signal.signal(signal.SIGALRM, old)
+    assert outcomes["ok"] > 50 and outcomes["H5Error"] > 50, outcomes      # both kinds of file were in the sample
