@@ -357,7 +357,7 @@ def png_io_rate(images):
     assert all(np.array_equal(b, a) for a, b in zip(images, back)) and np.array_equal(sq(back_p[0]), sq(images[0]))
     assert np.array_equal(dec_p(blobs[0]).reshape(images[0].shape), images[0])       # Pillow reads what the native encoder wrote
     return {"encode_images_per_s": round(len(images) / (t1 - t0), 1), "decode_images_per_s": round(len(images) / (t2 - t1), 1),
-            "threads": threads, "codec": "libimk (imk_png_encode / imk_png_decode: zlib level 1, filters None / Sub / Up per row)",
+            "threads": threads, "codec": "libimk (imk_png_encode / imk_png_decode: zlib level 1 Z_RLE, filters None / Sub / Up per row)",
             "pillow_encode_images_per_s": round(len(images) / (t4 - t3), 1), "pillow_decode_images_per_s": round(len(images) / (t5 - t4), 1),
             "sample": f"{len(images)} images {'x'.join(map(str, images[0].shape))}"}
 

@@ -11,7 +11,10 @@
 // greyscale + alpha, RGBA, non-interlaced -- and reports IMK_EUNSUPPORTED for anything else (16-bit, 1/2/4-bit, Adam7), for which
 // the Python layer falls back to Pillow.  Conversions follow Pillow's `convert("RGB")` / `convert("L")` (what rounds 1-4 returned):
 // alpha dropped, palette expanded, L = (19595 R + 38470 G + 7471 B + 32768) >> 16.  The ENCODER writes 8-bit greyscale or RGB with a
-// per-row choice among the filters None / Sub / Up (minimum sum of absolute differences) and deflate level `level`.
+// per-row choice among the filters None / Sub / Up (minimum sum of absolute differences) and deflate level `level` with the Z_RLE
+// strategy -- what cv2.imwrite itself uses by default (level 1, IMWRITE_PNG_STRATEGY_RLE) and, on filtered photographic rows, 1.5 x the
+// images per second of Z_FILTERED at level 1 for 11 % SMALLER files (tests/gpu_probe/png_encode_ab.py, 8 threads: 256 x 256 x 3 images
+// 1 130-1 270 -> 1 730-1 920 per second, 125 -> 111 KB; masks unchanged within the noise, 0.8 -> 0.5 KB).
 #include <zlib.h>
 
 #include <cstdint>
@@ -220,7 +223,7 @@ IMK_API int imk_png_encode(const uint8_t *pixels, int h, int w, int c, int level
     }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, Z_FILTERED) != Z_OK) return IMK_EINVAL;
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, Z_RLE) != Z_OK) return IMK_EINVAL;
     uLongf zn = deflateBound(&zs, (uLong)raw.size());
     std::vector<uint8_t> z(zn);
     zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();

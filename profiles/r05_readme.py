@@ -81,6 +81,7 @@ def main():
 | `r05_step_timeline_single_stream_city_a1.25.txt`, `_a1.5.txt` | the single-stream timelines of the IM+ width schedule's two middle widths (notes, section 3: kernel time by family, alpha 1 -> 2) |
 | `r05_final_check_bench.json`, `r05_final_check_gpu_tests.txt` | `tests/gpu_probe/final_check.sh` on the round's last commit, one box: `pytest -m gpu` (172 passed, 3 skipped = the Keras-golden fixtures this image cannot produce), `smoke()`, the default `python bench.py` line (25 452 images/s, 91.74 ms = 14.60 + 77.09; re-run after the host-code fixes of section 7) |
 | `r05_configs_bench_cityscapes_a125.json`, `r05_configs_kernel_stats_cityscapes_a125.csv` | `tests/gpu_probe/collect_a125.sh`: the Cityscapes shape at alpha 1.25 like the alpha 1 / 2 files (5 628 images/s per generation, training step 3.63 ms; no kernel above 6.1 % of the kernel time) |
+| `r05_full_driver_run_rle.txt` | the real-size ISIC generation after the PNG encoder's switch to the Z_RLE strategy (notes, section 8): pseudo-label stage 0.89 s, generation 17.2 s |
 | `r05_bench_repeats.txt` | the default bench command five times in a row on one box: 25.17-25.36 k images/s, +-0.4 % run to run |
 | `r05_bench_2ranks_one_gpu_gloo.json`, `r05_bench_8ranks_one_gpu_gloo.json` | same script: `IMK_BENCH_ONE_GPU=1 IMK_BENCH_BACKEND=gloo python bench.py --gpus 2` / `--gpus 8` -- the self-launching strong-scaling path with 2 / 8 ranks time-slicing ONE GPU (functional: `n_gpus` 2 / 8, shards of 2 335 / 8 = 291-292 images, `sharding_check.equals_sum_over_ranks` true; the throughput means nothing) |
 """)
