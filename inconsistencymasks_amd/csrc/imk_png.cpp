@@ -171,6 +171,8 @@ IMK_API int imk_png_decode(const uint8_t *data_in, int64_t len, int want_c, uint
         }
         prev = x;
         uint8_t *o = out + (size_t)r * hd.w * want_c;
+        // the two layouts the datasets and this package's writer produce need no per-pixel work: RGB -> RGB, greyscale -> greyscale
+        if ((hd.ctype == 2 && want_c == 3) || (hd.ctype == 0 && want_c == 1)) { memcpy(o, x, stride); continue; }
         for (int px = 0; px < hd.w; ++px) {
             int R, G, B;
             bool grey = false;
