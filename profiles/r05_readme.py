@@ -79,7 +79,7 @@ def main():
 | `r05_trajectory_diag_suim.txt` | `tests/gpu_probe/trajectory_diag.py`: per tensor, how far a GPU training run and the oracle's are apart after 1 ... 30 steps |
 | `r05_ab7.txt`, `r05_ab8.txt` | one-box A/B runs of the round's last two kernel changes: the staging maps of `bwd1x1_kernel` / `wgrad_gemm_kernel<.., 2, 2>` (kept) and `conv_gemm_kernel`'s RR form for 80- / 96-channel layers (`tests/gpu_probe/ab_rr.sh`: bit-identical, step-neutral, removed) |
 | `r05_step_timeline_single_stream_city_a1.25.txt`, `_a1.5.txt` | the single-stream timelines of the IM+ width schedule's two middle widths (notes, section 3: kernel time by family, alpha 1 -> 2) |
-| `r05_final_check_bench.json`, `r05_final_check_gpu_tests.txt` | `tests/gpu_probe/final_check.sh` on the round's last commit, one box: `pytest -m gpu` (172 passed, 3 skipped = the Keras-golden fixtures this image cannot produce), `smoke()`, the default `python bench.py` line (tests on the build before the PNG strategy change, whose own PNG-path GPU tests -- writers, drivers: 36 -- were re-run; the line itself from the last build: 25 476 images/s, 91.66 ms = 14.38 + 77.22, `png_io` 9.6 k encoded / 20.8 k decoded images/s) |
+| `r05_final_check_bench.json`, `r05_final_check_gpu_tests.txt` | `tests/gpu_probe/final_check.sh` on the round's last commit, one box: `pytest -m gpu` (172 passed, 3 skipped = the Keras-golden fixtures this image cannot produce), `smoke()`, the default `python bench.py` line (the test run is of the round's last commit; the line from the build one host-side commit earlier: 25 476 images/s, 91.66 ms = 14.38 + 77.22, `png_io` 9.6 k encoded / 20.8 k decoded images/s) |
 | `r05_configs_bench_cityscapes_a125.json`, `r05_configs_kernel_stats_cityscapes_a125.csv` | `tests/gpu_probe/collect_a125.sh`: the Cityscapes shape at alpha 1.25 like the alpha 1 / 2 files (5 628 images/s per generation, training step 3.63 ms; no kernel above 6.1 % of the kernel time) |
 | `r05_full_driver_run_rle.txt` | the real-size ISIC generation after the PNG encoder's switch to the Z_RLE strategy (notes, section 8): pseudo-label stage 0.89 s, generation 17.2 s |
 | `r05_bench_repeats.txt` | the default bench command five times in a row on one box: 25.17-25.36 k images/s, +-0.4 % run to run |
