@@ -34,6 +34,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("IMK_GOLDEN_OUT", HERE)       # tests/test_golden_regenerate.py writes to a scratch directory and compares
 REF = "/root/reference"
 
 
@@ -140,7 +141,7 @@ def gen_binary(F):
                 cases.append(k)
                 cid += 1
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "im_binary.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "im_binary.npz"), **out)
     print("im_binary:", len(cases), "cases")
 
 
@@ -167,7 +168,7 @@ def gen_hela(F):
                 cases.append(k)
                 cid += 1
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "im_hela.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "im_hela.npz"), **out)
     print("im_hela:", len(cases), "cases")
 
 
@@ -225,7 +226,7 @@ def gen_multiclass(F):
                     cases.append(k)
                     cid += 1
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "im_multiclass.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "im_multiclass.npz"), **out)
     print("im_multiclass:", len(cases), "cases")
 
 
@@ -299,7 +300,7 @@ def gen_writers(F, cv2):
                 for p, a in written.items():
                     out[tag + "/" + p] = a
     out["combos"] = np.array(combos)
-    np.savez_compressed(os.path.join(HERE, "writer_isic.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "writer_isic.npz"), **out)
     print("writer_isic:", len(combos), "flag combos")
 
     # ---- multiclass writer ----------------------------------------------------
@@ -336,7 +337,7 @@ def gen_writers(F, cv2):
                 for p, a in written.items():
                     out[tag + "/" + p] = a
     out["combos"] = np.array(combos)
-    np.savez_compressed(os.path.join(HERE, "writer_multi.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "writer_multi.npz"), **out)
     print("writer_multi:", len(combos), "flag combos")
 
 
@@ -372,7 +373,7 @@ def gen_metrics(F):
     out["dist_pts"] = pts
     out["dist_min"] = np.array([F.get_min_dist(tuple(p), [tuple(q) for q in pts]) for p in pts], np.float64)
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
     print("metrics:", len(cases), "cases")
 
 
@@ -392,7 +393,7 @@ def gen_augment(F):
         out[k + "_img"], out[k + "_noise"], out[k + "_out"], out[k + "_m"] = img, noise.astype(np.int16), got, np.array([m])
         cases.append(k)
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
     print("augment:", len(cases), "cases")
 
 
@@ -423,7 +424,7 @@ def gen_evalnet_labels(F):
         out[k + "_det"] = np.array(F.compute_classwise_detection(pred, K), np.int64)
         cases.append(k)
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "evalnet_labels.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "evalnet_labels.npz"), **out)
     print("evalnet_labels:", len(cases), "cases")
 
 
