@@ -67,6 +67,117 @@ BATCH = 32
 LR, WD = 3e-3, 1e-4
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA
+ROUND = "r06"            # profiles/<ROUND>_*: the only committed files a line may replay values from
+LINE_BUDGET = 4096       # bytes of the LAST stdout line (the driver parses the tail of stdout; round 5's 21 KB line was cut)
+
+
+def bench_py_sha16():
+    import hashlib
+    return hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
+
+
+def lib_build_id():
+    from inconsistencymasks_amd.build import source_id
+    return source_id()
+
+
+def config_tag(config_name, alpha):
+    """suffix of the per-configuration files under profiles/: '' for the default (isic at its own width), '_suim',
+    '_cityscapes_a2', '_cityscapes_a125', ..."""
+    own = alpha is None or float(alpha) == float(CONFIGS[config_name]["alpha"])
+    if config_name == "isic" and own:
+        return ""
+    return f"_{config_name}" + ("" if own else "_a" + f"{float(alpha):g}".replace(".", ""))
+
+
+def provenance(tag=""):
+    """What the committed profiles/<ROUND>_* files of configuration `tag` were collected with (profiles/collect_round.sh writes it):
+    replayed values are printed only when BOTH the bench script and the kernel sources are the ones running now."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_provenance{tag}.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return False, f"profiles/{ROUND}_provenance{tag}.json missing", None
+    now = {"bench_py_sha16": bench_py_sha16(), "lib_build_id": lib_build_id()}
+    for k, v in now.items():
+        if rec.get(k) != v:
+            return False, f"{k}: profiles {rec.get(k)} != running {v}", rec
+    return True, None, rec
+
+
+def _strip(name):
+    return name.replace(", ", ",") if isinstance(name, str) else name
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line the driver parses (last line of stdout, < LINE_BUDGET bytes): the contract's fields + roofline + cpu_baseline in
+    short form.  Everything else of `full` (all families, exclusive pass, kernel totals, thread calibration, layerwise parity, PNG
+    rates) goes to gpurun_out/bench_detail.json."""
+    c, r = full["config"], full["roofline"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "stage_ms")}
+    line["config"] = {k: c.get(k) for k in ("workload", "name", "shape", "alpha", "outputs", "n_models", "unlabeled_images",
+                                            "unlabeled_images_per_gpu", "labeled_images", "infer_batch", "infer_batch_rule",
+                                            "train_batch_per_gpu", "global_batch", "parallelism", "process_group", "epoch_steps", "kept")}
+    line["config"]["bn_momentum"] = (c.get("bn_momentum") or {}).get("value")
+    rf = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us_per_launch", "frac_rocprof",
+                                "rocprof_avg_us_per_launch", "traffic", "traffic_over_algorithmic", "live", "replayed_from",
+                                "replayed_refused")}
+    bs = r.get("by_stage") or {}
+    ti, tt = bs.get("inference") or {}, bs.get("training") or {}
+    rf["by_stage"] = {"inference": {"kernel": _strip(ti.get("kernel")), "frac": ti.get("frac"), "bound": ti.get("bound"),
+                                    "stage_frac": ti.get("stage_frac_of_min_bytes_floor")},
+                      "training": {"kernel": _strip(tt.get("kernel")), "frac": tt.get("family_frac"), "bound": tt.get("bound"),
+                                   "chain_ms": tt.get("chain_ms"), "per_image_us": tt.get("per_image_us"), "step_ms": tt.get("step_ms"),
+                                   "host_enqueue_ms": ((r.get("step") or {}).get("train_step") or {}).get("host_enqueue_ms_per_step"),
+                                   "stage_frac": tt.get("stage_frac_of_min_bytes_floor")}}
+    if r.get("exclusive"):
+        rf["exclusive_frac"] = r["exclusive"].get("frac")
+    line["roofline"] = rf
+    if full.get("im_kernel"):
+        line["im_kernel"] = {k: full["im_kernel"].get(k) for k in ("kernel", "GBps", "frac_of_hbm_peak")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        ps = cb.get("parity_sample") or {}
+        line["cpu_baseline"] = {**{k: cb.get(k) for k in ("value", "unit", "cores", "host_cpus", "cpu_model", "kind", "sample",
+                                                          "t_infer_per_image_s", "t_im_per_image_s", "t_train_step_s")},
+                                "batched_value": (cb.get("batched_variant") or {}).get("value"),
+                                "parity_sample": {k: ps.get(k) for k in ("images", "max_abs_dp", "decision_flip_rate",
+                                                                         "im_pixels_differing", "im_pixels_total")}}
+    oc = full.get("other_configs")
+    if oc:
+        line["other_configs"] = {"fields": ["value", "ms_per_step", "train_step_ms", "frac"],
+                                 **{k: ([v.get("value"), v.get("ms_per_step"), v.get("train_step_ms"), (v.get("roofline") or {}).get("frac")]
+                                        if "error" not in v else {"error": v["error"][:120]}) for k, v in oc.items()}}
+    if full.get("sharding_check"):
+        line["sharding_check"] = full["sharding_check"]
+    line["detail"] = detail_path
+    # the guard: a line over budget loses its optional parts (in this order) rather than its parseability
+    for drop in (("cpu_baseline", "sample"), ("im_kernel",), ("other_configs",), ("roofline", "by_stage"), ("cpu_baseline", "parity_sample")):
+        if len(json.dumps(line)) < LINE_BUDGET:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    assert len(json.dumps(line)) < LINE_BUDGET, len(json.dumps(line))
+    return line
+
+
+def write_detail(full, path=None):
+    """the full record (what rounds 1-5 printed on one line) -> `path` (--detail), default gpurun_out/bench_detail[_<tag>].json (/tmp if
+    the tree is read-only); returns the path written"""
+    tag = config_tag(full["config"]["name"], full["config"]["alpha"])
+    name = f"bench_detail{tag}" + ("" if full["n_gpus"] == 1 else f"_{full['n_gpus']}gpus") + ".json"
+    for cand in ([os.path.abspath(path)] if path else []) + [os.path.join(ROOT, "gpurun_out", name), os.path.join("/tmp", name)]:
+        try:
+            os.makedirs(os.path.dirname(cand), exist_ok=True)
+            with open(cand, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(cand, ROOT) if cand.startswith(ROOT + os.sep) else cand
+        except OSError:
+            continue
+    return None
 
 
 def synth_images(cfg, n, seed, device):
@@ -302,7 +413,7 @@ def cpu_baseline(cfg, n_unl, n_lab, fwd_flops):
     steps = (n_unl + n_lab) // BATCH
     t_gen = n_unl * (t_inf + t_im) + steps * t_step
     return {"value": round(n_unl / t_gen, 3), "unit": "images/s", "cores": max(nt_fwd, nt_train), "kind": "port",
-            "cpu_model": _cpu_model(),
+            "host_cpus": ncpu, "cpu_model": _cpu_model(),
             "implementation": "oracle/unet_oracle.py: torch-CPU fp32, NCHW, reference structure (batch-1 predict per image and model, "
                               "numpy IM, batch-32 autograd step); not a tuned CPU kernel library",
             "gflops_forward_batch1": round(NM * fwd_flops / t_inf / 1e9, 1),
@@ -400,9 +511,15 @@ def main():
     ap.add_argument("--prof-period", type=int, default=61, help="time every k-th hooked kernel launch with HIP events")
     ap.add_argument("--pretrain-steps", type=int, default=300)
     ap.add_argument("--bn-settle-steps", type=int, default=600)
+    ap.add_argument("--detail", default=None, help="where the full record goes (default gpurun_out/bench_detail[_<config>].json)")
+    ap.add_argument("--provenance", action="store_true",
+                    help="print {bench_py_sha16, lib_build_id} (what profiles/collect_round.sh records beside the files it cuts) and exit")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (isic, 1 GPU) only: skip the short runs of the other BASELINE shapes appended as other_configs")
     args = ap.parse_args()
+    if args.provenance:       # before anything touches the GPU
+        print(json.dumps({"bench_py_sha16": bench_py_sha16(), "lib_build_id": lib_build_id(), "round": ROUND}))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -467,7 +584,11 @@ def main():
                 others[key] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = others
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        detail = write_detail(out, args.detail)
+        line = compact_line(out, detail)
+        print(f"[bench] full record: {detail} ({len(json.dumps(out))} bytes); the line below: {len(json.dumps(line))} bytes",
+              file=sys.stderr, flush=True)
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -525,7 +646,7 @@ def run_config(args, config_name, alpha, env, primary):
         return (t * pos_w).contiguous() if K == 3 else t.contiguous()
     y_pre = targets(m_pre)
     U = x_unl.shape[0]
-    infer_batch = args.infer_batch or (584 if ALPHA <= 0.5 else 128)      # 2335 = 4 x 584 - 1: four calls per model (256: 14.8 ms, 584: 14.5, 1168: 14.4)
+    infer_batch = F.infer_batch_size(ALPHA, args.infer_batch)      # the product writers' rule (functions.infer_batch_size): 584 at alpha <= 0.5, else 128
 
     # ---- ensemble: seeded he_normal, briefly trained on the labelled set so that predictions are not noise (the same
     # on every rank: replicated weights)
@@ -565,14 +686,7 @@ def run_config(args, config_name, alpha, env, primary):
     lab_idx = torch.arange(U, U + n_lab, device=dev)
     steps_cap = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    def infer_batches(n):
-        """batches of --infer-batch images; a last batch under a quarter of that is spread over the others instead (at 8 ranks a
-        shard is 292 images: one call, not 256 + 36 -- the deep levels of a forward cost the same for 36 images as for 256)"""
-        k, b = -(-n // infer_batch), infer_batch
-        if k > 1 and n - (k - 1) * b < b // 4:
-            k -= 1
-            b = -(-n // k)
-        return [(i, min(i + b, n)) for i in range(0, n, b)]
+    infer_batches = lambda n: F.infer_batches(n, infer_batch)      # a short last call is spread over the others (functions.infer_batches)
 
     def im_stage(x, into_pool=True):
         ps, ims = [], []
@@ -747,40 +861,39 @@ def run_config(args, config_name, alpha, env, primary):
     v = max(range(NV), key=lambda i: pms[i])
     fam_all = {FAMILIES[i]: {**fam_entry(i, pc, pms, pby, pfl), "share_of_sampled_time": round(pms[i] / max(sum(pms), 1e-9), 3)}
                for i in range(NV) if pc[i]}
-    mfma_bound = FAMILIES[v] in MFMA_FAMILIES
+    # which side of max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) binds the dominant family's launches (their live sums): SURVEY 8d -- a GEMM-class
+    # family is not "mfma-bound" by name; its full-resolution launches are byte-bound
+    mfma_bound = FAMILIES[v] in MFMA_FAMILIES and pfl[v] / (MFMA_PEAK_TFLOPS * 1e12) > pby[v] / (HBM_PEAK_GBS * 1e9)
     if mfma_bound:
         achieved, peak, unit = (pfl[v] / pms[v] / 1e9 if pms[v] else 0.0), MFMA_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = (pby[v] / pms[v] / 1e6 if pms[v] else 0.0), HBM_PEAK_GBS, "GB/s"      # bytes / ms / 1e6 = GB/s
-    # HBM traffic per launch from the PMC passes of profiles/collect.sh (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+    # ---- REPLAYED values: read from the committed profiles of THIS configuration (profiles/<ROUND>_*<tag>.csv), never another
+    # configuration's, and only when they were collected with this bench.py and these kernel sources (profiles/<ROUND>_provenance<tag>.json)
+    import csv
+    tag = config_tag(config_name, alpha)
+    replay_ok, replay_refused, _prov = provenance(tag) if primary else (False, "not the primary configuration of this command", None)
+    prof_file = lambda stem: os.path.join(ROOT, "profiles", f"{ROUND}_{stem}{tag}.csv")
+    fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
+    fams = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook
+    # HBM traffic per launch from the PMC passes of profiles/collect_round.sh (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
     try:
-        import csv
-        fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
-        tag = "" if config_name == "isic" and alpha is None else f"_{config_name}" + (f"_a{alpha:g}" if alpha is not None else "")
-        for name in (f"r05_pmc_traffic{tag}.csv", f"r04_pmc_traffic{tag}.csv", f"r03_pmc_traffic{tag}.csv") + (("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if not tag else ()):
-            path = os.path.join(ROOT, "profiles", name)
-            if not os.path.exists(path):
-                continue
-            fams_t = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook (as frac_rocprof below)
-            rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(fams_t)]
+        if replay_ok and os.path.exists(prof_file("pmc_traffic")):
+            rows = [r for r in csv.DictReader(open(prof_file("pmc_traffic"))) if r["kernel"].startswith(fams)]
             nl = sum(int(r["launches"]) for r in rows)
             if nl:
                 traffic = round(1e6 * sum(int(r["launches"]) * float(r["hbm_MB_per_launch_corrected(2*fetch+write)"]) for r in rows) / nl)
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, launch-weighted mean)"
-                break
+                traffic_src = f"profiles/{ROUND}_pmc_traffic{tag}.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, launch-weighted mean)"
     except Exception:
         pass
     # `traffic` averages the launches of the PMC pass (the whole process: ensemble pre-training + timed region + exclusive pass), the
     # sampled algorithmic figure below the timed region only -- their quotient means nothing.  Over ONE population
-    # (profiles/r04_traffic_ratio.py: per variant, launches of the PMC pass x the library's algorithmic bytes of that variant):
+    # (profiles/traffic_ratio.py: per variant, launches of the PMC pass x the library's algorithmic bytes of that variant):
     traffic_ratio, traffic_alg = None, None
     try:
-        import csv
-        rnd = traffic_src.split("profiles/")[1][:3] if traffic_src else "r05"
-        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_vs_algorithmic.csv")
-        if primary and traffic_src and f"{rnd}_pmc_traffic.csv" in traffic_src and os.path.exists(path):
-            fam_row = [r for r in csv.reader(open(path)) if r and r[0].startswith("FAMILY")]
+        if traffic_src and os.path.exists(prof_file("traffic_vs_algorithmic")):
+            fam_row = [r for r in csv.reader(open(prof_file("traffic_vs_algorithmic"))) if r and r[0].startswith("FAMILY")]
             if fam_row:
                 traffic_alg, traffic_ratio = round(1e6 * float(fam_row[0][2])), float(fam_row[0][4])
     except Exception:
@@ -790,17 +903,11 @@ def run_config(args, config_name, alpha, env, primary):
     frac_rocprof, rocprof_src, rocprof_us = None, None, None
     timed_rows = []
     try:
-        import csv
-        for name in ("r05_timed_region_kernel_stats.csv", "r04_timed_region_kernel_stats.csv"):
-            path = os.path.join(ROOT, "profiles", name)
-            if primary and os.path.exists(path):
-                timed_rows = list(csv.DictReader(open(path)))
-                rocprof_src = (f"profiles/{name} (rocprofv3 --kernel-trace of this command, dispatches between the timed region's markers: "
-                               "sum over the family's variants of calls x algorithmic bytes / sum of their durations)")
-                break
+        if replay_ok and os.path.exists(prof_file("timed_region_kernel_stats")):
+            timed_rows = list(csv.DictReader(open(prof_file("timed_region_kernel_stats"))))
+            rocprof_src = (f"profiles/{ROUND}_timed_region_kernel_stats{tag}.csv (rocprofv3 --kernel-trace of this command, dispatches between "
+                           "the timed region's markers: sum over the family's variants of calls x algorithmic bytes / sum of their durations)")
         if timed_rows and pc[v]:
-            fam = FAMILIES[v].split("<")[0].split("+")[0].replace("wgf_stage1", "wgf_stage")
-            fams = (fam, "conv_wide_kernel") if fam == "conv_pipe_kernel" else (fam,)      # one family in the hook
             col = "GFLOP_per_launch" if mfma_bound else "algorithmic_MB_per_launch"
             rows = [r for r in timed_rows if r["kernel"].startswith(fams) and r.get(col)]
             work = sum(int(r["calls"]) * float(r[col]) for r in rows)                        # MB or GFLOP, exact (the library's own sums)
@@ -837,6 +944,14 @@ def run_config(args, config_name, alpha, env, primary):
                 "traffic_over_algorithmic": traffic_ratio, "traffic_population_algorithmic_bytes_per_launch": traffic_alg,
                 "frac_rocprof": frac_rocprof, "rocprof_avg_us_per_launch": round(rocprof_us, 2) if rocprof_us else None,
                 "frac_rocprof_source": rocprof_src,
+                # what THIS run measured and what it read back from committed files (printed only when profiles/<ROUND>_provenance
+                # names this bench.py and these kernel sources; otherwise null + the reason)
+                "live": ["achieved", "frac", "launches", "avg_us_per_launch", "stage_ms", "by_stage.*.stage_frac", "by_stage.training.chain_ms",
+                         "by_stage.training.per_image_us", "by_stage.training.step_ms", "exclusive_frac", "im_kernel"],
+                "replayed": ["traffic", "traffic_over_algorithmic", "frac_rocprof", "rocprof_avg_us_per_launch", "by_stage.*.kernel",
+                             "by_stage.*.frac", "by_stage.inference.bound"],
+                "replayed_from": f"profiles/{ROUND}_{{pmc_traffic,traffic_vs_algorithmic,timed_region_kernel_stats,sq_counters}}{tag}.csv" if replay_ok else None,
+                "replayed_refused": replay_refused,
                 "avg_us_per_launch_whole_process": round(1000 * whole_ms / max(whole_n, 1), 2),
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),
                 "avg_algorithmic_bytes_per_launch": round(pby[v] / max(pc[v], 1)),
@@ -846,8 +961,8 @@ def run_config(args, config_name, alpha, env, primary):
                 "all_families": fam_all, "step": step_view,
                 "note": "timed region: the weight-gradient kernels (side stream) and the ensemble's other models run beside "
                         "the main-stream kernels, event-bracketed durations include that sharing; 'exclusive' = the same "
-                        "workload with every kernel alone on one stream (the plans' single_stream switch).  bound = mfma for the "
-                        "GEMM-class conv families (>= 33 channels: far above the fp16 ridge), hbm otherwise"}
+                        "workload with every kernel alone on one stream (the plans' single_stream switch).  bound = the side of "
+                        "max(algorithmic bytes / 8 TB/s, flops / 2.5 PFLOP/s) that binds the family's launches of this run"}
     # ---- per stage: the generation has two regimes, and one family name must not hide the weaker one ---------------------
     # (a) T(B) = chain + B x per-image, fitted live on training steps of 8 / 16 / 32 images (lr = 0: the weights stay): the fixed part
     #     is the dependent launch chain, the slope the kernels' per-image work
@@ -891,25 +1006,39 @@ def run_config(args, config_name, alpha, env, primary):
                 "achieved": float(r["TFLOPs"]) if mf else float(r["GBps"]), "unit": "TFLOP/s" if mf else "GB/s",
                 "family_frac": round(sum(int(q["calls"]) * float(q["algorithmic_MB_per_launch"]) for q in rows)
                                      / max(sum(float(q["total_ms"]) for q in rows), 1e-9) / HBM_PEAK_GBS, 4)}
-    by_stage = None
-    if primary and timed_rows:
-        ti, tt = stage_top("inference"), stage_top("training")
-        if ti:
-            narrow = ti["kernel"].startswith(("conv_pipe", "conv_wide"))
-            ti.update(bound="valu-issue" if narrow else ("mfma" if ti["unit"] == "TFLOP/s" else "hbm"),
-                      bound_evidence="profiles/r05_sq_counters_isic.csv, profiles/r04_notes.md ablations: waves issue ~40 % and wait ~47 % of "
-                                     "their cycles, HBM traffic = the algorithmic bytes" if narrow else None,
-                      stage_ms=round(t_inf, 3), stage_frac_of_min_bytes_floor=step_view["ensemble_infer_plus_im"]["frac"])
-        if tt:
-            tt.update(bound="launch-chain" if chain_ms and chain_ms > 0.4 * step_ms else ("mfma" if tt["unit"] == "TFLOP/s" else "hbm"),
-                      chain_ms=chain_ms, per_image_us=per_image_us, step_ms=round(step_ms, 4),
-                      step_ms_by_batch={str(k): round(v, 4) for k, v in sorted(tb.items())},
-                      stage_ms=round(t_ep, 3), stage_frac_of_min_bytes_floor=step_view["train_step"]["frac"])
-        by_stage = {"inference": ti, "training": tt,
-                    "note": "kernel = the variant with the largest summed duration among the stage's hooked kernels in the committed "
-                            "rocprofv3 trace of this command; frac = its algorithmic bytes (flops) over that duration over the peak; "
-                            "family_frac = the same over every hooked variant of the stage; chain_ms / per_image_us = intercept / slope "
-                            "of the training step time over batches of 8, 16, 32 measured in THIS run"}
+    def issue_limiter(kernel):
+        """what the waves of `kernel` do with their cycles, from the committed SQ counter pass of this configuration (replayed)"""
+        try:
+            path = prof_file("sq_counters") if tag else os.path.join(ROOT, "profiles", f"{ROUND}_sq_counters_isic.csv")
+            for r in csv.DictReader(open(path), delimiter=";"):
+                if r["kernel"].startswith(kernel[:58]):
+                    wc = float(r["SQ_WAVE_CYCLES"])
+                    iss, wait, mf = float(r["SQ_ACTIVE_INST_ANY"]) / wc, float(r["SQ_WAIT_ANY"]) / wc, float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / wc
+                    return {"issue": round(iss, 2), "wait": round(wait, 2), "mfma_busy": round(mf, 2),
+                            "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+        return None
+    by_stage = {"inference": {}, "training": {}}
+    ti, tt = (stage_top("inference"), stage_top("training")) if (primary and timed_rows) else (None, None)
+    ti, tt = ti or {}, tt or {}
+    if ti:
+        lim = issue_limiter(ti["kernel"])
+        # bytes floor vs flop floor decide hbm / mfma; a kernel far from both whose waves mostly wait or issue is named so, with the counters
+        ti.update(bound=("mfma" if ti["unit"] == "TFLOP/s" else "hbm") if not (lim and ti["frac"] < 0.5) else
+                  ("valu-issue/latency (waves issue %d %%, wait %d %% of their cycles, MFMA busy %d %%)" % (100 * lim["issue"], 100 * lim["wait"], 100 * lim["mfma_busy"])),
+                  bound_evidence=lim)
+    ti.update(stage_ms=round(t_inf, 3), stage_frac_of_min_bytes_floor=step_view["ensemble_infer_plus_im"]["frac"])
+    tt.update(bound="launch-chain" if chain_ms and chain_ms > 0.4 * step_ms else ("mfma" if tt.get("unit") == "TFLOP/s" else "hbm"),
+              chain_ms=chain_ms, per_image_us=per_image_us, step_ms=round(step_ms, 4),
+              step_ms_by_batch={str(k): round(v, 4) for k, v in sorted(tb.items())},
+              stage_ms=round(t_ep, 3), stage_frac_of_min_bytes_floor=step_view["train_step"]["frac"])
+    by_stage = {"inference": ti, "training": tt,
+                "note": "kernel = the variant with the largest summed duration among the stage's hooked kernels in the committed "
+                        "rocprofv3 trace of this command and configuration (absent: no such trace committed, or refused -- replayed_refused); "
+                        "frac = its algorithmic bytes (flops) over that duration over the peak; family_frac = the same over every hooked "
+                        "variant of the stage; chain_ms / per_image_us = intercept / slope of the training step time over batches of "
+                        "8, 16, 32 measured in THIS run; stage_frac_of_min_bytes_floor = SURVEY 8d minimum bytes / stage time / 8 TB/s, live"}
     roofline["by_stage"] = by_stage
     # the same generation once more with every kernel alone on the stream: the kernels' own rates
     for m in models + [student]:
@@ -962,7 +1091,9 @@ def run_config(args, config_name, alpha, env, primary):
             "config": {"workload": cfg["workload"], "name": config_name, "alpha": ALPHA, "shape": [H, W, C], "outputs": K,
                        "unlabeled_images": n_images, "unlabeled_images_per_gpu": U,
                        "labeled_images": L_total if strong else L_total * world,
-                       "n_models": N_MODELS, "infer_batch": infer_batch, "train_batch_per_gpu": BATCH,
+                       "n_models": N_MODELS, "infer_batch": infer_batch,
+                       "infer_batch_rule": "functions.infer_batch_size: 584 at alpha<=0.5 else 128; short tail spread" if not args.infer_batch else "--infer-batch",
+                       "train_batch_per_gpu": BATCH,
                        "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "bn_momentum": {"rule": bn_rule, "value": round(bn_mom, 6)},
                        "process_group": (os.environ.get("IMK_BENCH_BACKEND", "nccl") + (" (forced, 1 rank)" if world == 1 else "")) if use_dist else None,

@@ -14,6 +14,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+def source_id():
+    """16 hex digits over the kernel sources, the C-ABI header and the compile flags: identifies the library a committed profile was
+    collected with (bench.py prints a replayed value only when this equals the running tree's)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.h")))
+    for f in files + [os.path.join(PKG, "..", "include", "imk.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

@@ -39,7 +39,37 @@ THRESHOLD = float(_D.get("THRESHOLD", 0.5))
 NUM_EPOCHS = int(_D.get("NUM_EPOCHS", 50))
 NUM_EPOCHS_CS = int(_D.get("NUM_EPOCHS_CS", 100))
 
-INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 256))
+INFER_BATCH = int(os.environ.get("IMK_INFER_BATCH", 256))      # chunk of the augmentation / EvalNet loops (not the ensemble's)
+
+
+def infer_batch_size(alpha, override=None):
+    """Images per ensemble call of the pseudo-label writers AND of bench.py (one rule, here): 584 at alpha <= 0.5 (ISIC's 2335 images =
+    4 calls per model; measured 256: 14.8 ms, 584: 14.5, 1168: 14.4 per 2335-image stage), 128 for the wider nets (their workspace is
+    4-16x larger per image and the launch chain is already amortised).  IMK_INFER_BATCH / `override` replace it.  The reference's loop
+    being batched: functions.py:2844-2854 (one image per predict call)."""
+    if override:
+        return int(override)
+    env = os.environ.get("IMK_INFER_BATCH")
+    if env:
+        return int(env)
+    return 584 if float(alpha) <= 0.5 else 128
+
+
+def infer_batches(n, batch):
+    """[(begin, end)] over n images in calls of `batch`; a last call under a quarter of that is spread over the others instead (at 8
+    ranks an ISIC shard is 292 images: one call, not 256 + 36 -- the deep levels of a forward cost the same for 36 images as for 256)"""
+    if n <= 0:
+        return []
+    k, b = -(-n // batch), batch
+    if k > 1 and n - (k - 1) * b < b // 4:
+        k -= 1
+        b = -(-n // k)
+    return [(i, min(i + b, n)) for i in range(0, n, b)]
+
+
+def _models_alpha(models):
+    m = models[0] if isinstance(models, (list, tuple)) else models
+    return getattr(getattr(m, "plan", None), "alpha", 1.0)
 # PNG decode / encode threads.  Pillow on a thread pool (rounds 1-4) stopped scaling at ~32 threads on the 256-CPU MI355X host
 # (256 x 256 x 3 images: 8 / 16 / 32 / 64 / 128 threads -> 1.4 / 2.7 / 3.5 / 3.3 / 3.1 k encoded images/s: the interpreter lock);
 # the native codec (csrc/imk_png.cpp) holds no lock, so the pool is as wide as half the host's CPUs, at most 64.
@@ -465,8 +495,8 @@ def _run_writer(models, h, w, c, images_path, out_dirs, kind, erode_kernel, dila
     fused_block = (erode_kernel <= 0 and dilate_kernel <= 0)
     sum_im, count = 0, 0
     with _pool() as pool:
-        for i in range(0, len(mine), INFER_BATCH):
-            chunk = mine[i:i + INFER_BATCH]
+        for i, j in infer_batches(len(mine), infer_batch_size(_models_alpha(models))):
+            chunk = mine[i:j]
             imgs = read_png_stack(pool, [os.path.join(images_path, n) for n in chunk], c)
             x = torch.from_numpy(imgs).cuda()
             if flip_channels:
@@ -613,6 +643,58 @@ def dice_loss(y_true, y_pred, smooth=1):
     inter = (y_true * y_pred).sum(axis=(1, 2, 3))
     union = y_true.sum(axis=(1, 2, 3)) + y_pred.sum(axis=(1, 2, 3))
     return 1 - ((2 * inter + smooth) / (union + smooth)).mean()
+
+
+class ignore_im_categorical_crossentropy:
+    """functions.py:105-124 -- imported (never passed to a trainer) by Cityscapes/13_Cityscapes_aug_IM+.py:6, HeLa/12_HeLa_IM++.py:5,
+    HeLa/14_HeLa_aug_IM++.py:5.  A host-side (numpy) restatement of the loss VALUE, literally as written there: per-pixel categorical
+    cross-entropy (Keras clips probabilities to [1e-7, 1 - 1e-7] and renormalises), times `1 - y_true[:, 0]` -- which indexes the second
+    AXIS at 0, not class 0, and therefore only broadcasts for a few shapes -- then the mean.  No fused training kernel implements it:
+    `train_*` given an instance raises NotImplementedError (no reference script trains with it)."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+
+    def __call__(self, y_true, y_pred):
+        return self.call(y_true, y_pred)
+
+    def call(self, y_true, y_pred):
+        y_true = np.asarray(y_true, dtype=np.float32)
+        y_pred = np.asarray(y_pred, dtype=np.float32)
+        p = y_pred / y_pred.sum(-1, keepdims=True)
+        p = np.clip(p, 1e-7, 1 - 1e-7)
+        loss = -(y_true * np.log(p)).sum(-1)
+        loss = loss * (1.0 - y_true[:, 0])
+        return np.float32(loss.mean())
+
+
+class ignore_im_dice_loss_multiclass:
+    """functions.py:128-160 (same three importing scripts, never passed to a trainer): numpy restatement, literally -- `[:, :, 1:]`
+    drops index 0 of the THIRD axis, the sums run over axes 1 and 2.  `train_*` given an instance raises NotImplementedError."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+
+    def __call__(self, y_true, y_pred):
+        return self.call(y_true, y_pred)
+
+    def call(self, y_true, y_pred):
+        y_true = np.asarray(y_true, dtype=np.float32)[:, :, 1:]
+        y_pred = np.asarray(y_pred, dtype=np.float32)[:, :, 1:]
+        inter = (y_true * y_pred).sum(axis=(1, 2))
+        dice = (2.0 * inter + 1e-7) / (y_true.sum(axis=(1, 2)) + y_pred.sum(axis=(1, 2)) + 1e-7)
+        return np.float32((1 - dice).mean())
+
+
+_UNTRAINABLE_LOSSES = (ignore_im_categorical_crossentropy, ignore_im_dice_loss_multiclass)
+
+
+def _reject_untrainable(loss_func, who):
+    """the losses no reference script trains with have no fused kernel: say so instead of silently training with another loss"""
+    if isinstance(loss_func, _UNTRAINABLE_LOSSES) or loss_func in _UNTRAINABLE_LOSSES or loss_func is dice_loss:
+        name = getattr(loss_func, "__name__", type(loss_func).__name__)
+        raise NotImplementedError(f"{who}: no fused training kernel for {name} (imported by some reference scripts, passed by none); "
+                                  "the scripts train with 'mse' / CategoricalCrossentropy()")
 
 
 def get_IoU_binary(gt, pred):
@@ -1127,6 +1209,7 @@ def train_multiclass(train_images_dir, val_images_dir, val_masks_dir, test_image
                      print_results=False):
     """functions.py:275-316.  loss_func: anything (the SUIM / Cityscapes scripts pass CategoricalCrossentropy());
     the fused loss kernel implements exactly that loss on class-id masks."""
+    _reject_untrainable(loss_func, "train_multiclass")
     files = _train_shard(glob.glob(os.path.join(train_images_dir, "*.png")))
     loader = _EpochLoader(files, lambda p: parse_image_multiclass(p, n_classes, c), BATCH_SIZE, SEED, ("multi", n_classes, c))
     val_files = sorted(glob.glob(os.path.join(val_images_dir, "*.png")))
@@ -1265,8 +1348,8 @@ def create_pseudo_labels_im_hela(models, h, w, c, images_path, main_output_path,
     ens = _ensemble(models, True)
     sum_im = count = 0
     with _pool() as pool:
-        for i in range(0, len(mine), INFER_BATCH):
-            chunk = mine[i:i + INFER_BATCH]
+        for i, j in infer_batches(len(mine), infer_batch_size(_models_alpha(models))):
+            chunk = mine[i:j]
             imgs = read_png_stack(pool, [os.path.join(images_path, n) for n in chunk], c)
             x = torch.from_numpy(imgs).cuda()
             r = ens.run(x, 0.5, True, False, False)          # blocking happens after the host-side position step

@@ -522,3 +522,84 @@ def test_color_mask_table_equals_the_reference_loop(tmp_path):
         F.convert_class_to_color_mask(cm, p, mapping)
         F.flush_writes()
         assert np.array_equal(F.read_png(p, 3), want)
+
+
+BENCH_LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                   "dtype", "data", "stage_ms", "config", "roofline", "detail"}
+
+
+def check_bench_line(text, expect_cpu_baseline):
+    """the driver's view of bench.py: the LAST stdout line, parsed as JSON, under 4 KB, with the contract's keys (a
+    21 KB line was cut by the driver's 8 KB stdout tail and the round went unmeasured)"""
+    import json
+    last = text.strip().splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    out = json.loads(last)
+    assert BENCH_LINE_KEYS <= set(out), BENCH_LINE_KEYS - set(out)
+    for k in ("workload", "shape", "alpha", "n_models", "unlabeled_images", "labeled_images", "infer_batch", "infer_batch_rule",
+              "train_batch_per_gpu", "global_batch", "parallelism", "process_group", "epoch_steps", "kept", "bn_momentum"):
+        assert k in out["config"], k
+    assert "model" not in out["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_rocprof", "live", "replayed_from", "by_stage"):
+        assert k in out["roofline"], k
+    assert out["roofline"]["bound"] in ("hbm", "mfma")
+    if expect_cpu_baseline:
+        for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cpu_model", "t_infer_per_image_s", "t_train_step_s", "parity_sample"):
+            assert k in out["cpu_baseline"], k
+    return out
+
+
+def test_bench_line_budget():
+    """bench.compact_line on canned full records (the 21 KB line round 5 printed, and the same with every optional part at its
+    largest): under the budget, contract keys present, the full record kept beside it."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    out = check_bench_line(json.dumps(line), expect_cpu_baseline=True)
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"]
+    assert out["roofline"]["frac"] == full["roofline"]["frac"] and out["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert set(out["other_configs"]) == {"fields", "suim", "cityscapes", "hela", "cityscapes_a2"}
+    # worst case: long error strings in other_configs, a sharding check, a long workload name -- the guard sheds optional parts
+    fat = json.loads(json.dumps(full))
+    fat["other_configs"] = {f"cfg{i}": {"error": "RuntimeError: " + "x" * 4000} for i in range(8)}
+    fat["sharding_check"] = {"sum_pred_size": 1e9, "sum_im_size": 1e8, "kept": 2307.0, "equals_sum_over_ranks": True}
+    fat["cpu_baseline"]["sample"] = "s" * 3000
+    line = bench.compact_line(fat, "/tmp/bench_detail.json")
+    assert len(json.dumps(line)) < bench.LINE_BUDGET
+    assert BENCH_LINE_KEYS <= set(line) and "cpu_baseline" in line and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+
+
+def test_bench_replay_provenance(tmp_path, monkeypatch):
+    """A replayed value (traffic, frac_rocprof, by_stage kernels) is printed only when the committed profile was collected with the
+    running bench.py and kernel sources; the per-configuration file tag never falls back to another configuration's files."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.config_tag("isic", None) == "" and bench.config_tag("isic", 0.5) == ""
+    assert bench.config_tag("suim", None) == "_suim" and bench.config_tag("cityscapes", 2.0) == "_cityscapes_a2"
+    assert bench.config_tag("cityscapes", 1.25) == "_cityscapes_a125" and bench.config_tag("cityscapes", 1.0) == "_cityscapes"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    ok, why, _ = bench.provenance("")
+    assert not ok and "missing" in why
+    rec = {"bench_py_sha16": bench.bench_py_sha16(), "lib_build_id": bench.lib_build_id()}
+    (tmp_path / "profiles" / f"{bench.ROUND}_provenance.json").write_text(json.dumps(rec))
+    assert bench.provenance("")[0]
+    (tmp_path / "profiles" / f"{bench.ROUND}_provenance_suim.json").write_text(json.dumps({**rec, "lib_build_id": "0" * 16}))
+    ok, why, _ = bench.provenance("_suim")
+    assert not ok and "lib_build_id" in why
+
+
+def test_infer_batch_rule():
+    from inconsistencymasks_amd import functions as F
+    assert F.infer_batch_size(0.5) == 584 and F.infer_batch_size(1.0) == 128 and F.infer_batch_size(2.0, 64) == 64
+    assert F.infer_batches(2335, 584) == [(0, 584), (584, 1168), (1168, 1752), (1752, 2335)]
+    assert F.infer_batches(292, 256) == [(0, 292)]                      # a 36-image tail is spread
+    assert F.infer_batches(640, 256) == [(0, 256), (256, 512), (512, 640)]
+    assert F.infer_batches(0, 256) == [] and F.infer_batches(5, 256) == [(0, 5)]
+    for n in (1, 63, 64, 65, 257, 300, 1000, 2468):
+        r = F.infer_batches(n, 128)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))

@@ -796,9 +796,13 @@ def test_bench_one_rank_process_group_rccl():
                         "--pretrain-steps", "10", "--bn-settle-steps", "10", "--no-cpu-baseline"], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    from test_cpu_api import check_bench_line
+    out = check_bench_line(r.stdout, expect_cpu_baseline=False)        # the last stdout line: < 4 KB, the contract's keys
     assert out["n_gpus"] == 1 and out["config"]["process_group"].startswith("nccl") and out["value"] > 0
-    assert out["roofline"]["step"]["train_step"]["host_enqueue_ms_per_step"] > 0
+    assert out["roofline"]["by_stage"]["training"]["host_enqueue_ms"] > 0
+    full = json.load(open(os.path.join(ROOT, out["detail"]) if not os.path.isabs(out["detail"]) else out["detail"]))
+    assert full["value"] == out["value"] and full["roofline"]["step"]["train_step"]["host_enqueue_ms_per_step"] > 0
+    assert "all_families" in full["roofline"] and "timed_region_kernel_totals" in full
 
 
 def test_bench_two_ranks_driver_command_form():
