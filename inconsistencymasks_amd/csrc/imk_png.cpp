@@ -23,6 +23,7 @@
 #include <cstring>
 #include <climits>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/imk.h"
@@ -72,6 +73,9 @@ int parse_header(const uint8_t *p, size_t n, Header &hd) {
     hd.w = (int)be32(p + 16); hd.h = (int)be32(p + 20);
     hd.depth = p[24]; hd.ctype = p[25]; hd.interlace = p[28];
     if (hd.w <= 0 || hd.h <= 0 || p[26] != 0 || p[27] != 0) return IMK_EINVAL;
+    // CRC-32 over type + data: a damaged header is an error here as it is in Pillow (the decoder this one replaces), not a silently
+    // different image size; IDAT is covered by zlib's adler32, PLTE by its own CRC below
+    if (be32(p + 29) != (uint32_t)crc32(crc32(0L, Z_NULL, 0), p + 12, 17)) return IMK_EINVAL;
     return IMK_OK;
 }
 
@@ -134,6 +138,7 @@ IMK_API int imk_png_decode(const uint8_t *data_in, int64_t len, int want_c, uint
         if (!memcmp(type, "IDAT", 4)) z.insert(z.end(), data, data + n);
         else if (!memcmp(type, "PLTE", 4)) {
             if (n % 3 || n > 768) return IMK_EINVAL;
+            if (be32(data + n) != (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, n + 4)) return IMK_EINVAL;      // a damaged palette recolours the image
             memcpy(pal, data, n);
             have_pal = true;
         } else if (!memcmp(type, "IEND", 4)) break;
@@ -259,11 +264,15 @@ IMK_API int imk_png_write_file(const char *path, const uint8_t *pixels, int h, i
     int64_t n = 0;
     const int rc = imk_png_encode(pixels, h, w, c, level, buf.data(), cap, &n);
     if (rc) return rc;
-    FILE *f = fopen(path, "wb");
+    // written beside the target and renamed into place: an interrupted or failed write leaves no truncated .png for the
+    // listdir-driven stages that follow (the temporary name does not end in .png)
+    std::string tmp = std::string(path) + ".imk-tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return IMK_EINVAL;
     const size_t put = fwrite(buf.data(), 1, (size_t)n, f);
     const int cl = fclose(f);
-    return (put == (size_t)n && cl == 0) ? IMK_OK : IMK_EINVAL;
+    if (put != (size_t)n || cl != 0 || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return IMK_EINVAL; }
+    return IMK_OK;
     )
 }
 

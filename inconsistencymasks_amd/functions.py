@@ -79,7 +79,26 @@ _IO_THREADS = int(os.environ.get("IMK_IO_THREADS", min(64, max(4, (os.cpu_count(
 # ---------------------------------------------------------------------------------------------------
 # distributed helpers
 # ---------------------------------------------------------------------------------------------------
+_LOCAL = __import__("threading").local()
+
+
+class local_rank_scope:
+    """Inside this block (on the entering THREAD) the package behaves as a one-rank run although a process group exists: file lists
+    are not sharded, no gradient all-reduce, no barrier, evaluations see every file.  im_driver's IM_DP_MODE=candidates trains whole
+    candidates per rank this way (independent models, no collective; ISIC_2018/09_ISIC_2018_IM.py:90)."""
+
+    def __enter__(self):
+        _LOCAL.depth = getattr(_LOCAL, "depth", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _LOCAL.depth -= 1
+        return False
+
+
 def _dist():
+    if getattr(_LOCAL, "depth", 0):
+        return None
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
@@ -163,7 +182,7 @@ def read_png_stack(pool, paths, channels):
     first = read_png(paths[0], channels)
     out = np.empty((len(paths),) + first.shape, np.uint8)
     out[0] = first
-    pool.map(lambda i: _read_png_into(paths[i], channels, out[i]), range(1, len(paths)))
+    list(pool.map(lambda i: _read_png_into(paths[i], channels, out[i]), range(1, len(paths))))      # consumed: a plain executor's map is lazy
     return out
 
 
@@ -203,10 +222,18 @@ class _ReaderPool:
     def __exit__(self, *exc):
         return False
 
+    @staticmethod
+    def _not_from_a_reader():
+        # a task that waits for the pool it runs on can starve it (every thread waiting for a queued task): refuse instead of hanging
+        assert not __import__("threading").current_thread().name.startswith("imk-read"), \
+            "the reader pool was used from one of its own tasks"
+
     def submit(self, fn, *args, **kw):
+        self._not_from_a_reader()
         return self._executor().submit(fn, *args, **kw)
 
     def map(self, fn, items):
+        self._not_from_a_reader()
         items = list(items)
         ex = self._executor()
         if len(items) <= 4 * _IO_THREADS:
@@ -233,11 +260,24 @@ _PENDING = {}                                       # thread id -> futures that 
 _PENDING_LOCK = __import__("threading").Lock()      # candidates training on threads (im_driver) queue writes concurrently
 
 
+_MAX_PENDING_WRITES = int(os.environ.get("IMK_MAX_PENDING_WRITES", 512))      # tasks (8 files each from write_pngs_async) per calling thread
+
+
 def _submit_write(job):
-    """queue `job()` (a PNG write, possibly with its last host-side preparation) on the writer pool, on the calling thread's account"""
+    """queue `job()` (a PNG write, possibly with its last host-side preparation) on the writer pool, on the calling thread's account.
+    Back-pressure: every queued task pins its arrays, so a thread with more than IMK_MAX_PENDING_WRITES tasks outstanding waits for
+    its OLDEST half before it queues more (re-raising a failed write) -- the host backlog stays bounded when the GPU stages outrun the
+    encoders on large images or sets."""
+    me = __import__("threading").get_ident()
     with _PENDING_LOCK:
         _ensure_write_pool()
-        _PENDING.setdefault(__import__("threading").get_ident(), []).append(_WRITE_POOL.submit(job))
+        mine = _PENDING.setdefault(me, [])
+        mine.append(_WRITE_POOL.submit(job))
+        oldest = []
+        if len(mine) > _MAX_PENDING_WRITES:
+            oldest, _PENDING[me] = mine[:len(mine) // 2], mine[len(mine) // 2:]
+    for f in oldest:
+        f.result()
 
 
 def write_png_async(path, arr):
@@ -792,11 +832,11 @@ class _EpochLoader:
     def _load(self):
         """decode the whole set once: every pool thread parses a slice of the files straight into its rows of two host arrays
         (no per-item list, no np.stack pass).  The candidates of a generation train on the same directory, so the device copy is
-        kept in the decode cache under (parse_key, names, sizes, newest mtime) and the next candidate starts without decoding."""
+        kept in the decode cache under (parse_key, names, hash of every file's size and mtime) and the next candidate starts without decoding."""
         key = None
         if self.parse_key is not None and self.files:
             st = [os.stat(f) for f in self.files]
-            key = ("train", self.parse_key, tuple(self.files), sum(x.st_size for x in st), max(x.st_mtime_ns for x in st))
+            key = ("train", self.parse_key, tuple(self.files), _stat_sig(st))
         with _CACHE_LOCK:
             hit = _DECODE_CACHE.get(key) if key is not None else None
             if hit is not None:
@@ -1004,11 +1044,22 @@ def _decode_cache_put(key, tensors):
         _DECODE_CACHE[key] = tensors
 
 
+def _stat_sig(stats):
+    """one hash over EVERY file's (size, mtime_ns): a same-sized file replaced by an older one changes it (a sum of sizes + newest
+    mtime did not)"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for x in stats:
+        h.update(x.st_size.to_bytes(8, "little", signed=False))
+        h.update(x.st_mtime_ns.to_bytes(8, "little", signed=True))
+    return h.hexdigest()
+
+
 def _decoded_set(pool, dirs_and_channels, names):
     """[(directory, channels)] x names -> list of uint8 device tensors [N,H,W,C] (one per directory), cached"""
     def sig(d):
         st = [os.stat(os.path.join(d, n)) for n in names]
-        return (d, tuple(names), sum(x.st_size for x in st), max((x.st_mtime_ns for x in st), default=0))
+        return (d, tuple(names), _stat_sig(st))
     key = tuple((sig(d), c) for d, c in dirs_and_channels)
     with _CACHE_LOCK:       # (candidates on threads: one decodes, the others wait for it instead of decoding the same files again)
         hit = _DECODE_CACHE.get(key)
@@ -1316,9 +1367,12 @@ def mod_pos_size(gray_img, max_pos_circle_size=8, min_pos_circle_size=3):
 
 
 def get_cell_count(positions, img_alive, img_dead, measuring_range=3):
-    """functions.py:6298-6371.  Host C++ (imk_cell_count)."""
-    a = np.ascontiguousarray(img_alive, dtype=np.uint8)
-    d = np.ascontiguousarray(img_dead, dtype=np.uint8)
+    """functions.py:6298-6371.  Host C++ (imk_cell_count) on one grey plane per image: [h, w], [h, w, 1] or BGR [h, w, 3] (converted as
+    the reference does, functions.py:6321-6338).  A position whose clamped window (functions.py:6346-6356) still leaves the image --
+    where the reference's slices would wrap or come out empty -- is IMK_EINVAL here, as is an image smaller than the window."""
+    a, d = _u8_plane(img_alive), _u8_plane(img_dead)
+    if a.shape != d.shape:
+        raise ValueError(f"get_cell_count: alive {a.shape} and dead {d.shape} masks differ in size")
     xy = np.ascontiguousarray(np.asarray(positions, np.int32).reshape(-1, 2))
     counts = np.zeros(3, np.int32)
     check(lib.imk_cell_count(xy.ctypes.data, xy.shape[0], a.ctypes.data, d.ctypes.data, a.shape[0], a.shape[1],

@@ -124,6 +124,26 @@ def _candidate_streams(n):
 PARALLEL_CANDIDATES_DEFAULT = 3
 
 
+def dp_mode():
+    """How several ranks train a generation's candidates (IM_DP_MODE):
+      'gradient'   (default, the north star's path): every candidate data-parallel over all ranks -- per-GPU batch 32, one flat gradient
+                   all-reduce per step, epoch steps = images // (32 N).  Fastest per candidate; the optimisation recipe is no longer the
+                   reference's (global batch 32 N, N times fewer steps: profiles/r03_dp_convergence.txt).
+      'candidates' (SURVEY 8e row 3): candidate i trains WHOLE on rank i mod N with the reference's batch 32 and step count, no
+                   collective; the rows are gathered for ranking / rename / CSV.  Exactly the one-rank results (byte for byte), at most
+                   min(N, candidates) ranks busy during training.  Use it when the reference's recipe matters more than wall time."""
+    m = os.environ.get("IM_DP_MODE", "gradient").lower()
+    if m not in ("gradient", "candidates"):
+        raise ValueError(f"IM_DP_MODE={m!r}: expected 'gradient' or 'candidates'")
+    return m
+
+
+def epoch_steps(n_files, batch, world):
+    """steps_per_epoch of a candidate: files // batch on one rank and with whole candidates per rank (the reference's,
+    ISIC_2018/09_ISIC_2018_IM.py:87-88); files // (batch N) data-parallel"""
+    return max(n_files // batch // (1 if (world > 1 and dp_mode() == "candidates") else world), 1)
+
+
 def train_candidates(cands, train_candidate, world, tick=None, parallel=None):
     """rows of `train_candidate(i, side_by_side)` for i in cands, in that order.
 
@@ -133,40 +153,59 @@ def train_candidates(cands, train_candidate, world, tick=None, parallel=None):
     reach 1.58x the model-steps per second of one (tests/gpu_probe/concurrent_candidates.py) and a real ISIC generation of 5
     candidates x 50 epochs takes 17.9 s instead of 27.5 s (profiles/r05_notes.md).  Every candidate computes exactly what it computes
     alone: CSVs, checkpoints and prediction files equal the sequential run's byte for byte (tests/test_gpu_driver.py).
-    k = `parallel`, else IM_PARALLEL_CANDIDATES, else 3; 1 is the reference's order.  Several ranks: always 1 (collectives issued
-    from several threads would not line up across ranks)."""
+    k = `parallel`, else IM_PARALLEL_CANDIDATES, else PARALLEL_CANDIDATES_DEFAULT; 1 is the reference's order.
+    Several ranks, IM_DP_MODE=gradient: always 1 (collectives issued from several threads would not line up across ranks).
+    Several ranks, IM_DP_MODE=candidates: this rank trains the candidates at positions rank, rank + N, ... of `cands` inside
+    functions.local_rank_scope (k of them side by side as on one rank), then every rank receives all rows (all_gather_object)."""
     tick = tick or (lambda what: None)
     par = parallel if parallel is not None else int(os.environ.get("IM_PARALLEL_CANDIDATES", PARALLEL_CANDIDATES_DEFAULT))
-    if world > 1 or len(cands) < 2:
+    by_candidate = world > 1 and dp_mode() == "candidates"
+    rank = F._rank_world()[0]
+    mine = [i for pos, i in enumerate(cands) if pos % world == rank] if by_candidate else list(cands)
+    if (world > 1 and not by_candidate) or len(mine) < 2:
         par = 1
-    par = min(par, len(cands))
+    par = min(par, max(len(mine), 1))
+
+    def one(i, side_by_side):
+        if by_candidate:
+            with F.local_rank_scope():
+                return train_candidate(i, side_by_side)
+        return train_candidate(i, side_by_side)
+
     if par <= 1:
         rows = []
-        for i in cands:
-            rows.append(train_candidate(i, False))
+        for i in mine:
+            rows.append(one(i, False))
             tick(f"candidate {i}: training + 3 benchmarks")
-        return rows
-    import queue
-    from concurrent.futures import ThreadPoolExecutor
-    dev_index = torch.cuda.current_device()
-    free = queue.SimpleQueue()                    # a fixed set of streams, reused over candidates and generations;
-    for st in _candidate_streams(par):            # a worker holds one for the whole candidate
-        free.put(st)
-
-    def worker(i):
-        torch.cuda.set_device(dev_index)          # the current device is per thread
-        st = free.get()
-        try:
-            with torch.cuda.stream(st):
-                row = train_candidate(i, True)
-                st.synchronize()
-        finally:
+    else:
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        dev_index = torch.cuda.current_device()
+        free = queue.SimpleQueue()                    # a fixed set of streams, reused over candidates and generations;
+        for st in _candidate_streams(par):            # a worker holds one for the whole candidate
             free.put(st)
-        return row
-    with ThreadPoolExecutor(max_workers=par) as pool:
-        rows = list(pool.map(worker, cands))
-    F.flush_writes(all_threads=True)              # every candidate's prediction PNGs are on disk
-    tick(f"{len(cands)} candidates, {par} side by side: training + 3 benchmarks each")
+
+        def worker(i):
+            torch.cuda.set_device(dev_index)          # the current device is per thread
+            st = free.get()
+            try:
+                with torch.cuda.stream(st):
+                    row = one(i, True)
+                    st.synchronize()
+            finally:
+                free.put(st)
+            return row
+        with ThreadPoolExecutor(max_workers=par) as pool:
+            rows = list(pool.map(worker, mine))
+        F.flush_writes(all_threads=True)              # every candidate's prediction PNGs are on disk
+        tick(f"{len(mine)} candidates, {par} side by side: training + 3 benchmarks each")
+    if by_candidate:
+        F.flush_writes(all_threads=True)
+        got = [None] * world
+        torch.distributed.all_gather_object(got, list(zip(mine, rows)))      # also the barrier behind the checkpoints on disk
+        by_i = {i: row for part in got for i, row in part}
+        rows = [by_i[i] for i in cands]
+        tick(f"{len(cands)} candidates, one whole candidate per rank ({world} ranks): training + 3 benchmarks each")
     return rows
 
 
@@ -250,7 +289,7 @@ def run(dataset, approach="IM", parallel_candidates=None):
                 if torch.distributed.is_initialized():
                     torch.distributed.barrier()
                 train_dir = os.path.join(unl, "brightfield" if ds["kind"] == "hela" else "images")
-                steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+                steps = epoch_steps(len(os.listdir(train_dir)), batch, world)
 
                 def train_candidate(i, side_by_side=False):
                     name_i = f"{modelname}_{i}"
@@ -290,7 +329,7 @@ def run(dataset, approach="IM", parallel_candidates=None):
                         import json     # goes into a sidecar file
                         rule, mom = F.dp_bn_momentum_rule(world)
                         with open(os.path.join(csv_dir, f"results_{modelname}.meta.json"), "w", encoding="utf-8") as f:
-                            json.dump({"data_parallel_ranks": world, "batch_per_rank": batch, "bn_momentum_rule": rule,
+                            json.dump({"data_parallel_ranks": world, "dp_mode": dp_mode(), "batch_per_rank": batch, "bn_momentum_rule": rule,
                                        "bn_momentum": round(mom, 6), "env": "IMK_DP_BN_MOMENTUM"}, f)
                     with open(os.path.join(csv_dir, f"mean_im_size_{modelname}.csv"), "w", encoding="utf-8", newline="") as f:
                         wr = csv.writer(f, delimiter=";")

@@ -18,7 +18,7 @@ import torch
 from . import functions as F
 from . import paths
 from .evalnet import get_evalnet, get_evalnet_miou
-from .im_driver import DATASETS, _ints, color_mapping, train_candidates
+from .im_driver import DATASETS, _ints, color_mapping, epoch_steps, train_candidates
 from .unet import get_unet
 
 _HELA = dict(   # HeLa/14_HeLa_aug_IM++.py:53-57 (identical in 12_HeLa_IM++.py)
@@ -163,9 +163,9 @@ def run(dataset, aug=False, train_new_evalnet=True, gt=False):
                                     shutil.copy(os.path.join(src, sub, name), os.path.join(unl, sub, name))
                 barrier()
                 train_dir = os.path.join(unl, subs[0])
-                steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+                steps = epoch_steps(len(os.listdir(train_dir)), batch, world)
                 if gt:      # :126-132: never fewer steps than an epoch over the full training set
-                    steps = max(steps, len(os.listdir(P("TRAIN_FULL_IMAGES_DIR"))) // batch // world)
+                    steps = max(steps, epoch_steps(len(os.listdir(P("TRAIN_FULL_IMAGES_DIR"))), batch, world))
                 def train_candidate(i, side_by_side=False):
                     name_i = f"{modelname}_{i}"
                     h5 = os.path.join(model_dir, name_i + ".h5")

@@ -16,7 +16,7 @@ import torch
 
 from . import functions as F
 from . import paths
-from .im_driver import DATASETS, _ints, color_mapping, train_candidates
+from .im_driver import DATASETS, _ints, color_mapping, epoch_steps, train_candidates
 from .unet import get_unet
 
 # (index of the ranking value in the row, descending?) -- ISIC_2018/03_ISIC_2018_subset.py:82, SUIM/04_SUIM_subset.py:84,
@@ -63,7 +63,7 @@ def run(dataset, aug=False):
             torch.distributed.barrier()
     lab = "TRAIN_LABELED_AUG" if aug else "TRAIN_LABELED"
     train_dir = os.path.join(P(f"{lab}_DIR"), "brightfield") if ds["kind"] == "hela" else P(f"{lab}_IMAGES_DIR")
-    steps = max(len(os.listdir(train_dir)) // batch // world, 1)
+    steps = epoch_steps(len(os.listdir(train_dir)), batch, world)
     os.makedirs(model_dir, exist_ok=True)
     idx, desc = _RANK[ds["kind"]]
     for runid in _ints("IM_RUNIDS", [1, 2, 3]):

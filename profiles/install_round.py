@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""Copy the summaries profiles/collect_round.sh left under gpurun_out/<rNN>/ into profiles/ under their <rNN>_* names:
-    python profiles/install_round.py r05"""
+"""Copy the summaries profiles/collect_round.sh left under gpurun_out/<rNN>/cfg<tag>/ into profiles/ as <rNN>_<stem><tag>.*:
+    python profiles/install_round.py r06
+then profiles/traffic_ratio.py <rNN> for the default configuration's traffic / algorithmic table."""
 import glob
+import json
 import os
 import shutil
 import sys
 
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S = os.path.join(R, "gpurun_out", RND)
 P = os.path.join(R, "profiles")
 
 
+INSTALLED = []
+
+
 def cp(src, dst):
     src = os.path.join(S, src)
     if os.path.exists(src):
         shutil.copyfile(src, os.path.join(P, dst))
+        INSTALLED.append(dst)
         print("installed", dst)
 
 
@@ -29,18 +35,27 @@ def last_line(src, dst):
             print("installed", dst)
 
 
-last_line("bench.json", f"{RND}_bench.json")
-last_line("bench_traced.json", f"{RND}_bench_under_rocprof.json")
-cp("kernel_stats.csv", f"{RND}_bench_kernel_stats.csv")
-cp("pmc_traffic.csv", f"{RND}_pmc_traffic.csv")
-cp("timed_region_kernel_stats.csv", f"{RND}_timed_region_kernel_stats.csv")
-raw = glob.glob(os.path.join(S, "trace", "*", "*_kernel_stats.csv"))
-if raw:
-    shutil.copyfile(raw[0], os.path.join(P, f"{RND}_rocprofv3_kernel_stats_raw.csv"))
-for cfg in ("suim", "cityscapes", "hela", "cityscapes_a2"):
-    last_line(f"bench_{cfg}.json", f"{RND}_configs_bench_{cfg}.json")
-    cp(f"cfg_{cfg}/kernel_stats.csv", f"{RND}_configs_kernel_stats_{cfg}.csv")
-    cp(f"cfg_{cfg}/pmc_traffic.csv", f"{RND}_pmc_traffic_{cfg}.csv")
+for d in sorted(glob.glob(os.path.join(S, "cfg_*"))):
+    name = os.path.basename(d)[4:]
+    tag = "" if name == "isic" else "_" + name
+    sub = os.path.basename(d)
+    INSTALLED.clear()
+    last_line(f"{sub}/bench.json", f"{RND}_bench{tag}.json")
+    cp(f"{sub}/bench_detail.json", f"{RND}_bench_detail{tag}.json")
+    last_line(f"{sub}/bench_traced.json", f"{RND}_bench_under_rocprof{tag}.json")
+    cp(f"{sub}/kernel_stats.csv", f"{RND}_kernel_stats{tag}.csv")
+    cp(f"{sub}/timed_region_kernel_stats.csv", f"{RND}_timed_region_kernel_stats{tag}.csv")
+    cp(f"{sub}/excess_by_kernel.csv", f"{RND}_excess_by_kernel{tag}.csv")
+    cp(f"{sub}/pmc_traffic.csv", f"{RND}_pmc_traffic{tag}.csv")
+    # the provenance of a configuration's files counts only when its trace was actually cut
+    if os.path.exists(os.path.join(d, "timed_region_kernel_stats.csv")):
+        rec = json.load(open(os.path.join(d, "provenance.json")))
+        rec["files"] = sorted(INSTALLED)
+        json.dump(rec, open(os.path.join(P, f"{RND}_provenance{tag}.json"), "w"), indent=1)
+        print("installed", f"{RND}_provenance{tag}.json")
+    raw = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    if raw and not tag:
+        shutil.copyfile(raw[0], os.path.join(P, f"{RND}_rocprofv3_kernel_stats_raw.csv"))
 for f in sorted(glob.glob(os.path.join(S, "step_timeline_*.txt"))):
     shutil.copyfile(f, os.path.join(P, f"{RND}_" + os.path.basename(f)))
 for f in sorted(glob.glob(os.path.join(S, "sq_counters_*.csv"))):

@@ -5,6 +5,8 @@ per-dispatch CSVs are tens of MB and are deleted afterwards).
   pmc_traffic.csv       : per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch as reported (KB -> MB), and the
                           gfx950-corrected HBM bytes per launch (FETCH x 2 for wide coalesced reads + WRITE;
                           MI355X_MICROARCH.md, section HBM)
+  excess_by_kernel.csv (round 6): per (stage, variant) of the timed region: floor_us = max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) of one
+                          launch, the side that binds, excess_ms = calls x (avg_us - floor_us), sorted by excess
   timed_region_kernel_stats.csv (round 4): the dispatches BETWEEN bench.py's two marker kernels (imk_mark_kernel with 64 and
                           128 work-items: the timed region), per kernel variant: calls, average us from rocprofv3's own begin /
                           end timestamps, and -- joined from the bench line of the traced run (bench_traced.json:
@@ -118,9 +120,12 @@ def timed_region(out):
             agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     totals, stage_totals = {}, {}
     try:
-        line = [l for l in open(os.path.join(out, "bench_traced.json")).read().splitlines() if l.startswith("{")][-1]
-        totals = json.loads(line).get("timed_region_kernel_totals", {})
-        stage_totals = json.loads(line).get("stage_kernel_totals_per_generation", {})
+        # round 6: the full record of the traced run sits beside its (now compact) stdout line (bench.py --detail)
+        det = os.path.join(out, "bench_traced_detail.json")
+        rec = json.load(open(det)) if os.path.exists(det) else json.loads(
+            [l for l in open(os.path.join(out, "bench_traced.json")).read().splitlines() if l.startswith("{")][-1])
+        totals = rec.get("timed_region_kernel_totals", {})
+        stage_totals = rec.get("stage_kernel_totals_per_generation", {})
     except Exception:
         pass
     # the library sums some families under one name (wgf_stage1 + wgf_stage2, the step tail, the conv_mfma variants by tile): those
@@ -146,6 +151,30 @@ def timed_region(out):
                 extra = ["", "", "", "", "", ""]
             w.writerow([st, k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), round(100 * v[1] / max(tot_ns, 1), 2),
                         round(100 * v[1] / max(stage_ns[st], 1), 2)] + extra + [round((t1 - t0) / 1e6, 3)])
+    # Per variant: the floor of ONE launch = max(algorithmic bytes / 8 TB/s, flops / 2.5 PFLOP/s), which side binds, and the time the
+    # variant spends ABOVE that floor in the timed region (excess_ms = calls x (avg_us - floor_us)); sorted by excess: the rows at the
+    # top own the gap between the step and its roofline.  Kernels the library does not price (tiny per-channel reductions, the step
+    # tail: KB-sized) have floor 0: all of their time is excess (launch latency).
+    rows = []
+    for (st, k), v in agg.items():
+        avg_us = v[1] / v[0] / 1e3
+        t = stage_totals.get(st, {}).get(k) or totals.get(k)
+        if t and t.get("launches"):
+            fb, ff = t["MB_per_launch"] * 1e6 / (HBM_PEAK_GBS * 1e9) * 1e6, t["GFLOP_per_launch"] * 1e9 / (MFMA_PEAK_TFLOPS * 1e12) * 1e6
+            floor, bound, mb, gf = max(fb, ff), ("mfma" if ff > fb else "hbm"), t["MB_per_launch"], t["GFLOP_per_launch"]
+        else:
+            floor, bound, mb, gf = 0.0, "unpriced", "", ""
+        rows.append([st, k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), mb, gf, round(floor, 3), bound,
+                     round(floor / avg_us, 4) if avg_us else "", round(v[0] * (avg_us - floor) / 1e3, 3)])
+    rows.sort(key=lambda r: -r[-1])
+    tot_excess = sum(r[-1] for r in rows)
+    with open(os.path.join(out, "excess_by_kernel.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["stage", "kernel", "calls", "total_ms", "avg_us", "algorithmic_MB_per_launch", "GFLOP_per_launch", "floor_us",
+                    "binding_side", "floor_over_avg", "excess_ms", "percent_of_excess"])
+        for r in rows:
+            w.writerow(r + [round(100 * r[-1] / max(tot_excess, 1e-9), 2)])
+        w.writerow(["TOTAL", "", sum(r[2] for r in rows), round(sum(r[3] for r in rows), 3), "", "", "", "", "", "", round(tot_excess, 3), 100.0])
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ library's algorithmic bytes per launch, rocprofv3's durations inside the timed r
 import csv
 import os
 import sys
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 HERE = os.path.dirname(os.path.abspath(__file__))
 # From round 5 on the timed-region file has one row per (stage, variant) and the bench runs other batch sizes outside the clock (the
 # T(B) fit: 8 / 16 images): a variant is compared only where the two populations are the same -- it runs in ONE stage of the

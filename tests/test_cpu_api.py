@@ -603,3 +603,29 @@ def test_infer_batch_rule():
     for n in (1, 63, 64, 65, 257, 300, 1000, 2468):
         r = F.infer_batches(n, 128)
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_write_backlog_is_bounded_and_reader_pool_refuses_nested_use(built_lib, tmp_path, monkeypatch):
+    """(a) a thread that queues more than IMK_MAX_PENDING_WRITES tasks waits for its oldest half first -- the backlog
+    (and the arrays it pins) stays bounded, every file still arrives; (b) the shared reader pool asserts when one of its own tasks
+    uses it (a task waiting for the pool it runs on can starve it); (c) the decode-cache signature sees a same-sized file replaced by
+    an OLDER one."""
+    from inconsistencymasks_amd import functions as F
+    monkeypatch.setattr(F, "_MAX_PENDING_WRITES", 8)
+    a = np.random.default_rng(1).integers(0, 256, (8, 8), dtype=np.uint8)
+    peak = 0
+    for i in range(100):
+        F.write_png_async(str(tmp_path / f"w_{i}.png"), a)
+        peak = max(peak, len(F._PENDING.get(__import__("threading").get_ident(), [])))
+    assert peak <= 9
+    F.flush_writes()
+    assert len(os.listdir(tmp_path)) == 100
+    with F._pool() as pool:
+        with pytest.raises(AssertionError):
+            pool.map(lambda i: pool.map(lambda j: j, range(2)), range(3))
+    f1, f2 = tmp_path / "w_0.png", tmp_path / "w_1.png"
+    sig = lambda: F._stat_sig([os.stat(f1), os.stat(f2)])
+    before = sig()
+    st = os.stat(f1)
+    os.utime(f1, ns=(st.st_atime_ns, st.st_mtime_ns - 10**9))      # same size, OLDER mtime: sum-of-sizes + newest-mtime saw nothing
+    assert sig() != before

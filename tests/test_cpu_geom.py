@@ -94,3 +94,19 @@ def test_cell_count_rejects_what_the_reference_would_misread():
     with pytest.raises(Exception):
         F.get_cell_count([(-9, 4)], z, z)
     assert F.get_cell_count([], z, z) == (0, 0, 0)
+
+
+def test_cell_count_on_colour_and_single_channel_inputs():
+    """ADVICE round 5: a [h, w, 3] image is converted to grey first (functions.py:6321-6338), never read as an interleaved plane;
+    [h, w, 1] is the plane; alive / dead masks of different sizes are refused"""
+    rng = np.random.default_rng(9)
+    alive = rng.integers(0, 40, (48, 64)).astype(np.uint8)
+    dead = rng.integers(0, 40, (48, 64)).astype(np.uint8)
+    pos = [(10, 10), (30, 20), (60, 40), (3, 45)]
+    want = G.get_cell_count(pos, alive, dead)
+    assert F.get_cell_count(pos, alive[..., None], dead[..., None]) == want
+    grey3 = lambda a: np.repeat(a[..., None], 3, 2)                     # B = G = R: the grey conversion returns the plane (+- rounding)
+    a3, d3 = grey3(alive), grey3(dead)
+    assert F.get_cell_count(pos, a3, d3) == G.get_cell_count(pos, F._u8_plane(a3), F._u8_plane(d3))
+    with pytest.raises(ValueError):
+        F.get_cell_count(pos, alive, dead[:40])

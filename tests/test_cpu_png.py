@@ -212,3 +212,37 @@ def test_forged_header_is_an_error_code_not_a_crash():
     for (h, w, c) in ((0, 4, 3), (4, -1, 3), (4, 4, 2)):
         assert lib.imk_png_write_file(os.fsencode("/tmp/_imk_never_written.png"), px.ctypes.data, h, w, c, 1) != 0
     assert not os.path.exists("/tmp/_imk_never_written.png")
+
+
+def test_damaged_header_or_palette_chunk_is_refused(tmp_path):
+    """CRC-32 of IHDR and PLTE is verified (IDAT is covered by zlib's adler32) -- a bit flip in the size or in the palette
+    is an error, as it is in Pillow, not a silently different image; the file API then falls back to Pillow, which raises."""
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 200, (12, 20)).astype(np.uint8)              # > 16 colours: Pillow keeps 8 bits per index
+    im = Image.fromarray(idx, mode="P")
+    im.putpalette([v for k in range(200) for v in (k, 255 - k, (7 * k) % 256)])
+    buf = io.BytesIO()
+    im.save(buf, format="PNG")
+    good = np.frombuffer(buf.getvalue(), np.uint8).copy()
+    out = np.zeros((12, 20, 3), np.uint8)
+    dec = lambda a: lib.imk_png_decode(a.ctypes.data, ctypes.c_int64(a.size), 3, out.ctypes.data, ctypes.c_int64(out.nbytes), None, None)
+    assert dec(good) == 0 and np.array_equal(out, np.asarray(im.convert("RGB")))
+    raw = good.tobytes()
+    for where in (raw.index(b"IHDR") + 4 + 3, raw.index(b"PLTE") + 4 + 5):      # low byte of the width; one palette entry
+        bad = good.copy()
+        bad[where] ^= 0x01
+        assert dec(bad) != 0
+        p = tmp_path / f"bad_{where}.png"
+        p.write_bytes(bad.tobytes())
+        with pytest.raises(Exception):
+            F.read_png(str(p), 3)
+
+
+def test_file_writes_are_renamed_into_place(tmp_path):
+    """a finished file appears under its final name only; nothing else is left in the directory, and a write into a missing directory
+    fails without leaving a temporary file"""
+    a = np.random.default_rng(4).integers(0, 256, (16, 24, 3)).astype(np.uint8)
+    F.write_png(str(tmp_path / "x.png"), a)
+    assert os.listdir(tmp_path) == ["x.png"] and np.array_equal(F.read_png(str(tmp_path / "x.png"), 3), a)
+    rc = lib.imk_png_write_file(os.fsencode(str(tmp_path / "missing" / "y.png")), a.ctypes.data, 16, 24, 3, 1)
+    assert rc != 0 and os.listdir(tmp_path) == ["x.png"]

@@ -168,3 +168,62 @@ def test_gloo_world8_uneven_shards(tmp_path):
         assert o["tiny_tot"] == [10, 5]
     assert sorted(n for o in outs for n in o["tiny"]) == [f"t_{i}.png" for i in range(5)]
     assert sum(1 for o in outs if not o["tiny"]) == 3       # three ranks have nothing to infer and still take part in the reduction
+
+
+WORKER_CAND = textwrap.dedent("""
+    import os, sys, json
+    import torch, torch.distributed as dist
+    sys.path.insert(0, sys.argv[1])
+    world = int(sys.argv[4])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=world)
+    from inconsistencymasks_amd import functions as F, im_driver as D
+    seen = []
+    class M:
+        grads_and_stats = torch.ones(4)
+    def train_candidate(i, side_by_side=False):
+        # what a trainer sees inside: a one-rank run (no sharding, no collective), although the process group exists
+        files = [f"f{j}.png" for j in range(10)]
+        seen.append({"i": i, "dist_none": F._dist() is None, "rank_world": list(F._rank_world()), "shard": len(F._train_shard(files)),
+                     "bench": F.shard_list(files) == sorted(files), "scale": F._grad_allreduce(M())})
+        return (f"model_{i}", float(i) / 10, dist.get_rank())
+    rows = D.train_candidates([0, 1, 2, 3, 4], train_candidate, world, parallel=1)
+    outside = {"dist_none": F._dist() is None, "rank_world": list(F._rank_world())}
+    print(json.dumps({"rank": dist.get_rank(), "rows": rows, "seen": seen, "outside": outside,
+                      "steps": [D.epoch_steps(2594, 32, world), D.epoch_steps(10, 32, world)]}))
+    dist.destroy_process_group()
+""")
+
+
+def _run_cand(tmp_path, world, mode, port_base):
+    import json
+    script = tmp_path / f"c{world}{mode}.py"
+    script.write_text(WORKER_CAND)
+    port = str(port_base + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world)], stdout=subprocess.PIPE, text=True,
+                              env={**os.environ, "IMK_DIST_CPU": "1", "OMP_NUM_THREADS": "1", "IM_DP_MODE": mode}) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_whole_candidates_per_rank_host_logic(tmp_path):
+    """IM_DP_MODE=candidates (im_driver.train_candidates; SURVEY 8e row 3, ISIC_2018/09_ISIC_2018_IM.py:90): candidate at position p of
+    the list trains on rank p mod N inside functions.local_rank_scope -- where the package behaves as ONE rank -- and every rank gets
+    all rows, in candidate order; epoch steps are the reference's (files // 32), not files // (32 N).  World 2 and 8, gloo, CPU."""
+    for world, port in ((2, 33000), (8, 35000)):
+        outs = _run_cand(tmp_path, world, "candidates", port)
+        for o in outs:
+            assert o["rows"] == [[f"model_{i}", i / 10, i % world] for i in range(5)]           # gathered, ordered, trained on i mod N
+            assert [s["i"] for s in o["seen"]] == [i for i in range(5) if i % world == o["rank"]]
+            for s in o["seen"]:
+                assert s["dist_none"] and s["rank_world"] == [0, 1] and s["shard"] == 10 and s["bench"] and s["scale"] == 1.0
+            assert o["outside"] == {"dist_none": False, "rank_world": [o["rank"], world]}         # the scope ends with the candidate
+            assert o["steps"] == [81, 1]
+    # the default mode keeps the data-parallel contract: every rank trains every candidate, steps = files // (32 N)
+    outs = _run_cand(tmp_path, 2, "gradient", 37000)
+    for o in outs:
+        assert [s["i"] for s in o["seen"]] == [0, 1, 2, 3, 4] and not o["seen"][0]["dist_none"] and o["seen"][0]["scale"] == 0.5
+        assert o["steps"] == [40, 1]

@@ -917,6 +917,35 @@ def test_isic_driver_candidates_side_by_side(tmp_path):
             assert (a / n).read_bytes() == (b / n).read_bytes(), (i, n)
 
 
+def test_isic_driver_whole_candidates_per_rank(tmp_path):
+    """IM_DP_MODE=candidates (the reference's five independent candidates, ISIC_2018/09_ISIC_2018_IM.py:90-135): inference
+    + IM sharded over all ranks as always, then candidate i trained WHOLE on rank i mod N with the reference's batch 32 and step count
+    and no collective, the rows gathered for ranking / rename / CSV.  2 and 8 ranks time-slicing this box's one GPU over gloo must
+    reproduce the ONE-rank run byte for byte: results CSV, mean-IM-size CSV, the surviving checkpoints' tensors, every prediction PNG."""
+    from safetensors import safe_open
+    outs = _run_one_and_two_ranks(tmp_path, CONFIG, SETUP, os.path.join(ROOT, "ISIC_2018", "09_ISIC_2018_IM.py"), worlds=(1, 2, 8),
+                                  extra_env={"IM_DP_MODE": "candidates", "IM_CANDIDATES": "0,1,2", "IM_PARALLEL_CANDIDATES": "1"})
+    stem = "ISIC_2018_IM_1_n2_gen0_e0_d0_bi_True_bo_True"
+    for w in (2, 8):
+        for name in (f"results_{stem}.csv", f"mean_im_size_{stem}.csv"):
+            assert (outs[1] / "csv" / name).read_text() == (outs[w] / "csv" / name).read_text(), (w, name)
+        meta = json.loads((outs[w] / "csv" / f"results_{stem}.meta.json").read_text())
+        assert meta["data_parallel_ranks"] == w and meta["dp_mode"] == "candidates"
+        assert sorted(os.listdir(outs[1] / "models")) == sorted(os.listdir(outs[w] / "models"))
+        for j in (1, 2, 3):
+            sd = []
+            for q in (1, w):
+                with safe_open(str(outs[q] / "models" / f"{stem}_topK_{j}.h5"), framework="np") as f:
+                    sd.append({k: f.get_tensor(k) for k in f.keys()})
+            assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), (w, j)
+        for i in range(3):
+            for split in ("val", "test", "train_unlabeled"):
+                a, b = (outs[q] / f"{split}_predictions" / "IM" / f"{stem}_{i}" for q in (1, w))
+                assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) > 0
+                for n in os.listdir(a):
+                    assert (a / n).read_bytes() == (b / n).read_bytes(), (w, i, split, n)
+
+
 @pytest.mark.parametrize("which", ["hela_im", "suim_im", "isic_subset", "isic_impp_evalnets"])
 def test_other_drivers_candidates_side_by_side(tmp_path, which):
     """the default on one rank (three candidates side by side: im_driver.train_candidates) against IM_PARALLEL_CANDIDATES=1 (the
