@@ -477,8 +477,6 @@ FAMILIES = ["conv_mfma_kernel<16,1>", "conv_mfma_kernel<16,2>", "conv_mfma_kerne
             "conv_mfma_kernel<8,2>", "conv_mfma_kernel<8,4>", "conv_pipe_kernel", "wgrad_mfma_kernel", "bn_bwd_prep_kernel",
             "bn_bwd_coef_kernel", "bn_finalize_kernel", "wgf_stage1+2_kernel", "head_kernel", "head_loss_kernel",
             "step_tail(loss_finalize,adamw,pack,fold)", "im_kernel", "conv_gemm_kernel", "wgrad_gemm_kernel"]
-# families whose launches are convolutions far above the fp16 MFMA ridge (~400 FLOP/B): priced against the matrix cores
-MFMA_FAMILIES = {"conv_gemm_kernel", "wgrad_gemm_kernel"}
 
 
 def self_launch(args, argv):
@@ -863,7 +861,7 @@ def run_config(args, config_name, alpha, env, primary):
                for i in range(NV) if pc[i]}
     # which side of max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) binds the dominant family's launches (their live sums): SURVEY 8d -- a GEMM-class
     # family is not "mfma-bound" by name; its full-resolution launches are byte-bound
-    mfma_bound = FAMILIES[v] in MFMA_FAMILIES and pfl[v] / (MFMA_PEAK_TFLOPS * 1e12) > pby[v] / (HBM_PEAK_GBS * 1e9)
+    mfma_bound = pfl[v] / (MFMA_PEAK_TFLOPS * 1e12) > pby[v] / (HBM_PEAK_GBS * 1e9)
     if mfma_bound:
         achieved, peak, unit = (pfl[v] / pms[v] / 1e9 if pms[v] else 0.0), MFMA_PEAK_TFLOPS, "TFLOP/s"
     else:

@@ -25,6 +25,11 @@ struct ImkStopRing {
     hipEvent_t side_last = nullptr;
 };
 inline thread_local ImkStopRing *imk_tls_stop_ring = nullptr;
+// Measurement (imk_prof_totals_enable on the context bound to this thread): every launch is counted under the kernel's own name as
+// rocprofv3 prints it (template arguments included), with the algorithmic bytes / flops the enclosing ImkProfScope announced
+// (imk_conv.hip: imk_prof_note_launch).  Off: one thread-local load per launch.
+inline thread_local bool imk_tls_totals_on = false;
+void imk_prof_note_launch(const void *kern, hipStream_t stream);
 
 template <typename... KA, typename... A, size_t... I>
 inline hipError_t imk_klaunch_ext(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t stop,
@@ -37,6 +42,7 @@ inline hipError_t imk_klaunch_ext(void (*kern)(KA...), dim3 grid, dim3 block, si
 template <typename... KA, typename... A>
 inline void imk_klaunch(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A &&...args) {
     static_assert(sizeof...(KA) == sizeof...(A), "kernel argument count");
+    if (imk_tls_totals_on) imk_prof_note_launch(reinterpret_cast<const void *>(kern), stream);
     ImkStopRing *r = imk_tls_stop_ring;
     if (r && (r->stream == stream || (r->side && r->side == stream))) {
         hipEvent_t e = r->ev[r->cur];
@@ -150,10 +156,12 @@ enum ImkProfFamily {
     PF_COUNT = 18
 };
 // Returns a slot >= 0 when this launch is sampled (an event was recorded on `stream`), else -1.
-// variant: the launched kernel's name as rocprofv3 prints it (template arguments included) where a family has several variants
-// of very different cost (conv_pipe / conv_wide); nullptr = the family's name.  With totals enabled (imk_prof_totals_enable) the
-// bound context sums launches / algorithmic bytes / flops of EVERY hooked launch per such name -- what profiles/summarize.py
-// divides by rocprofv3's own per-kernel durations.
+// With totals enabled (imk_prof_totals_enable) the bound context sums launches / algorithmic bytes / flops per KERNEL NAME as
+// rocprofv3 prints it (template arguments included; resolved from the launched function itself in imk_klaunch): a scope announces
+// its work, the next launch on this thread takes it -- what profiles/summarize.py divides by rocprofv3's own per-kernel durations
+// and prices against max(bytes / 8 TB/s, flops / 2.5 PFLOP/s).  A scope with several launches re-announces per launch
+// (imk_prof_work); launches outside any scope are counted with no work ("unpriced": KB-sized).  `variant` is unused since round 6.
+void imk_prof_work(double algorithmic_bytes, double flops = 0.0);
 int imk_prof_begin(int family, double algorithmic_bytes, hipStream_t stream, double flops = 0.0, const char *variant = nullptr);
 void imk_prof_end(int slot, hipStream_t stream);
 struct ImkProfScope {

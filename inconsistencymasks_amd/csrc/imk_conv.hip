@@ -1814,8 +1814,15 @@ int imk_launch_wgrad_finalize_jobs(const ImkWgFinalJobs &jobs, const float *inv_
     for (int i = 0; i < jobs.n; ++i)   // partials read once, chunk sums written and read once, gradients written
         wgf_bytes += ((double)jobs.j[i].n_split + 2.0 * jobs.j[i].n_chunks + 1.0) * jobs.j[i].n_tiles * 256 * 4;
     ImkProfScope prof(PF_WGF, wgf_bytes, stream);
+    double b1 = 0, b2 = 0;            // per launch: stage 1 reads the partial rows and writes the chunk sums, stage 2 reads those and writes the gradients
+    for (int i = 0; i < jobs.n; ++i) {
+        b1 += ((double)jobs.j[i].n_split + jobs.j[i].n_chunks) * jobs.j[i].n_tiles * 256 * 4;
+        b2 += ((double)jobs.j[i].n_chunks + 1.0) * jobs.j[i].n_tiles * 256 * 4;
+    }
+    imk_prof_work(b1);
     imk_klaunch(wgf_stage1_kernel, dim3(jobs.total_work1), dim3(256), 0, stream, jobs);
     IMK_LAUNCH_CHECK();
+    imk_prof_work(b2);
     imk_klaunch(wgf_stage2_kernel, dim3(jobs.total_tiles), dim3(1024), 0, stream, jobs, inv_scale_ptr, found_inf);
     IMK_LAUNCH_CHECK();
     return IMK_OK;
@@ -1867,9 +1874,12 @@ int imk_conv_num_tiles(int B, int H, int W, int cs_in, int ksize) {
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cxxabi.h>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int variant; double bytes, flops; };
@@ -1909,21 +1919,65 @@ extern "C" int imk_prof_create(int period, imk_prof **out) {
 }
 extern "C" void imk_prof_destroy(imk_prof *p) {
     if (!p) return;
-    if (t_prof == p) t_prof = nullptr;
+    if (t_prof == p) { t_prof = nullptr; imk_tls_totals_on = false; }
     for (auto &r : p->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : p->pool) (void)hipEventDestroy(e);
     delete p;
 }
-extern "C" int imk_prof_bind(imk_prof *p) { t_prof = p; return IMK_OK; }
-extern "C" int imk_prof_unbind(imk_prof *p) { if (p && t_prof == p) { t_prof = nullptr; return 1; } return 0; }
+extern "C" int imk_prof_bind(imk_prof *p) { t_prof = p; imk_tls_totals_on = p && p->totals_on; return IMK_OK; }
+extern "C" int imk_prof_unbind(imk_prof *p) { if (p && t_prof == p) { t_prof = nullptr; imk_tls_totals_on = false; return 1; } return 0; }
 extern "C" int imk_prof_set_period(imk_prof *p, int period) { IMK_CHECK_ARG(p && period >= 0); p->period = period; return IMK_OK; }
+
+// name of a kernel as rocprofv3's kernel trace prints it, minus "void ", the anonymous namespace and the parameter list (what
+// profiles/summarize.py's short() leaves): resolved once per function through the runtime's own symbol table
+static const std::string &kernel_short_name(const void *kern, hipStream_t stream) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, std::string> names;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = names.find(kern);
+    if (it != names.end()) return it->second;
+    std::string n = "?";
+    if (const char *m = hipKernelNameRefByPtr(kern, stream)) {
+        int st = 0;
+        char *d = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+        n = (st == 0 && d) ? d : m;
+        free(d);
+        if (st != 0) {      // (_Float16 parameters defeat the demangler -- rocprofv3's too: the plain name, as summarize.py's short() cuts it)
+            const char *tag = "_ZN12_GLOBAL__N_1";
+            const size_t at = n.find(tag);
+            if (at != std::string::npos) {
+                size_t i = at + strlen(tag), len = 0;
+                while (i < n.size() && n[i] >= '0' && n[i] <= '9') len = 10 * len + (size_t)(n[i++] - '0');
+                if (len > 0 && i + len <= n.size()) n = n.substr(i, len);
+            }
+        }
+        for (const char *drop : {"void ", "(anonymous namespace)::"})
+            for (size_t at; (at = n.find(drop)) != std::string::npos;) n.erase(at, strlen(drop));
+        // cut the parameter list: the first '(' outside the template argument brackets
+        int depth = 0;
+        for (size_t i = 0; i < n.size(); ++i) {
+            if (n[i] == '<') ++depth;
+            else if (n[i] == '>') --depth;
+            else if (n[i] == '(' && depth == 0) { n.resize(i); break; }
+        }
+        if (n.size() > 90) n.resize(90);
+    }
+    return names.emplace(kern, n).first->second;
+}
+static thread_local struct { double bytes, flops; bool armed; } t_work = {0.0, 0.0, false};
+void imk_prof_work(double bytes, double flops) { t_work.bytes = bytes; t_work.flops = flops; t_work.armed = true; }
+void imk_prof_note_launch(const void *kern, hipStream_t stream) {
+    imk_prof *p = t_prof;
+    if (!p || !p->totals_on) return;
+    ProfTot &t = p->totals[kernel_short_name(kern, stream)];
+    t.launches += 1;
+    if (t_work.armed) { t.bytes += t_work.bytes; t.flops += t_work.flops; t_work.armed = false; }
+}
 
 int imk_prof_begin(int family, double bytes, hipStream_t stream, double flops, const char *variant) {
     imk_prof *p = t_prof;
-    if (p && p->totals_on && family >= 0 && family < PF_COUNT) {
-        ProfTot &t = p->totals[variant ? variant : kFamilyNames[family]];
-        t.launches += 1; t.bytes += bytes; t.flops += flops;
-    }
+    (void)variant;
+    if (p && p->totals_on && family >= 0 && family < PF_COUNT) imk_prof_work(bytes, flops);      // the scope's next launch takes it
     if (!p || p->period <= 0 || (p->counter++ % p->period) != 0) return -1;
     ProfRec pr{p->event(), p->event(), family, bytes, flops};
     if (hipEventRecord(pr.e0, stream) != hipSuccess) { p->pool.push_back(pr.e0); p->pool.push_back(pr.e1); return -1; }
@@ -1939,6 +1993,8 @@ extern "C" int imk_prof_totals_enable(imk_prof *p, int on) {
     IMK_CHECK_ARG(p);
     p->totals.clear();
     p->totals_on = on != 0;
+    if (t_prof == p) imk_tls_totals_on = p->totals_on;      // (the launches of the thread the context is bound to are the ones counted)
+    t_work.armed = false;
     return IMK_OK;
 }
 // "name;launches;bytes;flops\n" per kernel name; returns the bytes needed incl. the terminating 0 (call again if > cap)
@@ -2113,13 +2169,7 @@ static int launch_conv_pipe_k(const ImkConvArgs &a, hipStream_t stream) {
     if (grid > n_tiles) grid = n_tiles;
     const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y, DYN);
     if (DYN && wk.shift != 5) return IMK_EINVAL;      // (>= 2048 tiles: always the 32-group walk)
-    static const std::string vname = []() {     // as rocprofv3 prints the instantiation
-        char b[128];
-        snprintf(b, sizeof b, "conv_pipe_kernel<%d, %d, %d, %s, %d, %s, %s, %d, %d, %s>", LM, NC8, CHAIN, PAIR ? "true" : "false", EPI,
-                 DYSTAT ? "true" : "false", FULL ? "true" : "false", WG, PRE, DYN ? "true" : "false");
-        return std::string(b);
-    }();
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     imk_klaunch(kern, dim3(grid), dim3(256), lds, stream, a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;
@@ -2231,13 +2281,7 @@ static int launch_conv_wide_k(const ImkConvArgs &a, hipStream_t stream) {
     int grid = 256 * blocks_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     const ImkWalk wk = imk_walk_make(grid, n_tiles, tiles_x * tiles_y);
-    static const std::string vname = []() {
-        char b[128];
-        snprintf(b, sizeof b, "conv_wide_kernel<%d, %d, %d, %d, %s, %s, %s>", LM, NC8, MT, EPI, DYSTAT ? "true" : "false",
-                 FULL ? "true" : "false", CHAIN2 ? "true" : "false");
-        return std::string(b);
-    }();
-    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a), vname.c_str());
+    ImkProfScope prof(PF_CONV_PIPE, imk_conv_algorithmic_bytes(a), stream, imk_conv_flops(a));
     imk_klaunch(kern, dim3(grid), dim3(256), lds, stream, a, tiles_x, tiles_y, n_tiles, div_magic(tiles_x), wk);
     IMK_LAUNCH_CHECK();
     if (a.stats_rows) *a.stats_rows = grid;

@@ -1,7 +1,8 @@
 """GPU probabilities against the INDEPENDENT oracle (unet_oracle.forward(emulate_fp16=False): plain fp32, no knowledge of the kernels'
 rounding points), every parity configuration of tests/test_gpu_unet.py, default-init and randomised-BatchNorm weights: rel-L2, max |dp|,
 decision-flip rate -- and the same three numbers for the fp16-emulating oracle against the fp32 one (what fp16 storage costs on its own).
-The test bounds of test_inference_parity / test_baseline_shapes_full_size (FP32_BOUNDS) are frozen from this table.
+The bounds of test_inference_parity / test_baseline_shapes_full_size (check_against_fp32) are frozen from this table:
+tests/measured/fp32_gap_r06.json is its last line.
     python tests/gpu_probe/fp32_gap.py > gpurun_out/fp32_gap.txt"""
 import json
 import os
@@ -19,8 +20,8 @@ from oracle import unet_oracle as U           # noqa: E402
 
 
 def three(p, r, act):
-    flips = ((p.argmax(-1) != r.argmax(-1)) if act == "softmax" else ((p > 0.5) != (r > 0.5))).mean()
-    return [round(T.rel_l2(p, r), 6), round(float(np.abs(p - r).max()), 5), round(float(flips), 6)]
+    a, b, c = T.three(p, r, act)
+    return [round(a, 6), round(b, 5), round(c, 6)]
 
 
 out = {}

@@ -92,6 +92,16 @@ def test_profiler_totals_marker_and_unbind():
     pipe = {k: v for k, v in t.items() if k.startswith("conv_pipe_kernel<")}
     assert pipe and all(v["launches"] % 3 == 0 and v["bytes"] > 0 for v in pipe.values()), t
     assert any(k.endswith(", 0, 1>") for k in pipe) or len(pipe) >= 2        # template arguments spelled as rocprofv3 prints them
+    # round 6: EVERY launch is counted under its own kernel name (resolved from the launched function), priced or not
+    assert t["imk_mark_kernel"] == {"launches": 2, "bytes": 0.0, "flops": 0.0}, t
+    assert not any("(" in k or k.startswith("void ") or "anonymous" in k for k in t), list(t)
+    heads = {k: v for k, v in t.items() if k.startswith("head_")}
+    assert heads and all(v["launches"] == 3 and v["bytes"] > 0 for v in heads.values()), t
+    m.train_step(x, (torch.rand((4, 64, 64, 1), device="cuda") > 0.5).to(torch.uint8), 0, 3e-3, 1e-4)
+    torch.cuda.synchronize()
+    t = pr.totals_dump()
+    for name in ("wgf_stage1_kernel", "wgf_stage2_kernel", "adamw_kernel", "bn_bwd_coef_kernel"):
+        assert t[name]["launches"] >= 1 and t[name]["bytes"] > 0, (name, t.get(name))
     pr.totals(False)
     assert pr.totals_dump() == {}
     assert lib.imk_prof_unbind(pr._p) == 1 and lib.imk_prof_unbind(pr._p) == 0

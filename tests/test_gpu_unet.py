@@ -44,6 +44,42 @@ def UNet():
     return cls
 
 
+# ---- the INDEPENDENT oracle -----------------------------------------------------------------------------
+# unet_oracle.forward(emulate_fp16=False) is a plain fp32 restatement of unet.py:4-67 that knows nothing about where the kernels
+# round.  The fp16-emulating oracle has learnt the kernels' rounding points over the rounds (one-rounding BatchNorm affine, which
+# gradients are stored); so that the two cannot drift together unnoticed, every forward parity test ALSO bounds the GPU against fp32:
+#   (a) by 1.5 x what tests/gpu_probe/fp32_gap.py measured on the MI355X for that configuration and weight kind
+#       (tests/measured/fp32_gap_r06.json: rel-L2, max |dp|, decision-flip rate; floors 1e-3 / 2e-3 / 1e-3), and
+#   (b) by the emulation's own distance from fp32 on the same input: the GPU may not be further from fp32 than 1.5 x what fp16
+#       storage alone costs (+ 5e-4) -- a change that moves kernels and emulation TOGETHER away from fp32 fails (a) or (b).
+# Measured (round 6): GPU-vs-fp32 equals fp16emu-vs-fp32 within 10 % in every one of the 34 cases; default init rel-L2 <= 3.2e-3,
+# max |dp| <= 5.8e-3; randomised BatchNorm parameters at full size up to rel-L2 1.3e-2, max |dp| 5.2e-2, flips 1.3 % -- the cost of
+# the reference's own mixed_float16 policy on these nets (ISIC_2018/09_ISIC_2018_IM.py:16, unet.py:63), not of the kernels.
+import json as _json
+import os as _os
+FP32_GAP = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "measured", "fp32_gap_r06.json")))
+FP32_FLOORS = (1e-3, 2e-3, 1e-3)
+
+
+def three(p, r, act):
+    flips = ((p.argmax(-1) != r.argmax(-1)) if act == "softmax" else ((p > 0.5) != (r > 0.5))).mean()
+    return [rel_l2(p, r), float(np.abs(p - r).max()), float(flips)]
+
+
+def check_against_fp32(key, probs, sd, x, cfg, ref16=None):
+    """bounds (a) and (b) above for one (configuration, weight kind); returns the three measured numbers"""
+    c, k, alpha, act = cfg["c"], cfg["k"], cfg["alpha"], cfg["act"]
+    ref32 = U.forward(sd, x, c, k, alpha, act, emulate_fp16=False).numpy()
+    if ref16 is None:
+        ref16 = U.forward(sd, x, c, k, alpha, act, emulate_fp16=True).numpy()
+    got, emu, frozen = three(probs, ref32, act), three(ref16, ref32, act), FP32_GAP[key]["gpu_vs_fp32"]
+    for i, what in enumerate(("rel-L2", "max |dp|", "flip rate")):
+        assert got[i] <= max(1.5 * frozen[i], FP32_FLOORS[i]), f"{key}: GPU vs fp32 oracle {what} {got[i]:.3g}, measured in round 6: {frozen[i]:.3g}"
+    assert got[0] <= 1.5 * emu[0] + 5e-4, f"{key}: GPU is {got[0]:.3g} from fp32 (rel-L2), the fp16 emulation only {emu[0]:.3g}"
+    assert got[1] <= 2.0 * emu[1] + 2e-3, f"{key}: GPU max |dp| {got[1]:.3g} vs fp32, the fp16 emulation {emu[1]:.3g}"
+    return got
+
+
 def rel_l2(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
@@ -126,6 +162,10 @@ def test_inference_parity(UNet, name):
     assert flips <= 0.01, f"decision flip rate {flips}"
     # predict() (numpy in / numpy out, batches) is the same computation
     assert np.array_equal(m.predict([x], batch_size=3), probs)
+    # the independent fp32 oracle: randomised BatchNorm parameters (this model) and default initialisation
+    check_against_fp32(f"CFGS.{name}.random_bn", probs, sd, x, cfg, ref16=ref)
+    m0 = UNet(cfg["h"], cfg["w"], cfg["c"], cfg["k"], cfg["alpha"], cfg["act"], seed=1)
+    check_against_fp32(f"CFGS.{name}.default_init", m0.predict_device(xd).cpu().numpy(), m0.state_dict(), x, cfg)
 
 
 def test_inference_batch_invariance(UNet):
@@ -450,6 +490,11 @@ def test_baseline_shapes_full_size(UNet, name):
     assert rel_l2(probs, ref) <= 1e-2
     flips = ((probs.argmax(-1) != ref.argmax(-1)) if act == "softmax" else ((probs > 0.5) != (ref > 0.5))).mean()
     assert flips <= 0.01, f"decision flip rate {flips}"
+    # the independent fp32 oracle at the real sizes, both weight kinds (see check_against_fp32)
+    check_against_fp32(f"BASELINE_SHAPES.{name}.random_bn", probs, sd, x, cfg, ref16=ref)
+    m0 = UNet(cfg["h"], cfg["w"], c, k, alpha, act, seed=61)
+    check_against_fp32(f"BASELINE_SHAPES.{name}.default_init", m0.predict_device(xd).cpu().numpy(), m0.state_dict(), x, cfg)
+    del m0
     before = m.params.clone()
     for _ in range(6):       # the dynamic loss scale may need a few halvings at these sizes
         m.train_step(xd, torch.from_numpy(y).cuda(), 0 if cfg["loss"] == "mse" else 1, 3e-3, 1e-4)
