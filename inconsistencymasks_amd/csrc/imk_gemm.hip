@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
         };
         f16x8 b0[PM], b1[PM];
         loadB(b0);
+        // (Round 6, measured and removed: weight fragments TWO k-steps ahead of their MFMAs -- three register buffers, loads stopped
+        //  at the next stage's first two fragments, a select-rotation at the stage end; bit-identical.  +31 registers took the 128-channel
+        //  forms from 3 to 2 waves per SIMD: Cityscapes alpha 2 step 4.63 -> 4.87 ms, alpha 1.25 3.61 -> 3.83, 128-image inference 4.13 ->
+        //  4.42, EvalNet 2.02 -> 2.09 (profiles/r06_ab_adepth.txt).  One k-step of look-ahead with three resident waves hides the L2.)
         for (int f = 0; f < nk; f += 2) {
             loadA(a1, F + f + 1);
             loadB(b1);

@@ -932,12 +932,14 @@ def test_isic_driver_whole_candidates_per_rank(tmp_path):
         meta = json.loads((outs[w] / "csv" / f"results_{stem}.meta.json").read_text())
         assert meta["data_parallel_ranks"] == w and meta["dp_mode"] == "candidates"
         assert sorted(os.listdir(outs[1] / "models")) == sorted(os.listdir(outs[w] / "models"))
-        for j in (1, 2, 3):
+        kept = sorted(n for n in os.listdir(outs[1] / "models") if n.startswith(stem + "_topK_"))
+        assert len(kept) >= 2                                   # TOP_Ks of the toy config
+        for name in kept:
             sd = []
             for q in (1, w):
-                with safe_open(str(outs[q] / "models" / f"{stem}_topK_{j}.h5"), framework="np") as f:
+                with safe_open(str(outs[q] / "models" / name), framework="np") as f:
                     sd.append({k: f.get_tensor(k) for k in f.keys()})
-            assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), (w, j)
+            assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), (w, name)
         for i in range(3):
             for split in ("val", "test", "train_unlabeled"):
                 a, b = (outs[q] / f"{split}_predictions" / "IM" / f"{stem}_{i}" for q in (1, w))
