@@ -1036,7 +1036,10 @@ def run_config(args, config_name, alpha, env, primary):
                         "rocprofv3 trace of this command and configuration (absent: no such trace committed, or refused -- replayed_refused); "
                         "frac = its algorithmic bytes (flops) over that duration over the peak; family_frac = the same over every hooked "
                         "variant of the stage; chain_ms / per_image_us = intercept / slope of the training step time over batches of "
-                        "8, 16, 32 measured in THIS run; stage_frac_of_min_bytes_floor = SURVEY 8d minimum bytes / stage time / 8 TB/s, live"}
+                        "8, 16, 32 measured in THIS run; stage_frac_of_min_bytes_floor = SURVEY 8d minimum bytes / stage time / 8 TB/s, live.  "
+                        "Durations in the trace are those of the product's overlap: an inference launch shares the chip with the other "
+                        "ensemble member's launch on the second stream, a training-chain kernel with the weight gradients on the side stream "
+                        "(roofline.exclusive = the same workload with every kernel alone on one stream)"}
     roofline["by_stage"] = by_stage
     # the same generation once more with every kernel alone on the stream: the kernels' own rates
     for m in models + [student]:
