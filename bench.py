@@ -121,7 +121,7 @@ def compact_line(full, detail_path=None):
                                             "train_batch_per_gpu", "global_batch", "parallelism", "process_group", "epoch_steps", "kept")}
     line["config"]["bn_momentum"] = (c.get("bn_momentum") or {}).get("value")
     rf = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us_per_launch", "frac_rocprof",
-                                "rocprof_avg_us_per_launch", "traffic", "traffic_over_algorithmic", "live", "replayed_from",
+                                "frac_rocprof_union", "rocprof_avg_us_per_launch", "traffic", "traffic_over_algorithmic", "live", "replayed_from",
                                 "replayed_refused")}
     bs = r.get("by_stage") or {}
     ti, tt = bs.get("inference") or {}, bs.get("training") or {}
@@ -915,6 +915,20 @@ def run_config(args, config_name, alpha, env, primary):
                 frac_rocprof = round(work / ms / peak, 4)     # MB / ms = GB/s; GFLOP / ms = TFLOP/s
     except Exception:
         pass
+    # ... and against the UNION of the family's launch intervals instead of the sum of their durations (the two ensemble members' forwards
+    # overlap on two streams, the weight gradients run beside the dgrads): the bandwidth the family delivered while it was running
+    frac_union, union_by_stage = None, {}
+    try:
+        if replay_ok and os.path.exists(prof_file("timed_region_family_union")):
+            for r in csv.DictReader(open(prof_file("timed_region_family_union"))):
+                if r["family"].split("+")[0] == fams[0] and r.get("GBps_by_union"):
+                    f_u = float(r["frac_of_2.5PFLOPs_by_union"]) if mfma_bound else float(r["frac_of_8TBps_by_union"])
+                    if r["stage"] == "all":
+                        frac_union = f_u
+                    else:
+                        union_by_stage[r["stage"]] = {"frac_by_union": f_u, "overlap_factor": float(r["overlap_factor"])}
+    except Exception:
+        pass
     whole_n = setup_prof[0][v] + pc[v]
     whole_ms = setup_prof[1][v] + pms[v]
     steps_per_gen = max(info.get("epoch_steps", 1), 1)
@@ -941,14 +955,15 @@ def run_config(args, config_name, alpha, env, primary):
                 "traffic_source": traffic_src,
                 "traffic_over_algorithmic": traffic_ratio, "traffic_population_algorithmic_bytes_per_launch": traffic_alg,
                 "frac_rocprof": frac_rocprof, "rocprof_avg_us_per_launch": round(rocprof_us, 2) if rocprof_us else None,
+                "frac_rocprof_union": frac_union, "frac_rocprof_union_by_stage": union_by_stage or None,
                 "frac_rocprof_source": rocprof_src,
                 # what THIS run measured and what it read back from committed files (printed only when profiles/<ROUND>_provenance
                 # names this bench.py and these kernel sources; otherwise null + the reason)
                 "live": ["achieved", "frac", "launches", "avg_us_per_launch", "stage_ms", "by_stage.*.stage_frac", "by_stage.training.chain_ms",
                          "by_stage.training.per_image_us", "by_stage.training.step_ms", "exclusive_frac", "im_kernel"],
-                "replayed": ["traffic", "traffic_over_algorithmic", "frac_rocprof", "rocprof_avg_us_per_launch", "by_stage.*.kernel",
+                "replayed": ["traffic", "traffic_over_algorithmic", "frac_rocprof", "frac_rocprof_union", "rocprof_avg_us_per_launch", "by_stage.*.kernel",
                              "by_stage.*.frac", "by_stage.inference.bound"],
-                "replayed_from": f"profiles/{ROUND}_{{pmc_traffic,traffic_vs_algorithmic,timed_region_kernel_stats,sq_counters}}{tag}.csv" if replay_ok else None,
+                "replayed_from": f"profiles/{ROUND}_{{pmc_traffic,traffic_vs_algorithmic,timed_region_kernel_stats,timed_region_family_union,sq_counters}}{tag}.csv" if replay_ok else None,
                 "replayed_refused": replay_refused,
                 "avg_us_per_launch_whole_process": round(1000 * whole_ms / max(whole_n, 1), 2),
                 "launches": int(pc[v]), "avg_us_per_launch": round(1000 * pms[v] / max(pc[v], 1), 2),

@@ -46,6 +46,7 @@ for d in sorted(glob.glob(os.path.join(S, "cfg_*"))):
     cp(f"{sub}/kernel_stats.csv", f"{RND}_kernel_stats{tag}.csv")
     cp(f"{sub}/timed_region_kernel_stats.csv", f"{RND}_timed_region_kernel_stats{tag}.csv")
     cp(f"{sub}/excess_by_kernel.csv", f"{RND}_excess_by_kernel{tag}.csv")
+    cp(f"{sub}/timed_region_family_union.csv", f"{RND}_timed_region_family_union{tag}.csv")
     cp(f"{sub}/pmc_traffic.csv", f"{RND}_pmc_traffic{tag}.csv")
     # the provenance of a configuration's files counts only when its trace was actually cut
     if os.path.exists(os.path.join(d, "timed_region_kernel_stats.csv")):

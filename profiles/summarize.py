@@ -5,6 +5,8 @@ per-dispatch CSVs are tens of MB and are deleted afterwards).
   pmc_traffic.csv       : per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch as reported (KB -> MB), and the
                           gfx950-corrected HBM bytes per launch (FETCH x 2 for wide coalesced reads + WRITE;
                           MI355X_MICROARCH.md, section HBM)
+  timed_region_family_union.csv (round 6): per kernel family and stage: sum of the launches' durations, the UNION of their intervals
+                          (launches of a family overlap on two streams), algorithmic GB, GB/s and fraction of 8 TB/s by both
   excess_by_kernel.csv (round 6): per (stage, variant) of the timed region: floor_us = max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) of one
                           launch, the side that binds, excess_ms = calls x (avg_us - floor_us), sorted by excess
   timed_region_kernel_stats.csv (round 4): the dispatches BETWEEN bench.py's two marker kernels (imk_mark_kernel with 64 and
@@ -113,11 +115,15 @@ def timed_region(out):
         i = bisect.bisect_right(starts, ts) - 1
         return stage_marks[i][1] if i >= 0 else ("inference" if stage_marks else "")
     agg = collections.defaultdict(lambda: [0, 0.0])
+    spans = collections.defaultdict(list)      # (stage, family) -> [(start, end)]: the family's launches overlap (two ensemble members on two streams)
     for r in rows:
         if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1 and "imk_mark_kernel" not in r["Kernel_Name"]:
             k = (stage_of(int(r["Start_Timestamp"])), short(r["Kernel_Name"]))
             agg[k][0] += 1
             agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            fam = k[1].split("<")[0]
+            fam = "conv_pipe_kernel+conv_wide_kernel" if fam in ("conv_pipe_kernel", "conv_wide_kernel") else fam      # one family in the bench's hook
+            spans[(k[0], fam)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k[1]))
     totals, stage_totals = {}, {}
     try:
         # round 6: the full record of the traced run sits beside its (now compact) stdout line (bench.py --detail)
@@ -151,6 +157,51 @@ def timed_region(out):
                 extra = ["", "", "", "", "", ""]
             w.writerow([st, k, v[0], round(v[1] / 1e6, 3), round(avg_us, 3), round(100 * v[1] / max(tot_ns, 1), 2),
                         round(100 * v[1] / max(stage_ns[st], 1), 2)] + extra + [round((t1 - t0) / 1e6, 3)])
+    # Per family and stage: the SUM of the launches' durations against the time during which at least one of them was running (the
+    # union of their intervals).  Launches of one family overlap -- the two ensemble members' forwards run on two streams, a training
+    # step's weight gradients beside its dgrads -- so bytes / sum-of-durations prices every launch as if it had the chip to itself and
+    # took that long: the bandwidth the family DELIVERED while it ran is bytes / union.
+    def union_ns(iv):
+        iv = sorted((a, b) for a, b, _ in iv)
+        tot, cs, ce = 0, None, None
+        for a, b in iv:
+            if ce is None or a > ce:
+                if ce is not None:
+                    tot += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        return tot + (ce - cs if ce is not None else 0)
+    with open(os.path.join(out, "timed_region_family_union.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["stage", "family", "calls", "sum_ms", "union_ms", "overlap_factor", "algorithmic_GB", "GFLOP", "GBps_by_sum", "GBps_by_union",
+                    "frac_of_8TBps_by_sum", "frac_of_8TBps_by_union", "TFLOPs_by_union", "frac_of_2.5PFLOPs_by_union"])
+        def fam_rows(stage_filter, label):
+            out_rows = []
+            fams = sorted({fk[1] for fk in spans})
+            for fam in fams:
+                iv = [x for (st, fm), lst in spans.items() if fm == fam and (stage_filter is None or st == stage_filter) for x in lst]
+                if not iv:
+                    continue
+                mb = gf = 0.0
+                priced = True
+                for a, b, name in iv:
+                    st = stage_of(a)
+                    t = stage_totals.get(st, {}).get(name) or totals.get(name)
+                    if t and t.get("launches"):
+                        mb += t["MB_per_launch"]; gf += t["GFLOP_per_launch"]
+                    else:
+                        priced = False
+                sm, un = sum(b - a for a, b, _ in iv) / 1e6, union_ns(iv) / 1e6
+                if priced and un > 0:
+                    out_rows.append([label, fam, len(iv), round(sm, 3), round(un, 3), round(sm / un, 3), round(mb / 1e3, 3), round(gf, 1),
+                                     round(mb / sm, 1), round(mb / un, 1), round(mb / sm / HBM_PEAK_GBS, 4), round(mb / un / HBM_PEAK_GBS, 4),
+                                     round(gf / un, 1), round(gf / un / MFMA_PEAK_TFLOPS, 4)])
+                else:
+                    out_rows.append([label, fam, len(iv), round(sm, 3), round(un, 3), round(sm / max(un, 1e-9), 3)] + [""] * 8)
+            return sorted(out_rows, key=lambda r: -r[3])
+        for lab, flt in (("all", None), ("inference", "inference"), ("training", "training")):
+            w.writerows(fam_rows(flt, lab))
     # Per variant: the floor of ONE launch = max(algorithmic bytes / 8 TB/s, flops / 2.5 PFLOP/s), which side binds, and the time the
     # variant spends ABOVE that floor in the timed region (excess_ms = calls x (avg_us - floor_us)); sorted by excess: the rows at the
     # top own the gap between the step and its roofline.  Kernels the library does not price (tiny per-channel reductions, the step

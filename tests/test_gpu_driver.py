@@ -999,3 +999,54 @@ def test_other_drivers_candidates_side_by_side(tmp_path, which):
             with safe_open(str(outs[p] / "models" / n), framework="np") as f:
                 sd.append({k: f.get_tensor(k) for k in f.keys()})
         assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), n
+
+
+@pytest.mark.parametrize("which", ["hela_im", "suim_im", "isic_subset"])
+def test_other_drivers_whole_candidates_per_rank(tmp_path, which):
+    """IM_DP_MODE=candidates behind the HeLa and SUIM IM drivers and the ISIC subset driver (im_driver.train_candidates serves all
+    of them; subset_driver / impp_driver size their epochs with im_driver.epoch_steps): two ranks time-slicing one GPU over gloo
+    reproduce the one-rank run -- every CSV and every surviving checkpoint's tensors equal."""
+    from safetensors import safe_open
+    config, setup, script, cands = {
+        "hela_im": (HELA_CONFIG, HELA_SETUP, os.path.join("HeLa", "09_HeLa_IM.py"), "0,1,2"),
+        "suim_im": (MULTI_CONFIG, MULTI_SETUP, os.path.join("SUIM", "10_SUIM_IM.py"), "0,1,2"),
+        "isic_subset": (CONFIG, SETUP, os.path.join("ISIC_2018", "03_ISIC_2018_subset.py"), "0,1,2"),
+    }[which]
+    import socket
+    outs = {}
+    for world in (1, 2):
+        work = tmp_path / f"w{world}"
+        base = work / "data"
+        work.mkdir()
+        cfg = work / "config.ini"
+        cfg.write_text(config.format(base=base))
+        env = {**os.environ, "IM_CONFIG": str(cfg), "IM_RUNIDS": "1", "IM_NS": "2", "IM_GENS": "0", "IM_CANDIDATES": cands,
+               "IM_PARALLEL_CANDIDATES": "1", "IM_DP_MODE": "candidates"}
+        subprocess.run([sys.executable, "-c", setup.format(root=ROOT)], env=env, check=True, cwd=work)
+        if which == "isic_subset":
+            for f in os.listdir(base / "models"):
+                os.remove(base / "models" / f)
+        if world == 1:
+            cmd = [sys.executable, os.path.join(ROOT, script)]
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env.update(IMK_DIST_BACKEND="gloo", IMK_ONE_GPU="1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.join(ROOT, script)]
+        r = subprocess.run(cmd, env=env, cwd=work, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[world] = base
+    csvs = sorted(n for n in os.listdir(outs[1] / "csv") if n.endswith(".csv"))
+    assert csvs and csvs == sorted(n for n in os.listdir(outs[2] / "csv") if n.endswith(".csv"))
+    for name in csvs:
+        assert (outs[1] / "csv" / name).read_text() == (outs[2] / "csv" / name).read_text(), name
+    tops = sorted(n for n in os.listdir(outs[1] / "models") if "_topK_" in n and (which == "isic_subset" or "_IM_" in n))
+    assert tops and all((outs[2] / "models" / n).exists() for n in tops)
+    for n in tops:
+        sd = []
+        for w in (1, 2):
+            with safe_open(str(outs[w] / "models" / n), framework="np") as f:
+                sd.append({k: f.get_tensor(k) for k in f.keys()})
+        assert sd[0].keys() == sd[1].keys() and all(np.array_equal(sd[0][k], sd[1][k]) for k in sd[0]), n
