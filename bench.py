@@ -1012,7 +1012,8 @@ def run_config(args, config_name, alpha, env, primary):
         if not rows:
             return None
         r = max(rows, key=lambda q: float(q["total_ms"]))
-        mf = r["kernel"].startswith(("conv_gemm", "wgrad_gemm"))
+        # which side of max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) binds THIS variant's launches (not a label by family name)
+        mf = float(r.get("GFLOP_per_launch") or 0) / (MFMA_PEAK_TFLOPS * 1e3) > float(r["algorithmic_MB_per_launch"]) / (HBM_PEAK_GBS * 1e3)
         return {"kernel": r["kernel"], "calls": int(r["calls"]), "avg_us": float(r["avg_us"]),
                 "share_of_stage_kernel_time": round(float(r["total_ms"]) / max(sum(float(q["total_ms"]) for q in rows), 1e-9), 3),
                 "frac": float(r["frac_of_2.5PFLOPs"]) if mf else float(r["frac_of_8TBps"]),
