@@ -48,7 +48,12 @@ struct GemmGeom {
 // holds ALL output channels of its 128 pixels (gy == 1: cout <= BN), so out2 = relu(W2 . tile + b2) needs nothing else: B operand =
 // 16-byte reads of s_out rows (the k order of the 1x1's regular pack), A = that pack from global, result back into s_out and out
 // through the same coalesced sweep.  The 3x3's output is never written: one launch and one tensor round trip less per block.
-template <int LM, bool KS3, int PN, bool NC4, bool CH2 = false>
+// AD: k-steps the weight fragments run ahead of their MFMAs.  1 (two register buffers) for launches that fill the chip -- three
+// workgroups per CU hide the L2 round trip by themselves, and the registers of a deeper ring would cost the third one (round 6:
+// two steps ahead everywhere was 5 % SLOWER).  3 (a ring of four; 2 where the load mode's staging registers leave no room) for the launches that cannot: the deep levels at batch 32 run one
+// or two workgroups per CU, and the in-kernel stamps show their k-steps taking 467 ns for 115 ns of MFMA -- every step waited for
+// the fragment requested one step earlier (tests/gpu_probe/stamps.py, Cityscapes alpha 2: 16 stages of 4.2 us in a 256-workgroup dgrad).
+template <int LM, bool KS3, int PN, bool NC4, bool CH2 = false, int AD = 1>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGeom gm) {
     constexpr int NT = 256, PM = G_PM, WN = G_WN, TH = G_TH;
     constexpr int BN = 16 * PN * WN;
@@ -127,22 +132,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     };
 
     // ---- operands ------------------------------------------------------------------------------------------------------
-    // Weight fragments: address = (wave-uniform base of channel tile m at k-step F) + lane * 16 -- scalar base, constant lane
-    // offset: no vector address arithmetic in the k-loop
+    // Weight fragments through a BUFFER load: resource = the packed weights (scalar registers), scalar offset = channel tile m at
+    // k-step F, vector offset = lane * 16 -- `buffer_load_dwordx4 v, v_lane16, s[rsrc], s_off offen`: no vector address arithmetic in
+    // the k-loop.  (Written as pointer arithmetic the compiler formed a 64-bit VECTOR address per fragment and k-step -- v_lshl_add_u64
+    // into the fragment's own destination registers, each behind an s_waitcnt vmcnt for the load still in flight there: round 6.)
     const int ct0 = by * (BN / 16);
     const int wn_u = __builtin_amdgcn_readfirstlane(wn);
-    const char *wu[PN];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16 *>(a.wpk), 0, 0x7fffffff, 0x00020000);
+    int wso[PN];
 #pragma unroll
     for (int m = 0; m < PN; ++m) {
         int ct = ct0 + wn_u * PN + m;
         if (ct >= gm.mt_total) ct = gm.mt_total - 1;     // padding tiles of the last group: computed, never stored
-        wu[m] = reinterpret_cast<const char *>(a.wpk) + (size_t)ct * ns_total * 1024;
+        wso[m] = ct * ns_total * 1024;                   // < 2^31: the widest pack (512 x 512 x 9 fp16) is 4.7 MB
     }
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const int lane16 = lane * 16;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     auto loadA = [&](f16x8 (&af)[PN], int F) {
-        const size_t fo = (size_t)min(F, ns_total - 1) * 1024;
+        const int fo = min(F, ns_total - 1) * 1024;
 #pragma unroll
-        for (int m = 0; m < PN; ++m) af[m] = *reinterpret_cast<const f16x8 *>(wu[m] + fo + lane16);
+        for (int m = 0; m < PN; ++m) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, wso[m] + fo, 0);
+            af[m] = __builtin_bit_cast(f16x8, v);
+        }
     };
     int base[PM];
 #pragma unroll
@@ -161,11 +173,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
 
     const int n_stage = gm.n_stage;
     issue(0);
-    f16x8 a0[PN], a1[PN];
-    loadA(a0, 0);
+    f16x8 af[AD + 1][PN];                                // ring of weight-fragment buffers: fragment i lives in slot i % (AD + 1)
+    f16x8 (&a0)[PN] = af[0], (&a1)[PN] = af[1];
+    if constexpr (AD == 1) loadA(af[0], 0);
     __syncthreads();                                     // affine table visible
     commit(0, s_tile0);
     issue(min(1, n_stage - 1));
+    if constexpr (AD > 1) {
+        // the ring is filled BEHIND the second tile's requests, as in every later stage: the first stage's wait for that tile is then
+        // "all but the ring's AD x PN loads" like everyone else's (requested in front of them it had to be vmcnt(0) on the path into
+        // the loop, and the compiler's merged count for the loop's top drained the ring at EVERY stage)
+#pragma unroll
+        for (int i = 0; i < AD; ++i) loadA(af[i], i);
+    }
     __syncthreads();
     IMK_STAMP(1);
     const int mg_q = (65536 + nc8p - 1) / nc8p;          // q / nc8p as multiply-shift (q < 40)
@@ -178,7 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
     // written as zeros), so NC4 needs no validity masks.
     auto run_stage = [&](int st, const uint8_t *cur) {
         const int np = min(spp, gm.n_pass - st * spp);   // passes of this stage
-        const int nk = np * nsp;                         // k-steps
+        // k-steps.  A 3x3 with 4 chunks per pass has ONE pass per stage of exactly 9 steps (tap s = step s): a compile-time count, so the
+        // deep-look-ahead form's stage body is straight-line code and the compiler can count the loads in flight exactly -- behind a
+        // loop of unknown length its s_waitcnt for the NEXT stage's staged tile was vmcnt(0), which drained the weight ring every stage
+        constexpr bool NK9 = KS3 && NC4 && AD > 1;
+        const int nk = NK9 ? 9 : np * nsp;
         int pi = 0, s = 0;                               // (pass in stage, step in pass) of the next pixel-operand read
         int bg[PM];
 #pragma unroll
@@ -200,6 +224,64 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ImkConvArgs a, GemmGe
             for (int p = 0; p < PM; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(cur + bg[p] + off);
             if (++s == nsp) { s = 0; ++pi; }
         };
+        if constexpr (AD > 1) {
+            // Ring of NA = AD + 1 buffers.  Fragment r of the stage (r = 0: its first k-step) lives in slot r % NA; slots 0 .. AD - 1 hold
+            // fragments 0 .. AD - 1 on entry.  Step j requests fragment j + AD into the slot step j - 1 has just consumed.  On exit the
+            // next stage's first AD fragments sit in slots nk % NA ...: one register rotation per stage (a few dozen moves for a stage's
+            // 144 MFMAs).  Unrolled by lcm(NA, 2) so that every slot and the pixel operand's double buffer are compile-time names.
+            constexpr int NA = AD + 1, U = (NA % 2 == 0) ? NA : 2 * NA;
+            f16x8 bb[2][PM];
+            loadB(bb[0]);
+            // whole groups of U steps without a branch inside (the compiler counts the loads in flight exactly only on straight-line
+            // code: with a conditional step in the group its s_waitcnt assumed the shortest path and drained the ring), then the
+            // remainder as a NEST of conditions, so that step u + 1 is only reachable through step u
+            auto step = [&](auto U_T, int f) {
+                constexpr int u = decltype(U_T)::value;
+                loadA(af[(u + AD) % NA], F + f + u + AD);
+                loadB(bb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);       // the requests first, THEN the step's MFMAs (the scheduler sank the LDS reads to
+                mma(af[u % NA], bb[u & 1]);              // their uses to save registers: four exposed LDS round trips per step)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int f = 0;
+            for (; f + U <= nk; f += U) {
+                step(std::integral_constant<int, 0>{}, f); step(std::integral_constant<int, 1>{}, f);
+                step(std::integral_constant<int, 2>{}, f); step(std::integral_constant<int, 3>{}, f);
+                if constexpr (U == 6) { step(std::integral_constant<int, 4>{}, f); step(std::integral_constant<int, 5>{}, f); }
+            }
+            const int rem = nk - f;
+            if (rem >= 1) {
+                step(std::integral_constant<int, 0>{}, f);
+                if (rem >= 2) {
+                    step(std::integral_constant<int, 1>{}, f);
+                    if (rem >= 3) {
+                        step(std::integral_constant<int, 2>{}, f);
+                        if constexpr (U == 6) {
+                            if (rem >= 4) {
+                                step(std::integral_constant<int, 3>{}, f);
+                                if (rem >= 5) step(std::integral_constant<int, 4>{}, f);
+                            }
+                        }
+                    }
+                }
+            }
+            const int rot = nk % NA;                     // workgroup-uniform
+#pragma unroll
+            for (int r = 1; r < NA; ++r) {
+                if (rot == r) {
+#pragma unroll
+                    for (int m = 0; m < PN; ++m) {
+                        f16x8 t[NA];
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) t[i] = af[i][m];
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) af[i][m] = t[(i + r) % NA];
+                    }
+                }
+            }
+            F += nk;
+            return;
+        }
         f16x8 b0[PM], b1[PM];
         loadB(b0);
         // (Round 6, measured and removed: weight fragments TWO k-steps ahead of their MFMAs -- three register buffers, loads stopped
@@ -448,8 +530,36 @@ int plan_conv_gemm(const ImkConvArgs &a, GemmGeom &gm, int &pn, size_t &lds, int
     return IMK_OK;
 }
 
+// launches of at most this many workgroups take the deep-look-ahead form (AD > 1): few workgroups per compute unit are resident,
+// nothing else hides the weight fragments' L2 round trip (IMK_GEMM_AD3_WGS; 0 = never).  Measured on one box (profiles/r06_ab_ad3.txt),
+// training step old -> 512 / 1 024 / 1 600 / 6 000: ISIC 0.958 -> 0.930 / 0.936 / 0.943 / 0.936 ms, SUIM 1.630 -> 1.593 / 1.593 / 1.600 /
+// 1.596, HeLa 1.61 -> 1.588 / 1.584 / 1.593 / 1.592, EvalNet 2.04 -> 2.004 / 1.997 / 1.997 / 1.995, Cityscapes alpha 2 4.63 -> 4.618 /
+// 4.616 / 4.608 / 4.613, alpha 1.25 3.61 -> 3.619 / 3.619 / 3.618 / 3.677: bit-identical everywhere
+int gemm_ad3_max_wgs() {
+    static const int v = []() { const char *e = getenv("IMK_GEMM_AD3_WGS"); return e ? atoi(e) : 1024; }();
+    return v;
+}
+
+// ring depth of the deep-look-ahead form per load mode: what fits 256 registers without scratch (pool / upsample + add on load hold
+// 4 / 2 raw chunks per staged item)
+// (a 3x3 stage of 9 k-steps takes the ring of THREE: 9 % 3 == 0, the ring needs no rotation at the stage's end -- a rotation moves
+// registers whose loads are still in flight, i.e. waits for them)
+template <int LM, bool KS3, bool NC4> constexpr int gemm_deep_ad() { return (KS3 && NC4) || LM == LM_POOL || LM == LM_UPADD ? 2 : 3; }
+
 template <int LM>
 int launch_conv_gemm_chain(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t lds, int grid, hipStream_t stream) {
+    if (grid <= gemm_ad3_max_wgs()) {
+        if (gm.nc8p == 4) {
+            constexpr int AD = gemm_deep_ad<LM, true, true>();
+            if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, true, 4, true, true, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+            else imk_klaunch(conv_gemm_kernel<LM, true, 2, true, true, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+        } else {
+            constexpr int AD = gemm_deep_ad<LM, true, false>();
+            if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, true, 4, false, true, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+            else imk_klaunch(conv_gemm_kernel<LM, true, 2, false, true, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+        }
+        return IMK_OK;
+    }
     if (gm.nc8p == 4) {
         if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, true, 4, true, true>, dim3(grid), dim3(256), lds, stream, a, gm);
         else imk_klaunch(conv_gemm_kernel<LM, true, 2, true, true>, dim3(grid), dim3(256), lds, stream, a, gm);
@@ -462,6 +572,18 @@ int launch_conv_gemm_chain(const ImkConvArgs &a, const GemmGeom &gm, int pn, siz
 
 template <int LM, bool KS3>
 int launch_conv_gemm_k(const ImkConvArgs &a, const GemmGeom &gm, int pn, size_t lds, int grid, hipStream_t stream) {
+    if (grid <= gemm_ad3_max_wgs()) {
+        if (gm.nc8p == 4) {
+            constexpr int AD = gemm_deep_ad<LM, KS3, true>();
+            if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, KS3, 4, true, false, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+            else imk_klaunch(conv_gemm_kernel<LM, KS3, 2, true, false, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+        } else {
+            constexpr int AD = gemm_deep_ad<LM, KS3, false>();
+            if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, KS3, 4, false, false, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+            else imk_klaunch(conv_gemm_kernel<LM, KS3, 2, false, false, AD>, dim3(grid), dim3(256), lds, stream, a, gm);
+        }
+        return IMK_OK;
+    }
     if (gm.nc8p == 4) {      // 4 chunks per pass: scalar tile offsets in the k-loop
         if (pn == 4) imk_klaunch(conv_gemm_kernel<LM, KS3, 4, true>, dim3(grid), dim3(256), lds, stream, a, gm);
         else imk_klaunch(conv_gemm_kernel<LM, KS3, 2, true>, dim3(grid), dim3(256), lds, stream, a, gm);

@@ -12,12 +12,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     from inconsistencymasks_amd import build as B
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objs, procs = [], []
-    for s in sorted(glob.glob(os.path.join(B.CSRC, "*.hip"))):
+    for s in sorted(glob.glob(os.path.join(B.CSRC, "*.hip")) + glob.glob(os.path.join(B.CSRC, "*.cpp"))):      # (.cpp: the host PNG codec / geometry)
         o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ".o")
         objs.append(o)
-        procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + ["-DIMK_STAMPS", "-c", s, "-o", o]))
+        procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + ["-DIMK_STAMPS"] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]))
     assert all(p.wait() == 0 for p in procs)
-    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lz"])
     print(OUT)
     sys.exit(0)
 
