@@ -111,6 +111,11 @@ B x {r['by_stage']['training'].get('per_image_us')} us, the stage at {r['by_stag
             continue
         r = d["roofline"]
         t = r["by_stage"]["training"]
+        if r.get("traffic_over_algorithmic") is None:      # (the per-configuration ratio files were written after these lines were cut)
+            fr = [x for x in csv.reader(open(os.path.join(HERE, f"{R}_traffic_vs_algorithmic{tag}.csv"))) if x and x[0].startswith("FAMILY")] \
+                if os.path.exists(os.path.join(HERE, f"{R}_traffic_vs_algorithmic{tag}.csv")) else []
+            if fr:
+                r = dict(r, traffic_over_algorithmic=f"{fr[0][4]} (`{R}_traffic_vs_algorithmic{tag}.csv`)")
         out.append(f"| {name} | {d['value']:.0f} | {d['ms_per_step']} | {d['stage_ms']['ensemble_infer_plus_im']} | {d['stage_ms']['train_epoch']} ({d['config']['epoch_steps']} x {t.get('step_ms')}) | "
                    f"`{r['kernel']}` {r['achieved']} {r['unit']} = {r['frac']} ({r['bound']}) | {r.get('frac_rocprof')} / {r.get('frac_rocprof_union')} | {r.get('traffic_over_algorithmic')} | {(d.get('cpu_baseline') or {}).get('value', '-')} |")
     out.append("\n(`frac by rocprofv3` and `traffic` are `null` in the collection's own plain runs -- the files they replay are installed afterwards; the union / sum "
