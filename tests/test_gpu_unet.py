@@ -828,3 +828,22 @@ def test_decoder_first_stage_matches_its_own_launch(tmp_path):
             assert np.array_equal(got[0]["params%d" % i], got[1]["params%d" % i])
             assert np.array_equal(got[0]["last%d" % i], got[1]["last%d" % i]), (seed, i, int((got[0]["last%d" % i] != got[1]["last%d" % i]).sum()))
             assert np.array_equal(got[0]["probs%d" % i], got[1]["probs%d" % i]), (seed, i)
+
+
+@pytest.mark.parametrize("config,alpha", [("suim", "1"), ("city", "2")])
+def test_conv_gemm_look_ahead_forms_agree(config, alpha):
+    """The GEMM-class kernel has two forms of its k-loop (csrc/imk_gemm.hip: two fragment buffers for launches that fill the chip, a ring
+    of three / four with a straight-line 9-step stage for launches of at most IMK_GEMM_AD3_WGS = 1 024 workgroups).  Same arithmetic,
+    same k order: forced to one form and to the other (a child process each: the switch is read once), a batch-32 step at real size must
+    give bit-identical probabilities, stored activations, every layer's gradient and the parameters after the step."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for wgs in ("0", "100000"):
+        env = {**os.environ, "CONFIG": config, "ALPHA": alpha, "IMK_GEMM_AD3_WGS": wgs}
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_probe", "lib_ab.py")], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("probs", "act", "grad", "grads", "params", "stats")])
+    assert len(outs[0]) > 40 and outs[0] == outs[1]
