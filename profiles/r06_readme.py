@@ -82,6 +82,7 @@ def main():
 | `r06_sq_counters_{isic,cityscapes_a2}.csv` | SQ counters per kernel (what the waves do with their cycles; `by_stage.inference.bound` quotes them) |
 | `r06_ab_wgrad_splits.txt`, `r06_ab_adepth.txt`, `r06_ab_family_sweep.txt` | raw output of the round's one-box A/B runs (notes, section 3) |
 | `r06_full_driver_run_par{2,3,4,5}.txt`, `r06_full_driver_run_par{3,4}_epoch_turns.txt` | the real-size ISIC generation with 2-5 candidates side by side, one fresh box each, and with all five started and epochs taking turns (notes, section 4) |
+| `r06_bench_repeats.txt`, `r06_full_driver_run_five_generations.txt` | the default bench command five times in a row on one box, final build (25.29-25.56 k images/s, +-0.5 %); the real-size ISIC driver over generations 0-4 (25 candidates x 50 epochs through PNG directories, three side by side): 77.3 s (round 5: 79.7 s) |
 | `r06_final_check_*` | `tests/gpu_probe/final_check.sh` on the round's last commit: `pytest -m gpu`, `smoke()`, the driver's bench command (its last stdout line, parsed), 2- and 8-rank functional lines |
 """)
     b, bd = load(f"{R}_bench.json"), load(f"{R}_bench_detail.json")
